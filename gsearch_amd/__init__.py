@@ -1,0 +1,9 @@
+"""gsearch_amd — MI355X-native (gfx950) sketch-and-query hot path of gsearch behind a C ABI.
+
+See DESIGN.md / SPEC.md / INTEGRATION.md. Importing the package does not need a GPU; the first call
+that touches the device does, and fails loudly otherwise (no CPU fallback).
+"""
+from ._lib import ALGO, DATA, GsError, SO_PATH, SYMBOLS, load  # noqa: F401
+from .api import (Context, DistHamming, Hnsw, Neighbour, OptDensHashSketch, ProbHash3aSketch,  # noqa: F401
+                  RevOptDensHashSketch, SeqSketcherParams, SuperHash2Sketch, SuperHashSketch, ani,
+                  default_context, filter_aa_records, pack_dna_records, sketcher_for)

@@ -1,0 +1,411 @@
+"""Host-side mirror of the reference's operator interface for the sketch-and-query hot path.
+
+Names and argument meaning follow the Rust traits gsearch calls (paths relative to /root/reference):
+
+* ``SeqSketcherParams`` / ``*HashSketch.new(params)`` / ``sketch_compressedkmer`` / ``sketch_compressedkmer_seqs``
+  — kmerutils::sketching::setsketchert::SeqSketcherT, called at src/dna/dnasketch.rs:336,357,
+  src/dna/dnarequest.rs:272,287, src/aa/aasketch.rs:313,329.
+* ``DistHamming.eval`` — anndists::dist::DistHamming (src/dna/dnasketch.rs:72, src/bin/bindash.rs:93-99).
+* ``Hnsw.new / modify_level_scale / set_extend_candidates / set_keeping_pruned / parallel_insert /
+  parallel_search / get_nb_point`` — hnsw_rs::Hnsw (src/dna/dnasketch.rs:139-141,159-160,435; src/dna/dnarequest.rs:353).
+
+Everything here is a thin ctypes shell over the C ABI (include/gsearch_amd.h); the arithmetic runs in the
+HIP library. There is no CPU fallback.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALGO, DATA, KIND_F32, KIND_U16, KIND_U32, KIND_U64, GsError, IndexParams, SketchParams, check
+
+KIND_DTYPE = {KIND_U16: np.dtype(np.uint16), KIND_U32: np.dtype(np.uint32), KIND_U64: np.dtype(np.uint64),
+              KIND_F32: np.dtype(np.float32)}
+DTYPE_KIND = {v: k for k, v in KIND_DTYPE.items()}
+
+Neighbour = namedtuple("Neighbour", ["d_id", "distance"])   # hnsw_rs::Neighbour fields gsearch reads (answer.rs:42,55-57)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One per (process, GPU): owns the HIP stream all calls are enqueued on."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        check(self.L.gs_ctx_create(C.byref(h), device_id, stream))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gs_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.L.gs_ctx_sync(self.h))
+
+    def device_info(self):
+        ncu, hbm, name = C.c_int(), C.c_uint64(), C.create_string_buffer(128)
+        check(self.L.gs_ctx_device_info(self.h, C.byref(ncu), C.byref(hbm), name, 128))
+        return {"n_cu": ncu.value, "hbm_bytes": hbm.value, "name": name.value.decode()}
+
+    # stopwatch / per-family kernel timers (HIP events on the context's stream)
+    def timer_start(self):
+        check(self.L.gs_ctx_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.L.gs_ctx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile(self, enable=True):
+        check(self.L.gs_ctx_profile(self.h, int(enable)))
+
+    def profile_read(self, family, reset=True):
+        ms, n = C.c_double(), C.c_uint64()
+        check(self.L.gs_ctx_profile_read(self.h, family, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    # device memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.L.gs_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        check(self.L.gs_dev_free(self.h, ptr))
+
+    def upload(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.L.gs_dev_upload(self.h, ptr, _p(arr), arr.nbytes))
+
+    def download(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        check(self.L.gs_dev_download(self.h, _p(out), ptr, out.nbytes))
+        return out
+
+    def memset(self, ptr, byte, nbytes):
+        check(self.L.gs_dev_memset(self.h, ptr, byte, nbytes))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ----------------------------------------------------------------------------------------------------------
+class SeqSketcherParams:
+    """kmerutils::sketcharg::SeqSketcherParams::new(kmer_size, sketch_size, algo, data_t) (gsearch.rs:258-263)."""
+
+    def __init__(self, kmer_size, sketch_size, algo, data_t="dna"):
+        self.c = SketchParams(int(kmer_size), int(sketch_size), ALGO[algo] if isinstance(algo, str) else int(algo),
+                              DATA[data_t] if isinstance(data_t, str) else int(data_t))
+        check(_lib.load().gs_check_params(C.byref(self.c)))
+
+    def get_kmer_size(self):
+        return self.c.k
+
+    def get_sketch_size(self):
+        return self.c.sketch_size
+
+    def sig_kind(self):
+        return _lib.load().gs_sig_kind(C.byref(self.c))
+
+    def sig_dtype(self):
+        return KIND_DTYPE[self.sig_kind()]
+
+
+def pack_dna_records(records):
+    """ASCII records -> (packed 2-bit buffer, rec_start, rec_len); each record starts on a byte boundary.
+    Same filtering as Sequence::encode_and_add (dnafiles.rs:70-71): non-ACGT dropped, case folded."""
+    L = _lib.load()
+    total = sum(len(r) for r in records) + 4 * len(records)
+    packed = np.zeros(total // 4 + 64, dtype=np.uint8)
+    starts = np.zeros(len(records), dtype=np.uint64)
+    lens = np.zeros(len(records), dtype=np.uint64)
+    off = 0
+    for i, r in enumerate(records):
+        a = np.frombuffer(r, dtype=np.uint8)
+        n = L.gs_pack_dna(_p(a) if len(a) else None, len(a), _p(packed), off)
+        starts[i], lens[i] = off, n
+        off += (n + 3) // 4 * 4
+    return packed[: (off + 3) // 4 + 8], starts, lens
+
+
+def filter_aa_records(records):
+    L = _lib.load()
+    outs = []
+    starts = np.zeros(len(records), dtype=np.uint64)
+    lens = np.zeros(len(records), dtype=np.uint64)
+    off = 0
+    for i, r in enumerate(records):
+        a = np.frombuffer(r, dtype=np.uint8)
+        o = np.zeros(max(len(a), 1), dtype=np.uint8)
+        n = L.gs_filter_aa(_p(a) if len(a) else None, len(a), _p(o))
+        outs.append(o[:n])
+        starts[i], lens[i] = off, n
+        off += n
+    seq = np.concatenate(outs) if outs else np.zeros(0, np.uint8)
+    return np.concatenate([seq, np.zeros(8, np.uint8)]), starts, lens
+
+
+class _SeqSketcher:
+    """Common shell of the SeqSketcherT implementations. A genome is a list of records (ASCII bytes)."""
+    ALGO_NAME = None
+
+    def __init__(self, params, ctx=None):
+        if self.ALGO_NAME is not None and params.c.algo != ALGO[self.ALGO_NAME]:
+            raise GsError(_lib.GS_ERR_INVALID, "params.algo does not match %s" % type(self).__name__)
+        self.params = params
+        self.ctx = ctx or default_context()
+
+    @classmethod
+    def new(cls, params, ctx=None):
+        return cls(params, ctx)
+
+    def sig_dtype(self):
+        return self.params.sig_dtype()
+
+    def sketch_packed(self, seq, rec_start, rec_len, genome_rec_off):
+        """Lowest level: already packed input (the layout of include/gsearch_amd.h gs_sketch_batch)."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        rec_start = np.ascontiguousarray(rec_start, dtype=np.uint64)
+        rec_len = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        goff = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
+        ng = len(goff) - 1
+        out = np.zeros((ng, self.params.c.sketch_size), dtype=self.sig_dtype())
+        check(self.ctx.L.gs_sketch_batch(self.ctx.h, C.byref(self.params.c), _p(seq), seq.nbytes, _p(rec_start), _p(rec_len),
+                                         len(rec_start), _p(goff), ng, _p(out)))
+        return out
+
+    def _pack(self, records):
+        if self.params.c.data_t == DATA["dna"]:
+            return pack_dna_records(records)
+        return filter_aa_records(records)
+
+    def sketch_compressedkmer_seqs(self, vseq):
+        """All sequences are ONE genome -> exactly one signature (assert at dnasketch.rs:359)."""
+        seq, rs, rl = self._pack(list(vseq))
+        return [row for row in self.sketch_packed(seq, rs, rl, np.array([0, len(rs)], dtype=np.uint64))]
+
+    def sketch_compressedkmer(self, vseq):
+        """One signature per input sequence, in input order (assert at dnasketch.rs:338)."""
+        seq, rs, rl = self._pack(list(vseq))
+        return [row for row in self.sketch_packed(seq, rs, rl, np.arange(len(rs) + 1, dtype=np.uint64))]
+
+    def sketch_genomes(self, genomes):
+        """Batch form used by the drivers: genomes = list of lists of records -> (n_genomes, m) array."""
+        recs, goff = [], [0]
+        for g in genomes:
+            recs.extend(g)
+            goff.append(len(recs))
+        seq, rs, rl = self._pack(recs)
+        return self.sketch_packed(seq, rs, rl, np.array(goff, dtype=np.uint64))
+
+
+class OptDensHashSketch(_SeqSketcher):
+    ALGO_NAME = "optdens"
+
+
+class RevOptDensHashSketch(_SeqSketcher):
+    ALGO_NAME = "revoptdens"
+
+
+class ProbHash3aSketch(_SeqSketcher):
+    ALGO_NAME = "prob"
+
+
+class SuperHashSketch(_SeqSketcher):
+    ALGO_NAME = "super"
+
+
+class SuperHash2Sketch(_SeqSketcher):
+    ALGO_NAME = "super2"
+
+
+def sketcher_for(params, ctx=None):
+    """(algo) dispatch of dna_process_tohnsw (dnasketch.rs:493-644)."""
+    table = {ALGO["optdens"]: OptDensHashSketch, ALGO["revoptdens"]: RevOptDensHashSketch, ALGO["prob"]: ProbHash3aSketch,
+             ALGO["super"]: SuperHashSketch, ALGO["super2"]: SuperHash2Sketch}
+    return table[params.c.algo](params, ctx)
+
+
+# ----------------------------------------------------------------------------------------------------------
+class DistHamming:
+    """anndists::dist::DistHamming — eval(a, b) = count(a[i] != b[i]) / len, f32."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def eval(self, va, vb):
+        va = np.ascontiguousarray(va)
+        vb = np.ascontiguousarray(vb, dtype=va.dtype)
+        return float(self.eval_qxc(va[None, :], vb[None, :])[0, 0])
+
+    def eval_qxc(self, Q, Cm):
+        Q = np.ascontiguousarray(Q)
+        Cm = np.ascontiguousarray(Cm, dtype=Q.dtype)
+        if Q.shape[1] != Cm.shape[1]:
+            raise GsError(_lib.GS_ERR_INVALID, "signature lengths differ")
+        out = np.zeros((Q.shape[0], Cm.shape[0]), dtype=np.float32)
+        check(self.ctx.L.gs_hamming_qxc(self.ctx.h, DTYPE_KIND[Q.dtype], Q.shape[1], _p(Q), Q.shape[0], _p(Cm), Cm.shape[0], _p(out)))
+        return out
+
+    def eval_pairs(self, A, B, ia, ib):
+        A = np.ascontiguousarray(A)
+        B = np.ascontiguousarray(B, dtype=A.dtype)
+        ia = np.ascontiguousarray(ia, dtype=np.uint64)
+        ib = np.ascontiguousarray(ib, dtype=np.uint64)
+        out = np.zeros(len(ia), dtype=np.float32)
+        check(self.ctx.L.gs_hamming_pairs(self.ctx.h, DTYPE_KIND[A.dtype], A.shape[1], _p(A), A.shape[0], _p(B), B.shape[0],
+                                          _p(ia), _p(ib), len(ia), _p(out)))
+        return out
+
+
+def ani(distance, kmer_size, model=1):
+    """reformat.rs:80-86 calculate_ani."""
+    return _lib.load().gs_ani(float(distance), int(kmer_size), int(model))
+
+
+# ----------------------------------------------------------------------------------------------------------
+class Hnsw:
+    """hnsw_rs::Hnsw<Sig, DistHamming> as gsearch uses it."""
+
+    def __init__(self, max_nb_connection, max_elements, max_layer, ef_construction, dist_f=None, dtype=np.float32,
+                 sketch_size=None, seed=0, insert_batch=0, ctx=None):
+        self.ctx = ctx or (dist_f.ctx if dist_f is not None else default_context())
+        self.prm = IndexParams(DTYPE_KIND[np.dtype(dtype)], int(sketch_size or 0), int(max_nb_connection), int(max_elements),
+                               int(max_layer), int(ef_construction), 1.0, 0, 0, int(seed), int(insert_batch))
+        self.dtype = np.dtype(dtype)
+        self.h = None
+
+    @classmethod
+    def new(cls, max_nb_connection, max_elements, max_layer, ef_construction, dist_f=None, **kw):
+        return cls(max_nb_connection, max_elements, max_layer, ef_construction, dist_f, **kw)
+
+    # setters are only legal before the first point, like the reference's use (dnasketch.rs:141,159-160)
+    def modify_level_scale(self, scale_modification):
+        self._frozen_check()
+        self.prm.scale_modify = float(scale_modification)
+
+    def set_extend_candidates(self, flag):
+        self._frozen_check()
+        self.prm.extend_candidates = int(bool(flag))
+
+    def set_keeping_pruned(self, flag):
+        self._frozen_check()
+        self.prm.keep_pruned = int(bool(flag))
+
+    def _frozen_check(self):
+        if self.h is not None:
+            raise GsError(_lib.GS_ERR_STATE, "index parameters are frozen once the index holds points")
+
+    def _ensure(self, m):
+        if self.h is None:
+            if self.prm.m == 0:
+                self.prm.m = int(m)
+            h = C.c_void_p()
+            check(self.ctx.L.gs_index_create(self.ctx.h, C.byref(self.prm), C.byref(h)))
+            self.h = h
+        if int(m) != self.prm.m:
+            raise GsError(_lib.GS_ERR_INVALID, "signature length %d != index length %d" % (m, self.prm.m))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.gs_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_nb_point(self):
+        return 0 if self.h is None else self.ctx.L.gs_index_nb_point(self.h)
+
+    def parallel_insert(self, datas):
+        """datas: (n, m) array, or list of (vector, id) like the reference (ids must be nb_point.. in order)."""
+        if isinstance(datas, (list, tuple)) and len(datas) and isinstance(datas[0], tuple):
+            base = self.get_nb_point()
+            for i, (_, did) in enumerate(datas):
+                if did != base + i:
+                    raise GsError(_lib.GS_ERR_INVALID, "ids must continue the index in order (dnasketch.rs:429-433)")
+            datas = np.stack([d for d, _ in datas])
+        datas = np.ascontiguousarray(datas, dtype=self.dtype)
+        self._ensure(datas.shape[1])
+        check(self.ctx.L.gs_index_parallel_insert(self.h, _p(datas), datas.shape[0]))
+
+    def search_arrays(self, datas, knbn, ef):
+        datas = np.ascontiguousarray(datas, dtype=self.dtype)
+        if self.h is None:
+            raise GsError(_lib.GS_ERR_STATE, "search on an empty index")
+        nq = datas.shape[0]
+        ids = np.zeros((nq, knbn), dtype=np.uint64)
+        dist = np.zeros((nq, knbn), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        ev = np.zeros(nq, dtype=np.uint64)
+        check(self.ctx.L.gs_index_parallel_search(self.h, _p(datas), nq, knbn, ef, _p(ids), _p(dist), _p(cnt), _p(ev)))
+        return ids, dist, cnt, ev
+
+    def parallel_search(self, datas, knbn, ef):
+        """-> Vec<Vec<Neighbour>>, ascending distance (dnarequest.rs:353)."""
+        ids, dist, cnt, _ = self.search_arrays(datas, knbn, ef)
+        return [[Neighbour(int(ids[i, j]), float(dist[i, j])) for j in range(int(cnt[i]))] for i in range(len(ids))]
+
+    def bruteforce_search(self, datas, knbn):
+        datas = np.ascontiguousarray(datas, dtype=self.dtype)
+        ids = np.zeros((datas.shape[0], knbn), dtype=np.uint64)
+        dist = np.zeros((datas.shape[0], knbn), dtype=np.float32)
+        check(self.ctx.L.gs_index_bruteforce_search(self.h, _p(datas), datas.shape[0], knbn, _p(ids), _p(dist)))
+        return ids, dist
+
+    # graph import/export in the library's dense layout (role of HnswIo::load_hnsw / file_dump)
+    def import_graph(self, sigs, g):
+        sigs = np.ascontiguousarray(sigs, dtype=self.dtype)
+        self._ensure(sigs.shape[1])
+        a = {k: np.ascontiguousarray(v) for k, v in g.items() if isinstance(v, np.ndarray)}
+        U = int(g["n_upper"])
+        check(self.ctx.L.gs_index_import(self.h, _p(sigs), sigs.shape[0], _p(a["levels"]), int(g["entry"]), _p(a["deg0"]),
+                                         _p(a["nbr0"]), _p(a["cnt0"]), _p(a["upidx"]), U,
+                                         _p(a["degU"]) if U else None, _p(a["nbrU"]) if U else None, _p(a["cntU"]) if U else None))
+
+    def export_graph(self):
+        n = self.get_nb_point()
+        M, ML = self.prm.max_nb_conn, self.prm.max_layer
+        levels = np.zeros(n, np.uint8)
+        entry = np.zeros(1, np.int64)
+        nup = np.zeros(1, np.uint64)
+        check(self.ctx.L.gs_index_export(self.h, None, _p(entry), None, None, None, None, _p(nup), None, None, None))
+        U = int(nup[0])
+        deg0, nbr0, cnt0 = np.zeros(n, np.uint32), np.zeros((n, 2 * M), np.uint32), np.zeros((n, 2 * M), np.uint32)
+        upidx = np.zeros(n, np.int32)
+        degU, nbrU, cntU = np.zeros((max(U, 1), ML), np.uint32), np.zeros((max(U, 1), ML, M), np.uint32), np.zeros((max(U, 1), ML, M), np.uint32)
+        check(self.ctx.L.gs_index_export(self.h, _p(levels), _p(entry), _p(deg0), _p(nbr0), _p(cnt0), _p(upidx), _p(nup),
+                                         _p(degU), _p(nbrU), _p(cntU)))
+        return dict(levels=levels, entry=int(entry[0]), deg0=deg0, nbr0=nbr0, cnt0=cnt0, upidx=upidx, n_upper=U,
+                    degU=degU[:U], nbrU=nbrU[:U], cntU=cntU[:U])
+
+    def get_data(self, first=0, n=None):
+        n = self.get_nb_point() - first if n is None else n
+        out = np.zeros((n, self.prm.m), dtype=self.dtype)
+        check(self.ctx.L.gs_index_get_data(self.h, first, n, _p(out)))
+        return out
+
+    def insert_evals(self):
+        return 0 if self.h is None else self.ctx.L.gs_index_insert_evals(self.h)

@@ -1,0 +1,298 @@
+// gs_ctx.hip — context, device-memory helpers, parameter tables, host-side helpers and the
+// synthetic-input generators of the C ABI (include/gsearch_amd.h).
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+#include "gs_internal.hpp"
+#include "gs_spec.hpp"
+
+namespace gs {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace gs
+
+extern "C" {
+
+const char *gs_last_error(void) { return gs::g_err; }
+const char *gs_version(void) { return "gsearch_amd 0.1 (gfx950)"; }
+
+int gs_ctx_create(gs_ctx **out, int device_id, void *stream)
+{
+    GS_REQUIRE(out, GS_ERR_INVALID, "gs_ctx_create: out is NULL");
+    int ndev = 0;
+    GS_HIP_CHECK(hipGetDeviceCount(&ndev));
+    GS_REQUIRE(ndev > 0 && device_id >= 0 && device_id < ndev, GS_ERR_HIP,
+               "gs_ctx_create: device %d not available (%d HIP devices visible)", device_id, ndev);
+    GS_HIP_CHECK(hipSetDevice(device_id));
+    gs_ctx *c = new gs_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    GS_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    c->n_cu = prop.multiProcessorCount;
+    c->hbm_bytes = prop.totalGlobalMem;
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { GS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    GS_HIP_CHECK(hipEventCreate(&c->t0));
+    GS_HIP_CHECK(hipEventCreate(&c->t1));
+    *out = c;
+    return GS_OK;
+}
+void gs_ctx_destroy(gs_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->prof) for (auto &p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+int gs_ctx_sync(gs_ctx *c)
+{
+    GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+void *gs_ctx_stream(gs_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int gs_ctx_device_info(gs_ctx *c, int *n_cu, uint64_t *hbm, char *name, size_t cap)
+{
+    GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    if (n_cu) *n_cu = c->n_cu;
+    if (hbm) *hbm = c->hbm_bytes;
+    if (name && cap) { strncpy(name, c->name, cap - 1); name[cap - 1] = 0; }
+    return GS_OK;
+}
+int gs_ctx_timer_start(gs_ctx *c)
+{
+    GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    GS_HIP_CHECK(hipEventRecord(c->t0, c->stream));
+    return GS_OK;
+}
+int gs_ctx_timer_stop(gs_ctx *c, float *ms)
+{
+    GS_REQUIRE(c && ms, GS_ERR_INVALID, "null argument");
+    GS_HIP_CHECK(hipEventRecord(c->t1, c->stream));
+    GS_HIP_CHECK(hipEventSynchronize(c->t1));
+    GS_HIP_CHECK(hipEventElapsedTime(ms, c->t0, c->t1));
+    return GS_OK;
+}
+int gs_ctx_profile(gs_ctx *c, int enable)
+{
+    GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    c->profile = enable != 0;
+    return GS_OK;
+}
+int gs_ctx_profile_read(gs_ctx *c, int family, double *total_ms, uint64_t *launches, int reset)
+{
+    GS_REQUIRE(c && family >= 0 && family < gs::FAM_COUNT, GS_ERR_INVALID, "bad family");
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    gs::ProfSlot &s = c->prof[family];
+    for (auto &p : s.pending) {
+        float ms = 0;
+        GS_HIP_CHECK(hipEventSynchronize(p.second));
+        GS_HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
+        s.total_ms += ms; s.launches++;
+        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+    }
+    s.pending.clear();
+    if (total_ms) *total_ms = s.total_ms;
+    if (launches) *launches = s.launches;
+    if (reset) { s.total_ms = 0; s.launches = 0; }
+    return GS_OK;
+}
+
+int gs_dev_alloc(gs_ctx *c, size_t bytes, void **p)
+{
+    GS_REQUIRE(c && p, GS_ERR_INVALID, "null argument");
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    GS_HIP_CHECK(hipMalloc(p, bytes ? bytes : 16));
+    return GS_OK;
+}
+int gs_dev_free(gs_ctx *c, void *p)
+{
+    GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    if (p) { GS_HIP_CHECK(hipStreamSynchronize(c->stream)); GS_HIP_CHECK(hipFree(p)); }
+    return GS_OK;
+}
+int gs_dev_upload(gs_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    GS_REQUIRE(c && (bytes == 0 || (dst && src)), GS_ERR_INVALID, "null argument");
+    if (bytes) {
+        GS_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return GS_OK;
+}
+int gs_dev_download(gs_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    GS_REQUIRE(c && (bytes == 0 || (dst && src)), GS_ERR_INVALID, "null argument");
+    if (bytes) {
+        GS_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return GS_OK;
+}
+int gs_dev_memset(gs_ctx *c, void *dst, int byte, size_t bytes)
+{
+    GS_REQUIRE(c && (bytes == 0 || dst), GS_ERR_INVALID, "null argument");
+    if (bytes) GS_HIP_CHECK(hipMemsetAsync(dst, byte, bytes, c->stream));
+    return GS_OK;
+}
+
+/* ---- parameter tables: (algo,k) dispatch of dnasketch.rs:493-644 / aasketch.rs:449-552 ---------- */
+int gs_check_params(const gs_sketch_params *p)
+{
+    GS_REQUIRE(p, GS_ERR_INVALID, "null params");
+    GS_REQUIRE(p->sketch_size >= 2, GS_ERR_INVALID, "sketch_size must be >= 2");
+    GS_REQUIRE(p->algo <= GS_ALGO_REVOPTDENS, GS_ERR_INVALID, "unknown sketch algo %u", p->algo);
+    GS_REQUIRE(p->algo != GS_ALGO_HLL, GS_ERR_UNSUPPORTED, "hll (SetSketch) is outside the accelerated path");
+    if (p->data_t == GS_DATA_DNA) {
+        GS_REQUIRE(p->k >= 1 && p->k <= 32, GS_ERR_INVALID, "DNA kmer size must be in 1..32");
+        GS_REQUIRE(p->k != 15, GS_ERR_INVALID, "kmer size 15 is rejected (dnarequest.rs:451-454)");
+    } else if (p->data_t == GS_DATA_AA) {
+        GS_REQUIRE(p->k >= 1 && p->k <= 12, GS_ERR_INVALID, "kmer for Amino Acids must be less or equal to 12");
+    } else {
+        GS_REQUIRE(false, GS_ERR_INVALID, "unknown data type %u", p->data_t);
+    }
+    return GS_OK;
+}
+int gs_value_bits(const gs_sketch_params *p)
+{
+    if (p->data_t == GS_DATA_DNA) return (p->k <= 14 || p->k == 16) ? 32 : 64;
+    return p->k <= 6 ? 32 : 64;
+}
+int gs_sig_kind(const gs_sketch_params *p)
+{
+    int vb = gs_value_bits(p);
+    switch (p->algo) {
+    case GS_ALGO_PROB3A: return vb == 32 ? GS_KIND_U32 : GS_KIND_U64;
+    case GS_ALGO_SUPER2: return vb == 32 ? GS_KIND_U32 : GS_KIND_U64;
+    case GS_ALGO_HLL: return GS_KIND_U16;
+    default: return GS_KIND_F32;
+    }
+}
+size_t gs_sig_elem_bytes(const gs_sketch_params *p) { return gs::kind_bytes(gs_sig_kind(p)); }
+
+/* ---- host helpers ----------------------------------------------------------------------------- */
+uint64_t gs_pack_dna(const uint8_t *ascii, uint64_t n, uint8_t *packed, uint64_t base_off)
+{
+    static const int8_t lut[256] = {
+#define X -1
+        X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,
+        X,0,X,1,X,X,X,2,X,X,X,X,X,X,X,X, X,X,X,X,3,X,X,X,X,X,X,X,X,X,X,X, X,0,X,1,X,X,X,2,X,X,X,X,X,X,X,X, X,X,X,X,3,X,X,X,X,X,X,X,X,X,X,X,
+        X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,
+        X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X, X,X,X,X,X,X,X,X,X,X,X,X,X,X,X,X
+#undef X
+    };
+    uint64_t w = base_off;
+    for (uint64_t i = 0; i < n; i++) {
+        int c = lut[ascii[i]];
+        if (c < 0) continue;
+        packed[w >> 2] |= (uint8_t)(c << (6 - 2 * (w & 3)));
+        w++;
+    }
+    return w - base_off;
+}
+static inline int aa_valid(uint8_t c)
+{
+    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+    switch (c) {
+    case 'A': case 'C': case 'D': case 'E': case 'F': case 'G': case 'H': case 'I': case 'K': case 'L':
+    case 'M': case 'N': case 'P': case 'Q': case 'R': case 'S': case 'T': case 'V': case 'W': case 'Y': return 1;
+    default: return 0;
+    }
+}
+uint64_t gs_filter_aa(const uint8_t *ascii, uint64_t n, uint8_t *out)
+{
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint8_t c = ascii[i];
+        if (!aa_valid(c)) continue;
+        if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+        out[w++] = c;
+    }
+    return w;
+}
+double gs_ani(double distance, int k, int model)
+{
+    double f = (1.0 - distance) * 2.0 / (1.0 - distance + 1.0);
+    if (model == 1) return (1.0 + log(f) / (double)k) * 100.0;
+    return pow(f, 1.0 / (double)k) * 100.0;
+}
+
+}  // extern "C"
+
+/* ---- synthetic inputs --------------------------------------------------------------------------- */
+namespace gs {
+__host__ __device__ inline uint64_t synth_word(uint64_t seed, uint64_t g, uint64_t w)
+{
+    return splitmix_mix(seed * 0x9e3779b97f4a7c15ULL + g * 0xbf58476d1ce4e5b9ULL + w);
+}
+__global__ void k_synth_dna(uint64_t seed, uint64_t g0, uint64_t ng, uint64_t words_per, uint64_t len, uint64_t *out)
+{
+    uint64_t total = ng * words_per;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t g = i / words_per, w = i % words_per;
+        uint64_t x = synth_word(seed, g0 + g, w);
+        uint64_t nb = len - w * 32;                     // bases in this word
+        if (nb < 32) {                                  // zero the bits past the end: bytes are stored little endian,
+            uint64_t be = __builtin_bswap64(x);         // base j of the word sits at bits 62-2j of the byte-swapped value
+            be &= ~(uint64_t)0 << (64 - 2 * nb);
+            x = __builtin_bswap64(be);
+        }
+        out[i] = x;
+    }
+}
+// row r, slot s. root = r / per_root. root value = f(seed, root, s); member keeps it with prob J(r).
+template <int KIND>
+__global__ void k_synth_sigs(uint32_t m, uint64_t seed, uint64_t r0, uint64_t nrows, uint64_t per_root, double jlo, double jhi, void *out)
+{
+    uint64_t total = nrows * (uint64_t)m;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = r0 + i / m, s = i % m;
+        uint64_t root = r / per_root;
+        double J = jlo + (jhi - jlo) * ((double)(splitmix_mix(seed + 0x1234567ULL * (r + 1)) >> 11) * 0x1.0p-53);
+        uint64_t rootv = splitmix_mix(seed ^ (root * 0xD1342543DE82EF95ULL + s * 0x2545F4914F6CDD1DULL + 1));
+        uint64_t coin = splitmix_mix(seed ^ (r * 0x9E3779B97F4A7C15ULL + s * 0xC2B2AE3D27D4EB4FULL + 7));
+        uint64_t ownv = splitmix_mix(coin + 0x5851F42D4C957F2DULL);
+        bool keep = ((double)(coin >> 11) * 0x1.0p-53) < J;
+        uint64_t v = keep ? rootv : ownv;
+        if (KIND == GS_KIND_F32) ((float *)out)[i] = (float)(uint32_t)(v >> 41) * 0x1.0p-23f;
+        else if (KIND == GS_KIND_U32) ((uint32_t *)out)[i] = (uint32_t)(v >> 32);
+        else ((uint64_t *)out)[i] = v;
+    }
+}
+}  // namespace gs
+
+extern "C" {
+int gs_synth_dna_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_t len, void *seq_dev)
+{
+    GS_REQUIRE(c && seq_dev, GS_ERR_INVALID, "null argument");
+    uint64_t wp = (len + 31) / 32;
+    if (ng * wp == 0) return GS_OK;
+    hipLaunchKernelGGL(gs::k_synth_dna, dim3(c->n_cu * 8), dim3(256), 0, c->stream, seed, g0, ng, wp, len, (uint64_t *)seq_dev);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+int gs_synth_sigs_dev(gs_ctx *c, int kind, uint32_t m, uint64_t seed, uint64_t r0, uint64_t nrows, uint64_t per_root,
+                      double jlo, double jhi, void *out)
+{
+    GS_REQUIRE(c && out && per_root > 0, GS_ERR_INVALID, "bad argument");
+    if (nrows == 0) return GS_OK;
+    dim3 g(c->n_cu * 8), b(256);
+    if (kind == GS_KIND_F32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_F32>, g, b, 0, c->stream, m, seed, r0, nrows, per_root, jlo, jhi, out);
+    else if (kind == GS_KIND_U32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U32>, g, b, 0, c->stream, m, seed, r0, nrows, per_root, jlo, jhi, out);
+    else if (kind == GS_KIND_U64) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U64>, g, b, 0, c->stream, m, seed, r0, nrows, per_root, jlo, jhi, out);
+    else GS_REQUIRE(false, GS_ERR_INVALID, "unsupported kind %d", kind);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+}

@@ -1,0 +1,614 @@
+// gs_index.hip — Hnsw<Sig, DistHamming> on gfx950 (SPEC.md 5).
+//
+// Replaces hnsw_rs::Hnsw::{new, parallel_insert, parallel_search} as gsearch drives them
+// (/root/reference/src/dna/dnasketch.rs:139-141,159-160,435; src/dna/dnarequest.rs:353; src/aa/aasketch.rs:407;
+// src/aa/aarequest.rs:344) with the DistHamming::eval inner loop (dnasketch.rs:72) fused in.
+//
+// Data layout in HBM: signature rows padded to a 256-byte stride (zero padded, so padding never mismatches);
+// layer-0 adjacency dense [n][2M] ids (+ mismatch counts), upper layers dense for the few nodes of level >= 1.
+//
+// Search kernel: ONE workgroup (1024 lanes) per query, persistent over a query queue. The candidate heap C and
+// the bounded result set R of Malkov's search_layer live in LDS as *sorted arrays* of 64-bit keys
+// (mismatch count << 32 | id) — the total order of SPEC 5. One iteration = pop the closest candidate, gather its
+// unvisited neighbours (visited bitmap in L2-resident global memory), evaluate all their distances at once
+// (the HBM-bound part: every 16-byte chunk of a candidate row is fetched exactly once, compared with
+// v_cmp + ballot/popcount against the query chunk held in registers), then apply the sequential accept rule of
+// search_layer in closed form and merge the accepted keys into R and C with one in-LDS parallel merge.
+#include <algorithm>
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include "gs_internal.hpp"
+#include "gs_spec.hpp"
+
+namespace gs {
+
+constexpr int ST = 1024;          // lanes per search workgroup
+constexpr int SMAXI = 16;         // staged keys per lane in a merge -> arrays up to 16384 keys
+constexpr int RIF = 8;            // candidate rows in flight per lane
+#define KEY(c, id) (((uint64_t)(c) << 32) | (uint64_t)(id))
+#define KCNT(k) ((uint32_t)((k) >> 32))
+#define KID(k) ((uint32_t)(k))
+#define INF_CNT 0xFFFFFFFFu
+
+struct IndexDev {
+    const uint8_t *data; uint64_t stride; uint32_t nchunks; uint32_t m;
+    uint32_t M, max_layer;
+    const uint8_t *levels; const uint32_t *deg0; const uint32_t *nbr0;
+    const int32_t *upidx; const uint32_t *degU; const uint32_t *nbrU;
+    uint64_t n; int64_t entry; int top;
+};
+
+struct SearchLds {              // carve-up of the dynamic LDS region
+    uint64_t *R, *C, *A;        // R[ef], C[capC], A[maxdeg]
+    uint32_t *Eid, *Ecnt;       // [maxdeg]
+    uint32_t *wsum;             // [ST/64]
+    uint64_t *scal;             // small scalars
+};
+__host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg)
+{
+    size_t capC = 2 * (size_t)ef + maxdeg + 64;
+    return 8 * (size_t)ef + 8 * capC + 8 * (size_t)maxdeg + 4 * (size_t)maxdeg * 2 + 4 * (ST / 64) + 8 * 8 + 64;
+}
+
+// number of keys in sorted a[0..n) that are < k
+__device__ __forceinline__ uint32_t lower_bound_keys(const uint64_t *a, uint32_t n, uint64_t k)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a[mid] < k) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// Merge sorted A[0..na) (na <= blockDim) into the sorted live range keys[head..n); the result starts at
+// keys[0] and is truncated to `keep`. All lanes call; returns the new length. Keys are unique.
+__device__ __forceinline__ uint32_t block_merge(uint64_t *keys, uint32_t head, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep)
+{
+    uint64_t kv[SMAXI]; uint32_t pos[SMAXI];
+    const uint32_t live = n - head;
+#pragma unroll
+    for (int it = 0; it < SMAXI; it++) {
+        uint32_t idx = threadIdx.x + it * ST;
+        pos[it] = 0xFFFFFFFFu; kv[it] = 0;
+        if (idx < live) { uint64_t k = keys[head + idx]; kv[it] = k; pos[it] = idx + lower_bound_keys(A, na, k); }
+    }
+    uint64_t ak = 0; uint32_t apos = 0xFFFFFFFFu;
+    if (threadIdx.x < na) { ak = A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(keys + head, live, ak); }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SMAXI; it++) if (pos[it] < keep) keys[pos[it]] = kv[it];
+    if (apos < keep) keys[apos] = ak;
+    __syncthreads();
+    uint32_t tot = live + na;
+    return tot < keep ? tot : keep;
+}
+
+template <int KIND>
+__device__ __forceinline__ uint32_t chunk_mismatch_wave(const uint4 &a, const uint4 &b, bool valid)
+{
+    // wave-uniform number of mismatching elements of this 16-byte chunk summed over the wavefront
+    if (KIND == GS_KIND_U64) {
+        bool n0 = valid && ((a.x != b.x) || (a.y != b.y));
+        bool n1 = valid && ((a.z != b.z) || (a.w != b.w));
+        return (uint32_t)__popcll(__ballot(n0)) + (uint32_t)__popcll(__ballot(n1));
+    } else if (KIND == GS_KIND_F32) {
+        bool n0 = valid && (__uint_as_float(a.x) != __uint_as_float(b.x));
+        bool n1 = valid && (__uint_as_float(a.y) != __uint_as_float(b.y));
+        bool n2 = valid && (__uint_as_float(a.z) != __uint_as_float(b.z));
+        bool n3 = valid && (__uint_as_float(a.w) != __uint_as_float(b.w));
+        return (uint32_t)__popcll(__ballot(n0)) + (uint32_t)__popcll(__ballot(n1)) + (uint32_t)__popcll(__ballot(n2)) + (uint32_t)__popcll(__ballot(n3));
+    } else {
+        bool n0 = valid && (a.x != b.x), n1 = valid && (a.y != b.y), n2 = valid && (a.z != b.z), n3 = valid && (a.w != b.w);
+        return (uint32_t)__popcll(__ballot(n0)) + (uint32_t)__popcll(__ballot(n1)) + (uint32_t)__popcll(__ballot(n2)) + (uint32_t)__popcll(__ballot(n3));
+    }
+}
+
+// Ecnt[e] = mismatch count between query row q and data row Eid[e], e < ne. All lanes call.
+template <int KIND>
+__device__ __forceinline__ void block_distances(const IndexDev &ix, const uint4 *__restrict__ q, const uint32_t *Eid, uint32_t ne, uint32_t *Ecnt)
+{
+    for (uint32_t e = threadIdx.x; e < ne; e += ST) Ecnt[e] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t j0 = 0; j0 < ix.nchunks; j0 += ST) {
+        const uint32_t ch = j0 + threadIdx.x;
+        const bool valid = ch < ix.nchunks;
+        if (j0 + (threadIdx.x & ~63u) >= ix.nchunks) break;          // whole wave past the row end
+        uint4 qv = make_uint4(0, 0, 0, 0);
+        if (valid) qv = q[ch];
+        for (uint32_t e0 = 0; e0 < ne; e0 += RIF) {
+            uint4 rv[RIF];
+#pragma unroll
+            for (int r = 0; r < RIF; r++) {
+                rv[r] = make_uint4(0, 0, 0, 0);
+                if (e0 + r < ne && valid) rv[r] = *(const uint4 *)(ix.data + (uint64_t)Eid[e0 + r] * ix.stride + (uint64_t)ch * 16);
+            }
+#pragma unroll
+            for (int r = 0; r < RIF; r++) {
+                if (e0 + r < ne) {
+                    uint32_t s = chunk_mismatch_wave<KIND>(qv, rv[r], valid);
+                    if (lane == 0 && s) atomicAdd(&Ecnt[e0 + r], s);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void node_neighbours(const IndexDev &ix, uint32_t node, int L, const uint32_t *&nbr, uint32_t &deg)
+{
+    if (L == 0) { nbr = ix.nbr0 + (uint64_t)node * 2 * ix.M; deg = ix.deg0[node]; }
+    else {
+        int32_t u = ix.upidx[node];
+        nbr = ix.nbrU + ((uint64_t)u * ix.max_layer + (uint32_t)(L - 1)) * ix.M;
+        deg = ix.degU[(uint64_t)u * ix.max_layer + (uint32_t)(L - 1)];
+    }
+}
+
+// Malkov alg. 2 / hnsw_rs::search_layer (SPEC 5) for one query by one workgroup. On return S.R[0..nR) holds the
+// result sorted ascending by (count,id). `vis` = this workgroup's visited bitmap (cleared by the caller).
+template <int KIND>
+__device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t *vis,
+                                                       uint32_t ep, uint32_t ep_cnt, uint32_t ef, int L, uint64_t &evals)
+{
+    const uint32_t maxdeg = 2 * ix.M;
+    const uint32_t capC = 2 * ef + maxdeg + 64;
+    uint32_t nR = 1, nC = 1, headC = 0;
+    if (threadIdx.x == 0) { S.R[0] = KEY(ep_cnt, ep); S.C[0] = KEY(ep_cnt, ep); atomicOr(&vis[ep >> 5], 1u << (ep & 31)); }
+    __syncthreads();
+    for (;;) {
+        if (headC >= nC) break;
+        const uint64_t c = S.C[headC];
+        const uint32_t dmax = (nR == ef) ? KCNT(S.R[ef - 1]) : INF_CNT;
+        if (KCNT(c) > dmax) break;
+        headC++;
+        // ---- gather unvisited neighbours of c, in stored order
+        const uint32_t *nbr; uint32_t deg;
+        node_neighbours(ix, KID(c), L, nbr, deg);
+        uint32_t id = 0; bool unv = false;
+        if (threadIdx.x < deg) {
+            id = nbr[threadIdx.x];
+            uint32_t bit = 1u << (id & 31);
+            uint32_t old = atomicOr(&vis[id >> 5], bit);
+            unv = !(old & bit);
+        }
+        const uint64_t bal = __ballot(unv);
+        const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = 0, ne = 0;
+#pragma unroll
+        for (int w = 0; w < ST / 64; w++) { uint32_t x = S.wsum[w]; if (w < (int)wv) off += x; ne += x; }
+        if (unv) S.Eid[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = id;
+        __syncthreads();
+        if (ne == 0) continue;
+        evals += ne;
+        // ---- all distances of this expansion (HBM-bound part)
+        block_distances<KIND>(ix, q, S.Eid, ne, S.Ecnt);
+        // ---- closed form of the sequential accept rule (DESIGN.md "accept rule"):
+        //      e_i accepted  <=>  #{x in R : c(x) <= c_i} + #{j < i : c_j <= c_i}  <  ef
+        uint64_t mykey = ~(uint64_t)0; bool acc = false;
+        if (threadIdx.x < ne) {
+            const uint32_t ci = S.Ecnt[threadIdx.x];
+            uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu) );          // keys < (ci,max) ; ids never reach 2^32-1
+            for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
+            acc = le < ef;
+            if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
+        }
+        if (threadIdx.x < maxdeg) S.A[threadIdx.x] = mykey;          // unsorted staging (~0 = rejected)
+        const uint64_t abal = __ballot(acc);
+        if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(abal);
+        __syncthreads();
+        uint32_t na = 0;
+#pragma unroll
+        for (int w = 0; w < ST / 64; w++) na += S.wsum[w];
+        uint32_t rank = 0;
+        if (acc) for (uint32_t j = 0; j < ne; j++) rank += (S.A[j] < mykey);
+        __syncthreads();
+        if (acc) S.A[rank] = mykey;                                  // sorted ascending, dense in [0,na)
+        __syncthreads();
+        if (na == 0) continue;
+        // ---- R <- ef smallest of R u A ; C <- live C u A ; drop dead tail of C
+        nR = block_merge(S.R, 0, nR, S.A, na, ef);
+        nC = block_merge(S.C, headC, nC, S.A, na, capC);
+        headC = 0;
+        if (nR == ef) {
+            uint32_t alive = lower_bound_keys(S.C, nC, KEY(KCNT(S.R[ef - 1]), 0xFFFFFFFFu));
+            if (alive < nC) nC = alive;
+        }
+    }
+    __syncthreads();
+    return nR;
+}
+
+// greedy descent on one upper layer (hnsw_rs::search outer loop, SPEC 5)
+template <int KIND>
+__device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t &ep,
+                                                   uint32_t &ep_cnt, int L, uint64_t &evals)
+{
+    for (;;) {
+        const uint32_t *nbr; uint32_t deg;
+        node_neighbours(ix, ep, L, nbr, deg);
+        if (deg == 0) return;
+        if (threadIdx.x < deg) S.Eid[threadIdx.x] = nbr[threadIdx.x];
+        if (threadIdx.x == 0) S.scal[0] = ~(uint64_t)0;
+        __syncthreads();
+        evals += deg;
+        block_distances<KIND>(ix, q, S.Eid, deg, S.Ecnt);
+        if (threadIdx.x < deg && S.Ecnt[threadIdx.x] < ep_cnt) atomicMin((unsigned long long *)&S.scal[0], (unsigned long long)KEY(S.Ecnt[threadIdx.x], threadIdx.x));
+        __syncthreads();
+        const uint64_t best = S.scal[0];
+        const uint32_t bid = best == ~(uint64_t)0 ? 0 : S.Eid[KID(best)];
+        __syncthreads();
+        if (best == ~(uint64_t)0) return;
+        ep = bid; ep_cnt = KCNT(best);
+    }
+}
+
+__device__ __forceinline__ SearchLds carve_lds(uint8_t *base, uint32_t ef, uint32_t maxdeg)
+{
+    SearchLds S;
+    const size_t capC = 2 * (size_t)ef + maxdeg + 64;
+    S.R = (uint64_t *)base; base += 8 * (size_t)ef;
+    S.C = (uint64_t *)base; base += 8 * capC;
+    S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
+    S.scal = (uint64_t *)base; base += 8 * 8;
+    S.Eid = (uint32_t *)base; base += 4 * (size_t)maxdeg;
+    S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
+    S.wsum = (uint32_t *)base;
+    return S;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *__restrict__ queries, uint64_t nq, uint32_t knbn, uint32_t ef,
+                                                     uint32_t *__restrict__ visited, uint32_t vis_words, unsigned long long *__restrict__ counter,
+                                                     uint64_t *__restrict__ ids_out, float *__restrict__ dist_out, uint32_t *__restrict__ count_out,
+                                                     uint64_t *__restrict__ evals_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    const uint32_t maxdeg = 2 * ix.M;
+    const uint32_t efs = ef > knbn ? ef : knbn;
+    SearchLds S = carve_lds(s_raw, efs, maxdeg);
+    uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.scal[1] = atomicAdd(counter, 1ull);
+        __syncthreads();
+        const uint64_t qi = S.scal[1];
+        if (qi >= nq) break;
+        const uint4 *q = (const uint4 *)(queries + qi * ix.stride);
+        for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
+        uint64_t evals = 1;
+        // distance to the entry point
+        if (threadIdx.x == 0) S.Eid[0] = (uint32_t)ix.entry;
+        __syncthreads();
+        block_distances<KIND>(ix, q, S.Eid, 1, S.Ecnt);
+        uint32_t ep = (uint32_t)ix.entry, ep_cnt = S.Ecnt[0];
+        __syncthreads();
+        for (int L = ix.top; L >= 1; L--) greedy_layer_block<KIND>(ix, q, S, ep, ep_cnt, L, evals);
+        const uint32_t nR = search_layer_block<KIND>(ix, q, S, vis, ep, ep_cnt, efs, 0, evals);
+        const uint32_t nout = nR < knbn ? nR : knbn;
+        for (uint32_t i = threadIdx.x; i < knbn; i += ST) {
+            if (i < nout) { ids_out[qi * knbn + i] = KID(S.R[i]); dist_out[qi * knbn + i] = (float)KCNT(S.R[i]) / (float)ix.m; }
+            else { ids_out[qi * knbn + i] = ~(uint64_t)0; dist_out[qi * knbn + i] = INFINITY; }
+        }
+        if (threadIdx.x == 0) { if (count_out) count_out[qi] = nout; if (evals_out) evals_out[qi] = evals; }
+    }
+}
+
+}  // namespace gs
+
+// ------------------------------------------------------------------------------------------------------
+struct gs_index {
+    gs_ctx *ctx = nullptr;
+    gs_index_params prm{};
+    size_t esz = 4, rowbytes = 0; uint64_t stride = 0; uint32_t nchunks = 0;
+    uint64_t n = 0, cap = 0; int64_t entry = -1; int top = -1;
+    uint64_t n_upper = 0, cap_upper = 0;
+    gs::DevBuf data, levels, deg0, nbr0, cnt0, upidx, degU, nbrU, cntU;
+    gs::DevBuf visited, counter;
+    uint64_t insert_evals = 0;
+};
+
+namespace gs {
+
+static int index_reserve(gs_index *ix, uint64_t need, uint64_t need_upper)
+{
+    gs_ctx *c = ix->ctx;
+    const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
+    if (need > ix->cap) {
+        uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap + ix->cap / 2, 1024));
+        struct { DevBuf *b; size_t per; } arr[] = {
+            {&ix->data, (size_t)ix->stride}, {&ix->levels, 1}, {&ix->deg0, 4}, {&ix->nbr0, (size_t)8 * M}, {&ix->cnt0, (size_t)8 * M}, {&ix->upidx, 4}};
+        for (auto &a : arr) {
+            DevBuf nb;
+            int rc = nb.alloc(a.per * ncap); if (rc) return rc;
+            GS_HIP_CHECK(hipMemsetAsync(nb.p, 0, a.per * ncap, c->stream));
+            if (ix->n) GS_HIP_CHECK(hipMemcpyAsync(nb.p, a.b->p, a.per * ix->n, hipMemcpyDeviceToDevice, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            std::swap(a.b->p, nb.p); std::swap(a.b->bytes, nb.bytes);
+        }
+        ix->cap = ncap;
+    }
+    if (need_upper > ix->cap_upper) {
+        uint64_t ncap = std::max<uint64_t>(need_upper, std::max<uint64_t>(ix->cap_upper * 2, 64));
+        struct { DevBuf *b; size_t per; } arr[] = {{&ix->degU, (size_t)4 * ML}, {&ix->nbrU, (size_t)4 * ML * M}, {&ix->cntU, (size_t)4 * ML * M}};
+        for (auto &a : arr) {
+            DevBuf nb;
+            int rc = nb.alloc(a.per * ncap); if (rc) return rc;
+            GS_HIP_CHECK(hipMemsetAsync(nb.p, 0, a.per * ncap, c->stream));
+            if (ix->n_upper) GS_HIP_CHECK(hipMemcpyAsync(nb.p, a.b->p, a.per * ix->n_upper, hipMemcpyDeviceToDevice, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            std::swap(a.b->p, nb.p); std::swap(a.b->bytes, nb.bytes);
+        }
+        ix->cap_upper = ncap;
+    }
+    return GS_OK;
+}
+
+static IndexDev index_dev(const gs_index *ix)
+{
+    IndexDev d;
+    d.data = ix->data.as<uint8_t>(); d.stride = ix->stride; d.nchunks = ix->nchunks; d.m = ix->prm.m;
+    d.M = ix->prm.max_nb_conn; d.max_layer = ix->prm.max_layer;
+    d.levels = ix->levels.as<uint8_t>(); d.deg0 = ix->deg0.as<uint32_t>(); d.nbr0 = ix->nbr0.as<uint32_t>();
+    d.upidx = ix->upidx.as<int32_t>(); d.degU = ix->degU.as<uint32_t>(); d.nbrU = ix->nbrU.as<uint32_t>();
+    d.n = ix->n; d.entry = ix->entry; d.top = ix->top;
+    return d;
+}
+
+// copy dense rows (host or device) into a zero-padded strided device buffer
+static int upload_rows(gs_ctx *c, void *dst, uint64_t stride, const void *src, size_t rowbytes, uint64_t nrows, hipMemcpyKind kind)
+{
+    if (nrows == 0) return GS_OK;
+    GS_HIP_CHECK(hipMemsetAsync(dst, 0, stride * nrows, c->stream));
+    GS_HIP_CHECK(hipMemcpy2DAsync(dst, stride, src, rowbytes, rowbytes, nrows, kind, c->stream));
+    return GS_OK;
+}
+
+static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
+                      uint32_t *count, uint64_t *evals)
+{
+    gs_ctx *c = ix->ctx;
+    const uint32_t efs = std::max(ef, knbn);
+    const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
+    const size_t lds = search_lds_bytes(efs, maxdeg);
+    GS_REQUIRE(lds <= 160 * 1024 - 64, GS_ERR_UNSUPPORTED, "ef=%u needs %zu bytes of LDS (max ~%u with M=%u)", efs, lds,
+               (unsigned)((160 * 1024 - 64 - 32 * maxdeg - 1024) / 24), ix->prm.max_nb_conn);
+    GS_REQUIRE(2 * (size_t)efs + maxdeg + 64 <= (size_t)SMAXI * ST, GS_ERR_UNSUPPORTED, "ef=%u too large for the in-LDS merge", efs);
+    GS_REQUIRE(maxdeg <= ST, GS_ERR_UNSUPPORTED, "max_nb_conn too large");
+    const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu);
+    int rc;
+    if ((rc = ix->visited.ensure((size_t)4 * vis_words * c->n_cu))) return rc;
+    if ((rc = ix->counter.ensure(64))) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
+    IndexDev d = index_dev(ix);
+    ProfScope ps(c, FAM_SEARCH);
+#define GS_LAUNCH_SEARCH(K)                                                                                               \
+    do {                                                                                                                  \
+        auto kern = k_hnsw_search<K>;                                                                                     \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST), lds, c->stream, d, (const uint8_t *)q_padded_dev, nq, knbn, ef,   \
+                           ix->visited.as<uint32_t>(), vis_words, ix->counter.as<unsigned long long>(), ids, dist, count, evals); \
+    } while (0)
+    if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_SEARCH(GS_KIND_F32);
+    else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_SEARCH(GS_KIND_U32);
+    else GS_LAUNCH_SEARCH(GS_KIND_U64);
+#undef GS_LAUNCH_SEARCH
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs
+
+extern "C" {
+
+int gs_index_create(gs_ctx *c, const gs_index_params *p, gs_index **out)
+{
+    GS_REQUIRE(c && p && out, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(p->kind == GS_KIND_F32 || p->kind == GS_KIND_U32 || p->kind == GS_KIND_U64, GS_ERR_UNSUPPORTED, "signature kind %d not supported by the index", p->kind);
+    GS_REQUIRE(p->m >= 1, GS_ERR_INVALID, "m must be positive");
+    GS_REQUIRE(p->max_nb_conn >= 2 && p->max_nb_conn <= 255, GS_ERR_INVALID, "max_nb_conn must be in 2..255 (gsearch.rs:268)");
+    GS_REQUIRE(p->max_layer >= 1 && p->max_layer <= 16, GS_ERR_INVALID, "max_layer must be in 1..16");
+    GS_REQUIRE(p->ef_construction >= 1, GS_ERR_INVALID, "ef_construction must be positive");
+    gs_index *ix = new gs_index();
+    ix->ctx = c; ix->prm = *p;
+    if (ix->prm.insert_batch == 0) ix->prm.insert_batch = 64;
+    ix->esz = gs::kind_bytes(p->kind);
+    ix->rowbytes = ix->esz * p->m;
+    ix->stride = gs::round_up(ix->rowbytes, 256);
+    ix->nchunks = (uint32_t)((ix->rowbytes + 15) / 16);
+    *out = ix;
+    return GS_OK;
+}
+void gs_index_destroy(gs_index *ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+    delete ix;
+}
+uint64_t gs_index_nb_point(const gs_index *ix) { return ix ? ix->n : 0; }
+uint64_t gs_index_insert_evals(const gs_index *ix) { return ix ? ix->insert_evals : 0; }
+
+int gs_index_import(gs_index *ix, const void *sigs, uint64_t n, const uint8_t *levels, int64_t entry, const uint32_t *deg0,
+                    const uint32_t *nbr0, const uint32_t *cnt0, const int32_t *upidx, uint64_t n_upper, const uint32_t *degU,
+                    const uint32_t *nbrU, const uint32_t *cntU)
+{
+    GS_REQUIRE(ix && ix->n == 0, GS_ERR_STATE, "import needs an empty index");
+    GS_REQUIRE(n > 0 && sigs && levels && deg0 && nbr0 && cnt0 && upidx, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(entry >= 0 && (uint64_t)entry < n, GS_ERR_INVALID, "entry point out of range");
+    GS_REQUIRE(n_upper == 0 || (degU && nbrU && cntU), GS_ERR_INVALID, "null upper-layer arrays");
+    gs_ctx *c = ix->ctx;
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
+    int top = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        GS_REQUIRE(levels[i] < ML, GS_ERR_INVALID, "level of node %llu out of range", (unsigned long long)i);
+        GS_REQUIRE(deg0[i] <= 2 * M, GS_ERR_INVALID, "degree of node %llu out of range", (unsigned long long)i);
+        for (uint32_t t = 0; t < deg0[i]; t++) GS_REQUIRE(nbr0[i * 2 * M + t] < n, GS_ERR_INVALID, "neighbour id out of range");
+        GS_REQUIRE((levels[i] > 0) == (upidx[i] >= 0), GS_ERR_INVALID, "upidx inconsistent with level at node %llu", (unsigned long long)i);
+        if (levels[i] > top) top = levels[i];
+    }
+    GS_REQUIRE(levels[entry] == top, GS_ERR_INVALID, "entry point is not on the top layer");
+    int rc = gs::index_reserve(ix, n, n_upper);
+    if (rc) return rc;
+    if ((rc = gs::upload_rows(c, ix->data.p, ix->stride, sigs, ix->rowbytes, n, hipMemcpyHostToDevice))) return rc;
+    GS_HIP_CHECK(hipMemcpyAsync(ix->levels.p, levels, n, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(ix->deg0.p, deg0, 4 * n, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(ix->nbr0.p, nbr0, (size_t)8 * M * n, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(ix->cnt0.p, cnt0, (size_t)8 * M * n, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(ix->upidx.p, upidx, 4 * n, hipMemcpyHostToDevice, c->stream));
+    if (n_upper) {
+        GS_HIP_CHECK(hipMemcpyAsync(ix->degU.p, degU, (size_t)4 * ML * n_upper, hipMemcpyHostToDevice, c->stream));
+        GS_HIP_CHECK(hipMemcpyAsync(ix->nbrU.p, nbrU, (size_t)4 * ML * M * n_upper, hipMemcpyHostToDevice, c->stream));
+        GS_HIP_CHECK(hipMemcpyAsync(ix->cntU.p, cntU, (size_t)4 * ML * M * n_upper, hipMemcpyHostToDevice, c->stream));
+    }
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    ix->n = n; ix->n_upper = n_upper; ix->entry = entry; ix->top = top;
+    return GS_OK;
+}
+
+int gs_index_export(gs_index *ix, uint8_t *levels, int64_t *entry, uint32_t *deg0, uint32_t *nbr0, uint32_t *cnt0, int32_t *upidx,
+                    uint64_t *n_upper, uint32_t *degU, uint32_t *nbrU, uint32_t *cntU)
+{
+    GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
+    gs_ctx *c = ix->ctx;
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
+    const uint64_t n = ix->n, U = ix->n_upper;
+    if (entry) *entry = ix->entry;
+    if (n_upper) *n_upper = U;
+    if (n) {
+        if (levels) GS_HIP_CHECK(hipMemcpyAsync(levels, ix->levels.p, n, hipMemcpyDeviceToHost, c->stream));
+        if (deg0) GS_HIP_CHECK(hipMemcpyAsync(deg0, ix->deg0.p, 4 * n, hipMemcpyDeviceToHost, c->stream));
+        if (nbr0) GS_HIP_CHECK(hipMemcpyAsync(nbr0, ix->nbr0.p, (size_t)8 * M * n, hipMemcpyDeviceToHost, c->stream));
+        if (cnt0) GS_HIP_CHECK(hipMemcpyAsync(cnt0, ix->cnt0.p, (size_t)8 * M * n, hipMemcpyDeviceToHost, c->stream));
+        if (upidx) GS_HIP_CHECK(hipMemcpyAsync(upidx, ix->upidx.p, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (U) {
+        if (degU) GS_HIP_CHECK(hipMemcpyAsync(degU, ix->degU.p, (size_t)4 * ML * U, hipMemcpyDeviceToHost, c->stream));
+        if (nbrU) GS_HIP_CHECK(hipMemcpyAsync(nbrU, ix->nbrU.p, (size_t)4 * ML * M * U, hipMemcpyDeviceToHost, c->stream));
+        if (cntU) GS_HIP_CHECK(hipMemcpyAsync(cntU, ix->cntU.p, (size_t)4 * ML * M * U, hipMemcpyDeviceToHost, c->stream));
+    }
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_index_get_data(gs_index *ix, uint64_t first, uint64_t n, void *out)
+{
+    GS_REQUIRE(ix && out && first + n <= ix->n, GS_ERR_INVALID, "bad range");
+    if (n == 0) return GS_OK;
+    gs_ctx *c = ix->ctx;
+    GS_HIP_CHECK(hipMemcpy2DAsync(out, ix->rowbytes, ix->data.as<uint8_t>() + first * ix->stride, ix->stride, ix->rowbytes, n, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
+                         uint32_t *count, uint64_t *evals)
+{
+    GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
+    GS_REQUIRE(knbn >= 1 && ef >= 1, GS_ERR_INVALID, "knbn and ef must be positive");
+    if (nq == 0) return GS_OK;
+    GS_REQUIRE(queries && ids && dist, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(ix->n > 0, GS_ERR_STATE, "search on an empty index");
+    gs_ctx *c = ix->ctx;
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    gs::DevBuf dq, dids, ddist, dcount, devals;
+    int rc;
+    if ((rc = dq.alloc(ix->stride * nq))) return rc;
+    if ((rc = gs::upload_rows(c, dq.p, ix->stride, queries, ix->rowbytes, nq, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
+    if (on_dev) {
+        if ((rc = gs::search_dev(ix, dq.p, nq, knbn, ef, ids, dist, count, evals))) return rc;
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return GS_OK;
+    }
+    if ((rc = dids.alloc(8 * nq * knbn))) return rc;
+    if ((rc = ddist.alloc(4 * nq * knbn))) return rc;
+    if ((rc = dcount.alloc(4 * nq))) return rc;
+    if ((rc = devals.alloc(8 * nq))) return rc;
+    if ((rc = gs::search_dev(ix, dq.p, nq, knbn, ef, dids.as<uint64_t>(), ddist.as<float>(), dcount.as<uint32_t>(), devals.as<uint64_t>()))) return rc;
+    GS_HIP_CHECK(hipMemcpyAsync(ids, dids.p, 8 * nq * knbn, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dist, ddist.p, 4 * nq * knbn, hipMemcpyDeviceToHost, c->stream));
+    if (count) GS_HIP_CHECK(hipMemcpyAsync(count, dcount.p, 4 * nq, hipMemcpyDeviceToHost, c->stream));
+    if (evals) GS_HIP_CHECK(hipMemcpyAsync(evals, devals.p, 8 * nq, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_index_parallel_search(gs_index *ix, const void *queries, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
+                             uint32_t *count, uint64_t *evals)
+{
+    return search_common(ix, queries, false, nq, knbn, ef, ids, dist, count, evals);
+}
+int gs_index_parallel_search_dev(gs_index *ix, const void *queries_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
+                                 uint32_t *count, uint64_t *evals)
+{
+    return search_common(ix, queries_dev, true, nq, knbn, ef, ids, dist, count, evals);
+}
+
+int gs_index_parallel_insert(gs_index *ix, const void *sigs, uint64_t n)
+{
+    GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
+    (void)sigs; (void)n;
+    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "device-side parallel_insert is not implemented yet (use gs_index_import)");
+}
+int gs_index_parallel_insert_dev(gs_index *ix, const void *sigs_dev, uint64_t n)
+{
+    GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
+    (void)sigs_dev; (void)n;
+    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "device-side parallel_insert is not implemented yet (use gs_index_import)");
+}
+
+int gs_index_bruteforce_search(gs_index *ix, const void *queries, uint64_t nq, uint32_t knbn, uint64_t *ids, float *dist)
+{
+    GS_REQUIRE(ix && knbn >= 1, GS_ERR_INVALID, "bad argument");
+    if (nq == 0) return GS_OK;
+    GS_REQUIRE(queries && ids && dist && ix->n > 0, GS_ERR_INVALID, "bad argument");
+    gs_ctx *c = ix->ctx;
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    // dense copy of the data rows (the tile kernel takes unpadded rows), query blocks of 256
+    const uint64_t n = ix->n;
+    gs::DevBuf dense, dq, dd;
+    int rc;
+    if ((rc = dense.alloc(ix->rowbytes * n))) return rc;
+    GS_HIP_CHECK(hipMemcpy2DAsync(dense.p, ix->rowbytes, ix->data.p, ix->stride, ix->rowbytes, n, hipMemcpyDeviceToDevice, c->stream));
+    const uint64_t QB = 256;
+    if ((rc = dq.alloc(ix->rowbytes * QB))) return rc;
+    if ((rc = dd.alloc(4 * QB * n))) return rc;
+    std::vector<float> h(QB * n);
+    std::vector<uint64_t> keys(n);
+    for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
+        const uint64_t nb = std::min(QB, nq - q0);
+        GS_HIP_CHECK(hipMemcpyAsync(dq.p, (const uint8_t *)queries + ix->rowbytes * q0, ix->rowbytes * nb, hipMemcpyHostToDevice, c->stream));
+        if ((rc = gs_hamming_qxc_dev(c, ix->prm.kind, ix->prm.m, dq.p, nb, dense.p, n, dd.as<float>()))) return rc;
+        GS_HIP_CHECK(hipMemcpyAsync(h.data(), dd.p, 4 * nb * n, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (uint64_t i = 0; i < nb; i++) {
+            const float *row = h.data() + i * n;
+            // distances are exact multiples count/m: recover the integer count for the (count,id) order
+            for (uint64_t j = 0; j < n; j++) keys[j] = ((uint64_t)(uint32_t)llrintf(row[j] * (float)ix->prm.m) << 32) | j;
+            const uint64_t kk = std::min<uint64_t>(knbn, n);
+            std::partial_sort(keys.begin(), keys.begin() + kk, keys.end());
+            for (uint32_t t = 0; t < knbn; t++) {
+                if (t < kk) { ids[(q0 + i) * knbn + t] = (uint32_t)keys[t]; dist[(q0 + i) * knbn + t] = row[(uint32_t)keys[t]]; }
+                else { ids[(q0 + i) * knbn + t] = ~(uint64_t)0; dist[(q0 + i) * knbn + t] = INFINITY; }
+            }
+        }
+    }
+    return GS_OK;
+}
+
+int gs_index_save(gs_index *ix, const char *path)
+{
+    GS_REQUIRE(ix && path, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "gs_index_save not implemented yet");
+}
+int gs_index_load(gs_ctx *c, const char *path, gs_index **out)
+{
+    GS_REQUIRE(c && path && out, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "gs_index_load not implemented yet");
+}
+
+}  // extern "C"

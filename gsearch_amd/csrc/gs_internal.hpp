@@ -1,0 +1,96 @@
+// gs_internal.hpp — shared plumbing of the C-ABI implementation (not part of the public interface).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/gsearch_amd.h"
+
+namespace gs {
+
+void set_error(const char *fmt, ...);
+
+#define GS_HIP_CHECK(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            gs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GS_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+#define GS_REQUIRE(cond, code, ...)                \
+    do {                                           \
+        if (!(cond)) {                             \
+            gs::set_error(__VA_ARGS__);            \
+            return (code);                         \
+        }                                          \
+    } while (0)
+
+enum { FAM_SKETCH = 0, FAM_HAMMING = 1, FAM_SEARCH = 2, FAM_INSERT = 3, FAM_COUNT = 4 };
+
+struct ProfSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+
+}  // namespace gs
+
+struct gs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 0;
+    uint64_t hbm_bytes = 0;
+    char name[128] = {0};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profile = false;
+    gs::ProfSlot prof[gs::FAM_COUNT];
+};
+
+namespace gs {
+
+// RAII-ish helpers -----------------------------------------------------------------------------
+struct ProfScope {   // brackets one kernel launch with events when profiling is on
+    gs_ctx *c; int fam; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(gs_ctx *ctx, int family) : c(ctx), fam(family)
+    {
+        if (c->profile) {
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (c->profile) {
+            (void)hipEventRecord(b, c->stream);
+            c->prof[fam].pending.emplace_back(a, b);
+        }
+    }
+};
+
+inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }
+inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+struct DevBuf {   // owning device allocation
+    void *p = nullptr; size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0) n = 16;
+        GS_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+        return GS_OK;
+    }
+    int ensure(size_t n) { return (n <= bytes && p) ? GS_OK : alloc(n); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace gs

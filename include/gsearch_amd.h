@@ -1,0 +1,175 @@
+/*
+ * gsearch_amd.h — C ABI of the MI355X-native sketch-and-query hot path of gsearch.
+ *
+ * The reference (Rust, /root/reference) has no FFI of its own for this path: the extension points are
+ * generic traits resolved at compile time. Each entry point below replaces one *batch-level* call the
+ * reference makes into those traits (paths relative to /root/reference); INTEGRATION.md shows the
+ * `extern "C"` block a Rust maintainer would add to bind them.
+ *
+ * Conventions: every function returns 0 on success and a negative GS_ERR_* code on failure; nothing
+ * throws or aborts across the boundary; gs_last_error() gives a thread-local message. All pointers
+ * are HOST pointers unless the name ends in `_dev`. Plain C types only.
+ * Arithmetic is normative in SPEC.md.
+ */
+#ifndef GSEARCH_AMD_H
+#define GSEARCH_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------- */
+enum {
+    GS_OK = 0,
+    GS_ERR_INVALID = -1,      /* bad argument / unsupported parameter combination */
+    GS_ERR_HIP = -2,          /* HIP runtime error (no device, OOM, launch failure) */
+    GS_ERR_UNSUPPORTED = -3,  /* valid in the reference but not implemented on the device yet */
+    GS_ERR_STATE = -4,        /* object used in the wrong state (e.g. search on an empty index) */
+    GS_ERR_IO = -5
+};
+/* kmerutils::sketcharg::SketchAlgo / DataType as parsed at src/bin/gsearch.rs:181-196,258-263 */
+enum { GS_ALGO_PROB3A = 0, GS_ALGO_SUPER = 1, GS_ALGO_SUPER2 = 2, GS_ALGO_HLL = 3, GS_ALGO_OPTDENS = 4, GS_ALGO_REVOPTDENS = 5 };
+enum { GS_DATA_DNA = 0, GS_DATA_AA = 1 };
+/* signature element type (table SURVEY 2.2; src/dna/dnasketch.rs:499-642, src/aa/aasketch.rs:455-550) */
+enum { GS_KIND_U16 = 0, GS_KIND_U32 = 1, GS_KIND_U64 = 2, GS_KIND_F32 = 3 };
+
+const char *gs_last_error(void);
+const char *gs_version(void);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Context: one per (process, GPU). Owns a HIP stream; every call on a context is enqueued on it.   */
+/* `stream` may be NULL (the context creates its own) or an existing hipStream_t to adopt.          */
+typedef struct gs_ctx gs_ctx;
+int   gs_ctx_create(gs_ctx **out, int device_id, void *stream);
+void  gs_ctx_destroy(gs_ctx *);
+int   gs_ctx_sync(gs_ctx *);
+void *gs_ctx_stream(gs_ctx *);                         /* the hipStream_t kernels are launched on */
+int   gs_ctx_device_info(gs_ctx *, int *n_cu, uint64_t *hbm_bytes, char *name, size_t name_cap);
+/* HIP-event stopwatch on the context's stream (bench.py measures kernels with it) */
+int   gs_ctx_timer_start(gs_ctx *);
+int   gs_ctx_timer_stop(gs_ctx *, float *elapsed_ms);
+/* duration (ms) and launch count of the kernels of one family since the last reset, measured with
+ * HIP events around every launch when profiling is enabled (gs_ctx_profile(ctx,1)).
+ * family: 0 = sketch main kernel, 1 = hamming q x c, 2 = index search kernel, 3 = index insert kernels */
+int   gs_ctx_profile(gs_ctx *, int enable);
+int   gs_ctx_profile_read(gs_ctx *, int family, double *total_ms, uint64_t *launches, int reset);
+
+/* plain device-memory helpers so that hosts without a HIP binding can keep data resident in HBM */
+int   gs_dev_alloc(gs_ctx *, size_t bytes, void **dev_ptr);
+int   gs_dev_free(gs_ctx *, void *dev_ptr);
+int   gs_dev_upload(gs_ctx *, void *dst_dev, const void *src_host, size_t bytes);
+int   gs_dev_download(gs_ctx *, void *dst_host, const void *src_dev, size_t bytes);
+int   gs_dev_memset(gs_ctx *, void *dst_dev, int byte, size_t bytes);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Sketching: replaces SeqSketcherT::sketch_compressedkmer_seqs / sketch_compressedkmer            */
+/*   call sites: src/dna/dnasketch.rs:336,357  src/dna/dnarequest.rs:272,287                        */
+/*               src/aa/aasketch.rs:313,329    src/aa/aarequest.rs:268,283  src/bin/bindash.rs:81   */
+/* mirrors kmerutils::sketcharg::SeqSketcherParams{kmer_size, sketch_size, algo, data_t}            */
+typedef struct { uint32_t k, sketch_size, algo, data_t; } gs_sketch_params;
+
+int    gs_check_params(const gs_sketch_params *);       /* k=15, k>32 (DNA) / k>12 (AA), hll -> error */
+int    gs_sig_kind(const gs_sketch_params *);           /* GS_KIND_* */
+size_t gs_sig_elem_bytes(const gs_sketch_params *);
+int    gs_value_bits(const gs_sketch_params *);         /* width of Kmer::Val: 32 or 64 */
+
+/*
+ * One signature per genome, in input order (asserts at dnasketch.rs:338,359).
+ *   seq        DNA: 2-bit packed, base i in byte i>>2 at bits [6-2(i&3), 7-2(i&3)] (SPEC 1.1);
+ *              AA : one ASCII letter per residue, already alphabet-filtered (aafiles.rs:11-28).
+ *   seq_bytes  size of seq; for the _dev variant the allocation must extend to a multiple of 8 bytes.
+ *   record r   = bases/residues [rec_start[r], rec_start[r]+rec_len[r]); k-mers never span records.
+ *   genome g   = records [genome_rec_off[g], genome_rec_off[g+1]).  `--block` mode = one record/genome.
+ *   sig_out    n_genomes x sketch_size elements of gs_sig_kind(), caller owned.
+ * Re-entrant per context (the reference clones the sketcher into every worker, dnasketch.rs:305).
+ */
+int gs_sketch_batch(gs_ctx *, const gs_sketch_params *, const void *seq, uint64_t seq_bytes,
+                    const uint64_t *rec_start, const uint64_t *rec_len, uint64_t n_rec,
+                    const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out);
+/* same, every pointer in device memory, asynchronous on the context's stream */
+int gs_sketch_batch_dev(gs_ctx *, const gs_sketch_params *, const void *seq_dev, uint64_t seq_bytes,
+                        const uint64_t *rec_start_dev, const uint64_t *rec_len_dev, uint64_t n_rec,
+                        const uint64_t *genome_rec_off_dev, uint64_t n_genomes, void *sig_out_dev);
+/* ASCII helpers for hosts that do not pack themselves (Sequence::encode_and_add, dnafiles.rs:70-71) */
+uint64_t gs_pack_dna(const uint8_t *ascii, uint64_t n, uint8_t *packed_zeroed, uint64_t base_off);
+uint64_t gs_filter_aa(const uint8_t *ascii, uint64_t n, uint8_t *out);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* DistHamming::eval, batched (anndists; bound at dnasketch.rs:72,139; direct use bindash.rs:93-99) */
+/* dist = (f32)count(a[i] != b[i]) / (f32)m                                                         */
+int gs_hamming_qxc(gs_ctx *, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc,
+                   float *dist_out /* nq x nc */);
+int gs_hamming_qxc_dev(gs_ctx *, int kind, uint32_t m, const void *Q_dev, uint64_t nq, const void *C_dev,
+                       uint64_t nc, float *dist_out_dev);
+int gs_hamming_pairs(gs_ctx *, int kind, uint32_t m, const void *A, uint64_t na, const void *B, uint64_t nb,
+                     const uint64_t *ia, const uint64_t *ib, uint64_t npairs, float *dist_out);
+/* reformat.rs:80-86 calculate_ani (model 1 Poisson, 2 binomial), host arithmetic in f64 */
+double gs_ani(double distance, int kmer_size, int model);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Hnsw<Sig, DistHamming> (hnsw_rs) as gsearch drives it:                                           */
+/*   new/modify_level_scale/set_extend_candidates/set_keeping_pruned  dnasketch.rs:139-141,159-160  */
+/*   parallel_insert dnasketch.rs:435, aasketch.rs:407;  parallel_search dnarequest.rs:353, aarequest.rs:344 */
+typedef struct gs_index gs_index;
+typedef struct {
+    int      kind;               /* GS_KIND_* of Sig */
+    uint32_t m;                  /* signature length */
+    uint32_t max_nb_conn;        /* M <= 255 (gsearch.rs:268) */
+    uint64_t capacity;           /* hnsw_params.capacity, 1_500_000 in gsearch (gsearch.rs:269); rows are pre-allocated */
+    uint32_t max_layer;          /* 16 (dnasketch.rs:139) */
+    uint32_t ef_construction;
+    double   scale_modify;       /* modify_level_scale factor (dnasketch.rs:141) */
+    int      extend_candidates;  /* true in gsearch (dnasketch.rs:159) */
+    int      keep_pruned;        /* false in gsearch (dnasketch.rs:160) */
+    uint64_t seed;               /* level generator seed (SPEC 5; upstream uses OS entropy) */
+    uint32_t insert_batch;       /* B of SPEC 5 parallel_insert; 0 -> default */
+} gs_index_params;
+
+int      gs_index_create(gs_ctx *, const gs_index_params *, gs_index **out);
+void     gs_index_destroy(gs_index *);
+uint64_t gs_index_nb_point(const gs_index *);
+/* parallel_insert(&[(&Vec<Sig>, usize)]): ids are assigned nb_point.. in input order (dnasketch.rs:429-433) */
+int      gs_index_parallel_insert(gs_index *, const void *sigs, uint64_t n);
+int      gs_index_parallel_insert_dev(gs_index *, const void *sigs_dev, uint64_t n);
+/* parallel_search(&[Vec<Sig>], knbn, ef) -> per query min(knbn, found) Neighbour{d_id, distance},
+ * ascending by (distance, d_id). Unused tail slots: id = UINT64_MAX, distance = +inf.
+ * evals_out (optional): number of DistHamming evaluations spent per query. */
+int      gs_index_parallel_search(gs_index *, const void *queries, uint64_t nq, uint32_t knbn, uint32_t ef,
+                                  uint64_t *ids_out, float *dist_out, uint32_t *count_out, uint64_t *evals_out);
+int      gs_index_parallel_search_dev(gs_index *, const void *queries_dev, uint64_t nq, uint32_t knbn, uint32_t ef,
+                                      uint64_t *ids_out_dev, float *dist_out_dev, uint32_t *count_out_dev,
+                                      uint64_t *evals_out_dev);
+/* exact top-k by exhaustive DistHamming (recall ground truth; also what bindash.rs:120-157 computes) */
+int      gs_index_bruteforce_search(gs_index *, const void *queries, uint64_t nq, uint32_t knbn,
+                                    uint64_t *ids_out, float *dist_out);
+/* Graph import / export (the role of hnswio::HnswIo::load_hnsw / Hnsw::file_dump, reloadhnsw.rs:41-51,
+ * dumpload.rs:31, in this library's own dense layout): levels[n], entry id, layer 0: deg0[n], nbr0[n*2M],
+ * cnt0[n*2M] (mismatch counts to the owner); upper layers: upidx[n] (-1 for level-0 nodes) and for the
+ * n_upper nodes of level >= 1: degU[U*max_layer], nbrU[U*max_layer*M], cntU[...] (row l-1 = layer l). */
+int      gs_index_import(gs_index *, const void *sigs, uint64_t n, const uint8_t *levels, int64_t entry,
+                         const uint32_t *deg0, const uint32_t *nbr0, const uint32_t *cnt0, const int32_t *upidx,
+                         uint64_t n_upper, const uint32_t *degU, const uint32_t *nbrU, const uint32_t *cntU);
+int      gs_index_export(gs_index *, uint8_t *levels, int64_t *entry, uint32_t *deg0, uint32_t *nbr0,
+                         uint32_t *cnt0, int32_t *upidx, uint64_t *n_upper, uint32_t *degU, uint32_t *nbrU,
+                         uint32_t *cntU);
+int      gs_index_get_data(gs_index *, uint64_t first, uint64_t n, void *sigs_out);
+int      gs_index_save(gs_index *, const char *path);
+int      gs_index_load(gs_ctx *, const char *path, gs_index **out);
+uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluations spent by inserts so far */
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Synthetic inputs generated in HBM (bench / tests): counter-based, reproducible on the host.      */
+/* DNA genome g of length L: packed word w (32 bases, 8 bytes little endian as stored) =             */
+/*   splitmix64 finaliser of (seed*0x9e3779b97f4a7c15 + g*0xbf58476d1ce4e5b9 + w)  (see gs_synth.hip) */
+int gs_synth_dna_dev(gs_ctx *, uint64_t seed, uint64_t first_genome, uint64_t n_genomes, uint64_t len_bases,
+                     void *seq_dev /* n_genomes * ceil(len/32)*8 bytes */);
+/* sketch-level database: n_roots random signatures, `per_root` members each, member slot kept from its
+ * root with probability J(member) ~ U[j_lo, j_hi], else re-randomised. Row r = root r/per_root. */
+int gs_synth_sigs_dev(gs_ctx *, int kind, uint32_t m, uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                      uint64_t per_root, double j_lo, double j_hi, void *sigs_dev /* n_rows x m */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

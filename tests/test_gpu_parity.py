@@ -1,0 +1,136 @@
+"""GPU parity tests: the HIP path (through the C ABI) must equal the CPU oracle bit for bit."""
+import numpy as np
+import pytest
+
+import helpers as H
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_sketch(k, m, algo, genomes, data="dna"):
+    recs = [r for g in genomes for r in g]
+    goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
+    if data == "dna":
+        seq, rs, rl = O.pack_dna(recs)
+    else:
+        seq, rs, rl = O.filter_aa(recs)
+    return O.sketch_batch(O.params(k, m, algo, data), seq, rs, rl, goff)
+
+
+def _bits(a):
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+@pytest.mark.parametrize("k,m,algo", [(21, 2000, "optdens"), (16, 1024, "optdens"), (14, 512, "optdens"), (32, 777, "optdens"),
+                                      (21, 2000, "revoptdens"), (7, 300, "optdens"), (1, 64, "optdens")])
+def test_sketch_dna_matches_oracle(gpu_ctx, k, m, algo):
+    import gsearch_amd as G
+    rng = np.random.default_rng(k * 1000 + m)
+    fam = H.family(rng, 50000, [0.001, 0.01, 0.05])
+    genomes = [[H.dna_ascii(g)] for g in fam]
+    # multi-record genome with N's / lower case / short records (< k) / empty record
+    g0 = H.dna_ascii(fam[0])
+    genomes.append([g0[:7000] + b"NNNNnnnn" + g0[7000:9000].lower(), b"ACGT", b"", g0[9000:9031], g0[20000:45003]])
+    genomes.append([b"ACGTN"])                       # too short for most k: no k-mer at all
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, algo))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(k, m, algo, genomes)
+    assert got.dtype == ref.dtype
+    assert np.array_equal(_bits(got), _bits(ref))
+
+
+@pytest.mark.parametrize("algo", ["optdens", "revoptdens"])
+def test_sketch_densification_matches_oracle(gpu_ctx, algo):
+    """few k-mers, many bins: exercises the empty-bin densification (cold path at BASELINE sizes)."""
+    import gsearch_amd as G
+    rng = np.random.default_rng(5)
+    genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (40, 300, 1500, 5000)]
+    sk = G.sketcher_for(G.SeqSketcherParams(21, 4096, algo))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(21, 4096, algo, genomes)
+    assert np.array_equal(_bits(got), _bits(ref))
+
+
+def test_sketch_aa_optdens_matches_oracle(gpu_ctx):
+    import gsearch_amd as G
+    rng = np.random.default_rng(8)
+    fam = H.family(rng, 30000, [0.01, 0.1], alphabet=20)
+    genomes = [[H.aa_ascii(g)] for g in fam]
+    genomes.append([H.aa_ascii(fam[0])[:5000] + b"*XBZ" + H.aa_ascii(fam[0])[5000:9000].lower(), b"MK", H.aa_ascii(fam[1])[100:7000]])
+    for k, m in ((7, 1000), (5, 512), (12, 256)):
+        sk = G.sketcher_for(G.SeqSketcherParams(k, m, "optdens", "aa"))
+        got = sk.sketch_genomes(genomes)
+        ref = _oracle_sketch(k, m, "optdens", genomes, "aa")
+        assert np.array_equal(_bits(got), _bits(ref))
+
+
+def test_sketch_split_over_workgroups(gpu_ctx):
+    """one long genome alone in the batch is split over several workgroups (global atomicMin merge)."""
+    import gsearch_amd as G
+    rng = np.random.default_rng(9)
+    genomes = [[H.dna_ascii(H.rand_dna(rng, 1200000))]]
+    sk = G.sketcher_for(G.SeqSketcherParams(21, 12000, "optdens"))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(21, 12000, "optdens", genomes)
+    assert np.array_equal(_bits(got), _bits(ref))
+
+
+@pytest.mark.parametrize("dtype,m", [(np.float32, 18000), (np.uint64, 2400), (np.uint32, 1001), (np.float32, 37)])
+def test_hamming_matches_oracle(gpu_ctx, dtype, m):
+    import gsearch_amd as G
+    db = H.synth_sig_db(5, 20, m, 1, dtype=dtype)
+    q = H.queries_from(db, 70, 2)
+    dh = G.DistHamming()
+    got = dh.eval_qxc(q, db)
+    ref = O.hamming_qxc(q, db)
+    assert np.array_equal(got, ref)
+    rng = np.random.default_rng(3)
+    ia, ib = rng.integers(0, len(q), 200), rng.integers(0, len(db), 200)
+    assert np.array_equal(dh.eval_pairs(q, db, ia, ib), O.hamming_pairs(q, db, ia, ib))
+    assert dh.eval(q[0], q[0]) == 0.0
+
+
+def test_hamming_float_semantics(gpu_ctx):
+    import gsearch_amd as G
+    a = np.array([[0.0, np.nan, 1.0, -0.0]], dtype=np.float32)
+    b = np.array([[-0.0, np.nan, 1.0, 0.0]], dtype=np.float32)
+    assert G.DistHamming().eval_qxc(a, b)[0, 0] == O.hamming_qxc(a, b)[0, 0] == np.float32(0.25)
+
+
+@pytest.mark.parametrize("dtype,m,M,efc,ef,knbn,scale", [(np.float32, 256, 8, 32, 48, 10, 1.0), (np.uint64, 120, 16, 64, 200, 50, 1.0),
+                                                         (np.float32, 1000, 24, 100, 300, 20, 0.25), (np.uint32, 64, 4, 16, 5, 8, 1.0)])
+def test_search_matches_oracle(gpu_ctx, dtype, m, M, efc, ef, knbn, scale):
+    """same graph (built by the oracle, imported) -> identical ids, distances, counts and number of DistHamming evaluations"""
+    import gsearch_amd as G
+    db = H.synth_sig_db(30, 40, m, 4, dtype=dtype, jlo=0.05, jhi=0.95)
+    oix = O.Index(dtype, m, M, efc, scale_modify=scale, seed=123)
+    oix.parallel_insert(db, batch=1)
+    hn = G.Hnsw.new(M, 10000, 16, efc, G.DistHamming(), dtype=dtype)
+    hn.import_graph(db, oix.export())
+    q = H.queries_from(db, 64, 6, frac=0.3)
+    ids, dist, cnt, ev = hn.search_arrays(q, knbn, ef)
+    oids, odist, ocnt, oev = oix.parallel_search(q, knbn, ef)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    assert np.array_equal(ev, oev)
+    # graph round trip
+    g = hn.export_graph()
+    og = oix.export()
+    for key in ("levels", "deg0", "nbr0", "cnt0", "upidx", "degU", "nbrU", "cntU"):
+        assert np.array_equal(g[key], og[key]), key
+    assert np.array_equal(hn.get_data().view(np.uint8), db.view(np.uint8))
+
+
+def test_bruteforce_matches_oracle(gpu_ctx):
+    import gsearch_amd as G
+    db = H.synth_sig_db(10, 30, 500, 14)
+    oix = O.Index(np.float32, 500, 8, 32, seed=1)
+    oix.parallel_insert(db, batch=1)
+    hn = G.Hnsw.new(8, 10000, 16, 32, G.DistHamming())
+    hn.import_graph(db, oix.export())
+    q = H.queries_from(db, 33, 15)
+    ids, dist = hn.bruteforce_search(q, 12)
+    oids, odist = O.bruteforce_topk(db, q, 12)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist)
