@@ -25,8 +25,8 @@ constexpr int HT = 64;      // tile edge (queries and candidates)
 constexpr int HKW = 32;     // words per K-chunk
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict__ Q, uint64_t nq, const uint32_t *__restrict__ C, uint64_t nc,
-                                                      uint32_t m, float *__restrict__ out)
+__global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict__ Q, uint64_t nq, uint64_t strideQ, const uint32_t *__restrict__ C, uint64_t nc,
+                                                      uint64_t strideC, uint32_t m, float *__restrict__ out, uint32_t *__restrict__ out_cnt)
 {
     constexpr int EW = ElemCmp<KIND>::EW;
     __shared__ uint32_t sq[HT][HKW + 1];
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
             uint32_t r = lr + 8 * i;
             uint64_t qr = q0 + r < nq ? q0 + r : nq - 1;
             uint64_t cr = c0 + r < nc ? c0 + r : nc - 1;
-            sq[r][lw] = wv ? Q[qr * roww + w0 + lw] : 0u;
-            sc[r][lw] = wv ? C[cr * roww + w0 + lw] : 0u;
+            sq[r][lw] = wv ? Q[qr * strideQ + w0 + lw] : 0u;
+            sc[r][lw] = wv ? C[cr * strideC + w0 + lw] : 0u;
         }
         __syncthreads();
 #pragma unroll 4
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             uint64_t cj = c0 + tx * 4 + j;
-            if (cj < nc) out[qi * nc + cj] = (float)cnt[i][j] / fm;
+            if (cj < nc) { if (out) out[qi * nc + cj] = (float)cnt[i][j] / fm; else out_cnt[qi * nc + cj] = cnt[i][j]; }
         }
     }
 }
@@ -102,20 +102,27 @@ __global__ __launch_bounds__(256) void k_hamming_pairs(const uint32_t *__restric
     }
 }
 
-static int hamming_qxc_dev(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc, float *out)
+int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, uint64_t strideQ_bytes, const void *C, uint64_t nc,
+                        uint64_t strideC_bytes, float *out, uint32_t *out_cnt)
 {
     GS_REQUIRE(c && m > 0, GS_ERR_INVALID, "bad argument");
     GS_REQUIRE(kind == GS_KIND_F32 || kind == GS_KIND_U32 || kind == GS_KIND_U64, GS_ERR_UNSUPPORTED, "DistHamming kind %d not on the device path", kind);
     if (nq == 0 || nc == 0) return GS_OK;
-    GS_REQUIRE(Q && C && out, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(Q && C && (out || out_cnt), GS_ERR_INVALID, "null argument");
     dim3 grid((uint32_t)((nc + HT - 1) / HT), (uint32_t)((nq + HT - 1) / HT)), block(256);
     GS_REQUIRE(grid.y <= 65535, GS_ERR_INVALID, "too many query rows for one call (max %d)", 65535 * HT);
     ProfScope ps(c, FAM_HAMMING);
-    if (kind == GS_KIND_F32) hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_F32>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, (const uint32_t *)C, nc, m, out);
-    else if (kind == GS_KIND_U32) hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_U32>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, (const uint32_t *)C, nc, m, out);
-    else hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_U64>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, (const uint32_t *)C, nc, m, out);
+    const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
+    if (kind == GS_KIND_F32) hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_F32>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt);
+    else if (kind == GS_KIND_U32) hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_U32>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt);
+    else hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_U64>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
+}
+static int hamming_qxc_dev(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc, float *out)
+{
+    const uint64_t row = kind_bytes(kind) * (uint64_t)m;
+    return hamming_qxc_strided(c, kind, m, Q, nq, row, C, nc, row, out, nullptr);
 }
 
 }  // namespace gs

@@ -295,6 +295,206 @@ __global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *
     }
 }
 
+
+// ======================================================================================================
+// parallel_insert (SPEC 5, batch-synchronous): phase 1 = k_hnsw_plan, one workgroup per new point
+// ======================================================================================================
+constexpr int PLAN_CH0 = 8;      // first chunk of accepted rows checked against a candidate, then PLAN_CH1
+constexpr int PLAN_CH1 = 32;
+
+// Malkov alg. 4 as hnsw_rs::select_neighbours applies it (SPEC 5). Candidates = S.R[0..nW) ascending;
+// accepted keys end up in S.A[0..na) ascending. `heuristic == false` -> take all (|W| <= deg, no extension).
+template <int KIND>
+__device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const SearchLds &S, uint32_t nW, uint32_t deg, bool heuristic, uint64_t &evals)
+{
+    if (!heuristic) {
+        for (uint32_t t = threadIdx.x; t < nW; t += ST) S.A[t] = S.R[t];
+        __syncthreads();
+        return nW;
+    }
+    const uint32_t maxdeg = 2 * ix.M;
+    uint32_t na = 0;
+    for (uint32_t i = 0; i < nW && na < deg; i++) {
+        const uint64_t e = S.R[i];
+        bool accept = true;
+        if (na > 0) {
+            if (KCNT(e) >= ix.m) accept = false;        // c(e,s) <= m = c(x,e) for every s: always pruned
+            else {
+                const uint4 *erow = (const uint4 *)(ix.data + (uint64_t)KID(e) * ix.stride);
+                uint32_t ch = PLAN_CH0;
+                for (uint32_t s0 = 0; s0 < na && accept; ) {
+                    uint32_t nch = na - s0 < ch ? na - s0 : ch;
+                    if (nch > maxdeg) nch = maxdeg;
+                    if (threadIdx.x < nch) S.Eid[threadIdx.x] = KID(S.A[s0 + threadIdx.x]);
+                    __syncthreads();
+                    block_distances<KIND>(ix, erow, S.Eid, nch, S.Ecnt);
+                    evals += nch;
+                    bool conflict = false;
+                    for (uint32_t t = 0; t < nch; t++) conflict |= (S.Ecnt[t] <= KCNT(e));
+                    __syncthreads();
+                    if (conflict) accept = false;
+                    s0 += nch; ch = PLAN_CH1;
+                }
+            }
+        }
+        if (accept) { if (threadIdx.x == 0) S.A[na] = e; na++; __syncthreads(); }
+    }
+    return na;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint32_t nb, const uint8_t *__restrict__ blevels,
+                                                   const uint32_t *__restrict__ cntmat, uint32_t efc, uint32_t ef_lds, int extend,
+                                                   uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ plan_keys,
+                                                   uint32_t *__restrict__ plan_n, unsigned long long *__restrict__ evals_total)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    const uint32_t maxdeg = 2 * ix.M;
+    SearchLds S = carve_lds(s_raw, ef_lds, maxdeg);
+    const uint32_t i = blockIdx.x;
+    const uint64_t id = b0 + i;
+    const int lv = blevels[i];
+    const uint4 *q = (const uint4 *)(ix.data + id * ix.stride);
+    uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
+    uint64_t evals = 0;
+    const bool have_graph = ix.n > 0;
+    uint32_t ep = 0, ep_cnt = 0;
+    if (have_graph) {
+        if (threadIdx.x == 0) S.Eid[0] = (uint32_t)ix.entry;
+        __syncthreads();
+        block_distances<KIND>(ix, q, S.Eid, 1, S.Ecnt);
+        ep = (uint32_t)ix.entry; ep_cnt = S.Ecnt[0]; evals++;
+        __syncthreads();
+        for (int L = ix.top; L > lv; L--) greedy_layer_block<KIND>(ix, q, S, ep, ep_cnt, L, evals);
+    }
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int L = lv; L >= 0; L--) {
+        uint32_t nW = 0;
+        if (have_graph && L <= ix.top) {
+            for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
+            __syncthreads();
+            nW = search_layer_block<KIND>(ix, q, S, vis, ep, ep_cnt, efc, L, evals);
+            ep = KID(S.R[0]); ep_cnt = KCNT(S.R[0]);
+        }
+        // batch-mates of sufficient level join the candidates (their distances come from the tile kernel)
+        uint64_t mykey = ~(uint64_t)0;
+        const bool ismate = threadIdx.x < nb && threadIdx.x != i && (int)blevels[threadIdx.x] >= L;
+        if (ismate) mykey = KEY(cntmat[(uint64_t)i * nb + threadIdx.x], (uint32_t)(b0 + threadIdx.x));
+        __syncthreads();
+        if (threadIdx.x < nb) S.C[threadIdx.x] = mykey;
+        const uint64_t mb = __ballot(ismate);
+        if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(mb);
+        __syncthreads();
+        uint32_t nm = 0;
+#pragma unroll
+        for (int w = 0; w < ST / 64; w++) nm += S.wsum[w];
+        uint32_t rank = 0;
+        if (ismate) for (uint32_t j = 0; j < nb; j++) rank += (S.C[j] < mykey);
+        __syncthreads();
+        if (ismate) S.C[nb + rank] = mykey;
+        __syncthreads();
+        if (nm) nW = block_merge(S.R, 0, nW, S.C + nb, nm, efc);
+        const uint32_t deg = L == 0 ? 2 * ix.M : ix.M;
+        const bool ext = (L == 0) && extend;
+        uint32_t na = 0;
+        if (nW) na = select_block<KIND>(ix, S, nW, deg, !(nW <= deg && !ext), evals);
+        uint64_t *pk = plan_keys + ((uint64_t)i * ix.max_layer + (uint32_t)L) * maxdeg;
+        for (uint32_t t = threadIdx.x; t < na; t += ST) pk[t] = S.A[t];
+        if (threadIdx.x == 0) plan_n[(uint64_t)i * ix.max_layer + (uint32_t)L] = na;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(evals_total, (unsigned long long)evals);
+}
+
+// ---- phase 2: links -------------------------------------------------------------------------------
+struct GraphDev {          // mutable adjacency
+    uint32_t *deg0, *nbr0, *cnt0; uint32_t *degU, *nbrU, *cntU; const int32_t *upidx;
+    uint32_t M, max_layer; uint64_t upper_base;
+};
+__device__ __forceinline__ void list_ptrs(const GraphDev &g, uint32_t list, uint32_t *&nbr, uint32_t *&cnt, uint32_t *&deg, uint32_t &cap)
+{
+    if (list < g.upper_base) { nbr = g.nbr0 + (uint64_t)list * 2 * g.M; cnt = g.cnt0 + (uint64_t)list * 2 * g.M; deg = g.deg0 + list; cap = 2 * g.M; }
+    else { uint64_t x = list - g.upper_base; nbr = g.nbrU + x * g.M; cnt = g.cntU + x * g.M; deg = g.degU + x; cap = g.M; }
+}
+__device__ __forceinline__ uint32_t list_of(const GraphDev &g, uint32_t node, uint32_t L)
+{
+    return L == 0 ? node : (uint32_t)(g.upper_base + (uint64_t)g.upidx[node] * g.max_layer + (L - 1));
+}
+// own lists of the new nodes
+__global__ void k_link_own(GraphDev g, uint64_t b0, uint32_t nb, const uint8_t *__restrict__ blevels, const uint64_t *__restrict__ plan_keys,
+                           const uint32_t *__restrict__ plan_n)
+{
+    const uint32_t i = blockIdx.x, maxdeg = 2 * g.M;
+    for (uint32_t L = 0; L <= blevels[i]; L++) {
+        uint32_t *nbr, *cnt, *deg, cap;
+        list_ptrs(g, list_of(g, (uint32_t)(b0 + i), L), nbr, cnt, deg, cap);
+        const uint32_t n = plan_n[(uint64_t)i * g.max_layer + L];
+        const uint64_t *pk = plan_keys + ((uint64_t)i * g.max_layer + L) * maxdeg;
+        for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) { nbr[t] = KID(pk[t]); cnt[t] = KCNT(pk[t]); }
+        if (threadIdx.x == 0) *deg = n;
+    }
+}
+// reverse links -> per-list inbox
+__global__ void k_link_scatter(GraphDev g, uint64_t b0, uint32_t nb, uint32_t inbox_cap, const uint8_t *__restrict__ blevels,
+                               const uint64_t *__restrict__ plan_keys, const uint32_t *__restrict__ plan_n, uint32_t *__restrict__ inbox_cnt,
+                               uint64_t *__restrict__ inbox, uint32_t *__restrict__ touched, uint32_t *__restrict__ ntouched)
+{
+    const uint32_t i = blockIdx.x, maxdeg = 2 * g.M;
+    for (uint32_t L = 0; L <= blevels[i]; L++) {
+        const uint32_t n = plan_n[(uint64_t)i * g.max_layer + L];
+        const uint64_t *pk = plan_keys + ((uint64_t)i * g.max_layer + L) * maxdeg;
+        for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+            const uint32_t list = list_of(g, KID(pk[t]), L);
+            const uint32_t pos = atomicAdd(&inbox_cnt[list], 1u);
+            inbox[(uint64_t)list * inbox_cap + pos] = KEY(KCNT(pk[t]), (uint32_t)(b0 + i));
+            if (pos == 0) touched[atomicAdd(ntouched, 1u)] = list;
+        }
+    }
+}
+// every touched list := the `cap` smallest keys of (list  u  inbox), duplicates removed (SPEC 5: order-free)
+constexpr int LM_T = 256, LM_MAX = 1024;
+__global__ __launch_bounds__(LM_T) void k_link_merge(GraphDev g, uint32_t inbox_cap, uint32_t *__restrict__ inbox_cnt, const uint64_t *__restrict__ inbox,
+                                                      const uint32_t *__restrict__ touched, const uint32_t *__restrict__ ntouched)
+{
+    __shared__ uint64_t keys[LM_MAX];
+    __shared__ uint32_t flag[LM_MAX];
+    const uint32_t nt = *ntouched;
+    for (uint32_t b = blockIdx.x; b < nt; b += gridDim.x) {
+        const uint32_t list = touched[b];
+        uint32_t *nbr, *cnt, *deg, cap;
+        list_ptrs(g, list, nbr, cnt, deg, cap);
+        const uint32_t d = *deg, ni = inbox_cnt[list], n = d + ni;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < n; t += LM_T)
+            keys[t] = t < d ? KEY(cnt[t], nbr[t]) : inbox[(uint64_t)list * inbox_cap + (t - d)];
+        __syncthreads();
+        // duplicates (the same undirected edge proposed from both ends inside one batch) have identical keys
+        for (uint32_t t = threadIdx.x; t < n; t += LM_T) {
+            const uint64_t k = keys[t]; uint32_t dup = 0;
+            for (uint32_t j = 0; j < t; j++) dup |= (keys[j] == k);
+            flag[t] = dup;
+        }
+        __syncthreads();
+        uint32_t rk[LM_MAX / LM_T]; uint64_t kv[LM_MAX / LM_T];
+#pragma unroll
+        for (int it = 0; it < LM_MAX / LM_T; it++) {
+            const uint32_t t = threadIdx.x + it * LM_T;
+            rk[it] = 0xFFFFFFFFu; kv[it] = 0;
+            if (t < n && !flag[t]) {
+                const uint64_t k = keys[t]; uint32_t r = 0;
+                for (uint32_t j = 0; j < n; j++) r += (!flag[j] && keys[j] < k);
+                rk[it] = r; kv[it] = k;
+            }
+        }
+        uint32_t ndup = 0;
+        for (uint32_t j = 0; j < n; j++) ndup += flag[j];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < LM_MAX / LM_T; it++) if (rk[it] < cap) { nbr[rk[it]] = KID(kv[it]); cnt[rk[it]] = KCNT(kv[it]); }
+        if (threadIdx.x == 0) { const uint32_t tot = n - ndup; *deg = tot < cap ? tot : cap; inbox_cnt[list] = 0; }
+    }
+}
+
 }  // namespace gs
 
 // ------------------------------------------------------------------------------------------------------
@@ -306,6 +506,9 @@ struct gs_index {
     uint64_t n_upper = 0, cap_upper = 0;
     gs::DevBuf data, levels, deg0, nbr0, cnt0, upidx, degU, nbrU, cntU;
     gs::DevBuf visited, counter;
+    // insert scratch
+    gs::DevBuf blevels, cntmat, plan_keys, plan_n, inbox, inbox_cnt, touched, ntouched, evals_dev;
+    uint64_t inbox_lists = 0;
     uint64_t insert_evals = 0;
 };
 
@@ -548,18 +751,117 @@ int gs_index_parallel_search_dev(gs_index *ix, const void *queries_dev, uint64_t
     return search_common(ix, queries_dev, true, nq, knbn, ef, ids, dist, count, evals);
 }
 
-int gs_index_parallel_insert(gs_index *ix, const void *sigs, uint64_t n)
+static int gen_level_host(const gs_index *ix, uint64_t id)
+{
+    // SPEC 5 level generator (hnsw_rs LayerGenerator restated; level scale = f / ln(M), dnasketch.rs:141)
+    const double scale = ix->prm.scale_modify / log((double)ix->prm.max_nb_conn);
+    gs::Rng g; g.seed(ix->prm.seed ^ gs::fx64(id));
+    const double u = g.u64f();
+    const uint64_t ML = ix->prm.max_layer, zone = gs::uint_zone(ML);
+    if (u == 0.0) return (int)gs::rng_uint(g, ML, zone);
+    int l = (int)floor(-log(u) * scale);
+    if (l >= (int)ML) l = (int)gs::rng_uint(g, ML, zone);
+    return l;
+}
+
+static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n)
 {
     GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
-    (void)sigs; (void)n;
-    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "device-side parallel_insert is not implemented yet (use gs_index_import)");
+    if (n == 0) return GS_OK;
+    GS_REQUIRE(sigs, GS_ERR_INVALID, "null signatures");
+    gs_ctx *c = ix->ctx;
+    const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer, maxdeg = 2 * M, efc = ix->prm.ef_construction;
+    const uint32_t B = std::min<uint32_t>(std::min<uint32_t>(ix->prm.insert_batch, 256u), gs::ST);
+    GS_REQUIRE(!ix->prm.keep_pruned, GS_ERR_UNSUPPORTED, "keep_pruned=true is not implemented on the device (gsearch sets false, dnasketch.rs:160)");
+    GS_REQUIRE(!ix->prm.extend_candidates || efc > maxdeg, GS_ERR_UNSUPPORTED,
+               "extend_candidates needs ef_construction > 2*max_nb_conn on the device (then the extension is provably a no-op, DESIGN.md)");
+    GS_REQUIRE(ix->n + n < ((uint64_t)1 << 32) - 1, GS_ERR_INVALID, "too many points");
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    // levels and upper-layer slots of the new points (host: needs libm log, like the oracle)
+    std::vector<uint8_t> lv(n);
+    std::vector<int32_t> up(n);
+    uint64_t nup = ix->n_upper;
+    for (uint64_t i = 0; i < n; i++) { lv[i] = (uint8_t)gen_level_host(ix, ix->n + i); up[i] = lv[i] > 0 ? (int32_t)nup++ : -1; }
+    int rc = gs::index_reserve(ix, ix->n + n, nup);
+    if (rc) return rc;
+    const uint64_t first = ix->n;
+    if ((rc = gs::upload_rows(c, ix->data.as<uint8_t>() + first * ix->stride, ix->stride, sigs, ix->rowbytes, n,
+                              on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
+    GS_HIP_CHECK(hipMemcpyAsync(ix->levels.as<uint8_t>() + first, lv.data(), n, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(ix->upidx.as<int32_t>() + first, up.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
+    // scratch
+    const uint32_t ef_lds = std::max(efc, B);
+    const size_t lds = gs::search_lds_bytes(ef_lds, maxdeg);
+    GS_REQUIRE(lds <= 160 * 1024 - 64, GS_ERR_UNSUPPORTED, "ef_construction=%u needs %zu bytes of LDS", efc, lds);
+    GS_REQUIRE(2 * (size_t)ef_lds + maxdeg + 64 <= (size_t)gs::SMAXI * gs::ST && maxdeg <= (uint32_t)gs::ST, GS_ERR_UNSUPPORTED, "ef_construction too large");
+    const uint32_t vis_words = (uint32_t)((first + n + 31) / 32);
+    if ((rc = ix->visited.ensure((size_t)4 * vis_words * std::max<uint32_t>(B, c->n_cu)))) return rc;
+    if ((rc = ix->blevels.ensure(B))) return rc;
+    if ((rc = ix->cntmat.ensure((size_t)4 * B * B))) return rc;
+    if ((rc = ix->plan_keys.ensure((size_t)8 * B * ML * maxdeg))) return rc;
+    if ((rc = ix->plan_n.ensure((size_t)4 * B * ML))) return rc;
+    if ((rc = ix->touched.ensure((size_t)4 * B * (maxdeg + (size_t)ML * M)))) return rc;
+    if ((rc = ix->ntouched.ensure(64))) return rc;
+    if (!ix->evals_dev.p) { if ((rc = ix->evals_dev.alloc(64))) return rc; GS_HIP_CHECK(hipMemsetAsync(ix->evals_dev.p, 0, 64, c->stream)); }
+    const uint64_t nlists = ix->cap + ix->cap_upper * ML;
+    if (nlists != ix->inbox_lists) {
+        if ((rc = ix->inbox.alloc((size_t)8 * nlists * B))) return rc;
+        if ((rc = ix->inbox_cnt.alloc((size_t)4 * nlists))) return rc;
+        GS_HIP_CHECK(hipMemsetAsync(ix->inbox_cnt.p, 0, (size_t)4 * nlists, c->stream));
+        ix->inbox_lists = nlists;
+    }
+    gs::GraphDev g;
+    g.deg0 = ix->deg0.as<uint32_t>(); g.nbr0 = ix->nbr0.as<uint32_t>(); g.cnt0 = ix->cnt0.as<uint32_t>();
+    g.degU = ix->degU.as<uint32_t>(); g.nbrU = ix->nbrU.as<uint32_t>(); g.cntU = ix->cntU.as<uint32_t>();
+    g.upidx = ix->upidx.as<int32_t>(); g.M = M; g.max_layer = ML; g.upper_base = ix->cap;
+    ix->n_upper = nup;
+    for (uint64_t b0 = first; b0 < first + n; b0 += B) {
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(B, first + n - b0);
+        const uint8_t *blv = lv.data() + (b0 - first);
+        GS_HIP_CHECK(hipMemcpyAsync(ix->blevels.p, blv, nb, hipMemcpyHostToDevice, c->stream));
+        GS_HIP_CHECK(hipMemsetAsync(ix->plan_n.p, 0, (size_t)4 * nb * ML, c->stream));
+        GS_HIP_CHECK(hipMemsetAsync(ix->ntouched.p, 0, 4, c->stream));
+        const uint8_t *rows = ix->data.as<uint8_t>() + b0 * ix->stride;
+        if (nb > 1) { if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, rows, nb, ix->stride, nullptr, ix->cntmat.as<uint32_t>()))) return rc; }
+        gs::IndexDev d = gs::index_dev(ix);
+        d.n = b0; d.entry = ix->entry; d.top = ix->top;                  // the graph frozen at batch start
+        const uint32_t vw = (uint32_t)((b0 + 31) / 32);
+        {
+            gs::ProfScope ps(c, gs::FAM_INSERT);
+#define GS_LAUNCH_PLAN(K)                                                                                                  \
+    do {                                                                                                                   \
+        auto kern = gs::k_hnsw_plan<K>;                                                                                    \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), efc, ef_lds, \
+                           ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
+                           ix->evals_dev.as<unsigned long long>());                                                        \
+    } while (0)
+            if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_PLAN(GS_KIND_F32);
+            else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_PLAN(GS_KIND_U32);
+            else GS_LAUNCH_PLAN(GS_KIND_U64);
+#undef GS_LAUNCH_PLAN
+        }
+        GS_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(gs::k_link_own, dim3(nb), dim3(256), 0, c->stream, g, b0, nb, ix->blevels.as<uint8_t>(), ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>());
+        hipLaunchKernelGGL(gs::k_link_scatter, dim3(nb), dim3(256), 0, c->stream, g, b0, nb, B, ix->blevels.as<uint8_t>(), ix->plan_keys.as<uint64_t>(),
+                           ix->plan_n.as<uint32_t>(), ix->inbox_cnt.as<uint32_t>(), ix->inbox.as<uint64_t>(), ix->touched.as<uint32_t>(), ix->ntouched.as<uint32_t>());
+        hipLaunchKernelGGL(gs::k_link_merge, dim3(std::min<uint32_t>(nb * 64u, (uint32_t)c->n_cu * 8u)), dim3(gs::LM_T), 0, c->stream, g, B, ix->inbox_cnt.as<uint32_t>(),
+                           ix->inbox.as<uint64_t>(), ix->touched.as<uint32_t>(), ix->ntouched.as<uint32_t>());
+        GS_HIP_CHECK(hipGetLastError());
+        // entry point: the first id of the highest new level (SPEC 5)
+        for (uint32_t i = 0; i < nb; i++) if ((int)blv[i] > ix->top) { ix->top = blv[i]; ix->entry = (int64_t)(b0 + i); }
+        ix->n = b0 + nb;
+        // the level / batch buffers are reused by the next batch: the stream orders the copies after the kernels
+    }
+    unsigned long long ev = 0;
+    GS_HIP_CHECK(hipMemcpyAsync(&ev, ix->evals_dev.p, 8, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    ix->insert_evals = ev;
+    return GS_OK;
 }
-int gs_index_parallel_insert_dev(gs_index *ix, const void *sigs_dev, uint64_t n)
-{
-    GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
-    (void)sigs_dev; (void)n;
-    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "device-side parallel_insert is not implemented yet (use gs_index_import)");
-}
+
+int gs_index_parallel_insert(gs_index *ix, const void *sigs, uint64_t n) { return insert_common(ix, sigs, false, n); }
+int gs_index_parallel_insert_dev(gs_index *ix, const void *sigs_dev, uint64_t n) { return insert_common(ix, sigs_dev, true, n); }
 
 int gs_index_bruteforce_search(gs_index *ix, const void *queries, uint64_t nq, uint32_t knbn, uint64_t *ids, float *dist)
 {

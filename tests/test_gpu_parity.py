@@ -134,3 +134,44 @@ def test_bruteforce_matches_oracle(gpu_ctx):
     ids, dist = hn.bruteforce_search(q, 12)
     oids, odist = O.bruteforce_topk(db, q, 12)
     assert np.array_equal(ids, oids) and np.array_equal(dist, odist)
+
+
+@pytest.mark.parametrize("dtype,m,M,efc,B,scale,n_roots,per", [
+    (np.float32, 256, 8, 32, 1, 1.0, 10, 12),
+    (np.float32, 256, 8, 32, 16, 1.0, 20, 25),
+    (np.uint64, 120, 16, 64, 64, 1.0, 30, 30),
+    (np.float32, 1000, 12, 100, 256, 0.25, 25, 40),
+    (np.uint32, 64, 4, 16, 7, 1.0, 15, 20),
+])
+def test_parallel_insert_matches_oracle(gpu_ctx, dtype, m, M, efc, B, scale, n_roots, per):
+    """device-built graph == oracle-built graph (same batch size), then identical search answers"""
+    import gsearch_amd as G
+    db = H.synth_sig_db(n_roots, per, m, 21, dtype=dtype, jlo=0.05, jhi=0.95)
+    oix = O.Index(dtype, m, M, efc, scale_modify=scale, seed=77)
+    hn = G.Hnsw.new(M, 10000, 16, efc, G.DistHamming(), dtype=dtype, seed=77, insert_batch=B)
+    hn.modify_level_scale(scale)
+    hn.set_extend_candidates(True)
+    hn.set_keeping_pruned(False)
+    # two calls: the second one continues an existing graph (the `add` path of the reference)
+    half = len(db) // 2 + 3
+    for part in (db[:half], db[half:]):
+        oix.parallel_insert(part, batch=B)
+        hn.parallel_insert(part)
+    assert hn.get_nb_point() == oix.nb_point() == len(db)
+    g, og = hn.export_graph(), oix.export()
+    assert g["entry"] == og["entry"] and g["n_upper"] == og["n_upper"]
+    for key in ("levels", "upidx", "deg0", "degU"):
+        assert np.array_equal(g[key], og[key]), key
+    # adjacency beyond deg is unspecified: compare the valid prefix
+    for i in range(len(db)):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]), ("nbr0", i)
+        assert np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d]), ("cnt0", i)
+    for u in range(og["n_upper"]):
+        for L in range(og["degU"].shape[1]):
+            d = int(og["degU"][u, L])
+            assert np.array_equal(g["nbrU"][u, L, :d], og["nbrU"][u, L, :d]), ("nbrU", u, L)
+    q = H.queries_from(db, 40, 6, frac=0.3)
+    ids, dist, cnt, ev = hn.search_arrays(q, 10, 50)
+    oids, odist, ocnt, oev = oix.parallel_search(q, 10, 50)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist) and np.array_equal(ev, oev)
