@@ -182,6 +182,153 @@ def run_sketch(args, torch, rank, world, local):
         ctx.free(p)
 
 
+# ------------------------------------------------------------------------------------------------------
+def run_request(args, torch, rank, world, local):
+    """BASELINE configs[2] (and [3] for N>1): `request` = sketch the query genomes + HNSW parallel_search (ef=5000, n=50)
+    against a prebuilt OptDens HNSW (M=128, efc=1600, scale 0.25) over `--db-genomes` synthetic genomes, DB replicated
+    per GPU, queries sharded, top-k all-gathered over RCCL."""
+    import ctypes as C
+    import gsearch_amd as G
+    from gsearch_amd.api import _p
+    chk = G._lib.check
+
+    k, m, L = args.kmer, args.sketch_size, args.genome_len
+    N, nq_rank, qps = args.db_genomes, args.queries, args.queries_per_step
+    knbn, ef = args.knbn, args.ef_search
+    n_roots = max(N // args.per_root, 1)
+    mu_lo, mu_hi = 0.001, 0.08
+    ctx = G.Context(local)
+    lib = ctx.L
+    prm = G.SeqSketcherParams(k, m, "optdens")
+    words = (L + 31) // 32
+    gbytes = words * 8
+    hn = G.Hnsw.new(args.max_nb_conn, 1_500_000, 16, args.ef_construction, G.DistHamming(ctx), dtype=np.float32, seed=args.seed,
+                    insert_batch=256, ctx=ctx)
+    hn.modify_level_scale(args.scale_modify); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+    hn._ensure(m)
+
+    def sketch_dev(d_seq, n, d_sig, d_rs, d_rl, d_goff):
+        chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, n * gbytes + 64, d_rs, d_rl, n, d_goff, n, d_sig))
+
+    # ---- tohnsw (untimed setup): generate -> sketch -> parallel_insert, in chunks
+    chunk = min(args.build_chunk, N)
+    d_seq = ctx.alloc(chunk * gbytes + 64)
+    d_sig = ctx.alloc(chunk * m * 4)
+    rs = np.arange(chunk, dtype=np.uint64) * np.uint64(words * 32)
+    d_rs, d_rl, d_goff = ctx.alloc(rs.nbytes), ctx.alloc(rs.nbytes), ctx.alloc(8 * (chunk + 1))
+    ctx.upload(d_rs, rs); ctx.upload(d_rl, np.full(chunk, L, np.uint64)); ctx.upload(d_goff, np.arange(chunk + 1, dtype=np.uint64))
+    t_b = time.perf_counter()
+    for g0 in range(0, N, chunk):
+        n = min(chunk, N - g0)
+        chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, g0, n, L, n_roots, mu_lo, mu_hi, d_seq))
+        sketch_dev(d_seq, n, d_sig, d_rs, d_rl, d_goff)
+        chk(lib.gs_index_parallel_insert_dev(hn.h, d_sig, n))
+        if rank == 0 and args.verbose:
+            print("# built %d / %d in %.1fs" % (g0 + n, N, time.perf_counter() - t_b), file=sys.stderr, flush=True)
+    ctx.sync()
+    build_s = time.perf_counter() - t_b
+    ctx.free(d_seq); ctx.free(d_sig)
+
+    # ---- query genomes resident in HBM before the timed region: fresh mutants of the DB's roots
+    d_qseq = ctx.alloc(nq_rank * gbytes + 64)
+    q_first = 1_000_000_000 + rank * nq_rank
+    chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, q_first, nq_rank, L, n_roots, mu_lo, mu_hi, d_qseq))
+    d_qsig = ctx.alloc(qps * m * 4)
+    ids_t = torch.empty((qps, knbn), dtype=torch.int64, device="cuda")
+    dist_t = torch.empty((qps, knbn), dtype=torch.float32, device="cuda")
+    cnt_t = torch.empty((qps,), dtype=torch.int32, device="cuda")
+    ev_t = torch.zeros((qps,), dtype=torch.int64, device="cuda")
+    if world > 1:
+        import torch.distributed as dist
+        all_ids = torch.empty((world * qps, knbn), dtype=torch.int64, device="cuda")
+        all_dist = torch.empty((world * qps, knbn), dtype=torch.float32, device="cuda")
+    nsteps_q = max(nq_rank // qps, 1)
+    evals_steps = []
+
+    def step(i):
+        b = i % nsteps_q
+        sketch_dev(d_qseq + b * qps * gbytes, qps, d_qsig, d_rs, d_rl, d_goff)
+        chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, qps, knbn, ef, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), ev_t.data_ptr()))
+        if world > 1:      # RCCL all-gather of the per-rank top-k blocks (ids + distances), SURVEY 8e
+            dist.all_gather_into_tensor(all_ids, ids_t)
+            dist.all_gather_into_tensor(all_dist, dist_t)
+
+    for i in range(args.warmup):
+        step(args.steps + i)
+    ctx.profile(True)
+    ctx.profile_read(2, reset=True); ctx.profile_read(0, reset=True)
+    barrier_sync(torch, world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        evals_steps.append(ev_t.clone())
+    barrier_sync(torch, world)
+    dt = max_over_ranks(torch, world, time.perf_counter() - t0)
+    srch_ms, srch_n = ctx.profile_read(2, reset=True)
+    sk_ms, sk_n = ctx.profile_read(0, reset=True)
+    ctx.profile(False)
+    evals_total = float(sum(int(e.sum().item()) for e in evals_steps))
+    value = world * qps * args.steps / dt
+    out = {
+        "metric": "query genomes/sec", "value": value, "unit": "genomes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "request: %d query genomes x %.1f Mbp per GPU per step (k=%d s=%d optdens sketch + HNSW search n=%d ef=%d) against a %d-genome "
+                               "OptDens HNSW (M=%d efc=%d scale %.2f) built on the GPU, DB replicated per GPU, queries sharded (BASELINE configs[2]/[3])"
+                               % (qps, L / 1e6, k, m, knbn, ef, N, args.max_nb_conn, args.ef_construction, args.scale_modify),
+                   "db_genomes": N, "queries_per_gpu_per_step": qps, "genome_len": L, "kmer_size": k, "sketch_size": m, "knbn": knbn, "ef_search": ef,
+                   "max_nb_conn": args.max_nb_conn, "ef_construction": args.ef_construction},
+        "build_seconds": build_s, "build_genomes_per_sec": N / build_s, "dist_evals_per_query": evals_total / (qps * args.steps),
+        "sketch_kmers_per_sec": (L - k + 1) * qps * sk_n / (sk_ms * 1e-3) if sk_ms > 0 else None,
+    }
+    if rank == 0:
+        avg_ms = srch_ms / max(srch_n, 1)
+        alg_bytes_launch = evals_total / max(srch_n, 1) * m * 4.0        # 72 000 B per (query,candidate) evaluation, SURVEY 8d
+        achieved = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "k_hnsw_search", "avg_launch_ms": avg_ms, "launches": srch_n, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                           "dist_evals_per_sec": evals_total / (srch_ms * 1e-3) if srch_ms > 0 else 0.0}
+        # ---- parity / recall / CPU baseline on a bounded sample of the last step's queries
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        ns = min(args.cpu_sample_queries, qps)
+        last = (args.steps - 1) % nsteps_q
+        qsig = ctx.download(d_qsig, (qps, m), np.float32)[:ns]
+        ids_g = ids_t.cpu().numpy().view(np.uint64)[:ns]
+        dist_g = dist_t.cpu().numpy()[:ns]
+        # (a) sketch parity + CPU sketch time for the sample's genomes
+        op = O.params(k, m, "optdens")
+        qbytes = ctx.download(d_qseq + last * qps * gbytes, (ns, gbytes), np.uint8)
+        buf = np.concatenate([qbytes.reshape(-1), np.zeros(16, np.uint8)])
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        osig = O.sketch_batch(op, buf, np.arange(ns, dtype=np.uint64) * np.uint64(words * 32), np.full(ns, L, np.uint64),
+                              np.arange(ns + 1, dtype=np.uint64), nthreads=cores)
+        cpu_sketch_s = time.perf_counter() - t0
+        sketch_ok = bool(np.array_equal(osig.view(np.uint32), qsig.view(np.uint32)))
+        # (b) the same graph searched by the oracle (CPU, all cores)
+        db = hn.get_data()
+        oix = O.Index(np.float32, m, args.max_nb_conn, args.ef_construction, scale_modify=args.scale_modify, seed=args.seed)
+        oix.import_graph(db, hn.export_graph())
+        t0 = time.perf_counter()
+        oids, odist, ocnt, oev = oix.parallel_search(qsig, knbn, ef, nthreads=cores)
+        cpu_search_s = time.perf_counter() - t0
+        ids_ok = bool(np.array_equal(oids, ids_g)) and bool(np.array_equal(odist.view(np.uint32), dist_g.view(np.uint32)))
+        # (c) recall@knbn against exhaustive search (tie-aware: a neighbour counts if it is within the k-th exact distance)
+        nb = min(ns, 32)
+        bi, bd = hn.bruteforce_search(qsig[:nb], knbn)
+        rec_gpu = float(np.mean([(dist_g[i] <= bd[i, -1]).mean() for i in range(nb)]))
+        rec_cpu = float(np.mean([(odist[i] <= bd[i, -1]).mean() for i in range(nb)]))
+        ani_err = float(max(abs(G.ani(float(d), k) - O.ani(float(d), k)) for d in dist_g[0][: min(knbn, 8)]))
+        out["parity_checked"] = {"queries": ns, "sketch_bit_exact_vs_oracle": sketch_ok, "neighbour_ids_and_distances_equal_oracle": ids_ok,
+                                 "max_ani_abs_err": ani_err}
+        out["recall_at_%d" % knbn] = {"gpu": rec_gpu, "cpu_oracle": rec_cpu, "queries": nb, "reference": "exhaustive DistHamming top-k, tie-aware"}
+        out["cpu_baseline"] = {"value": ns / (cpu_sketch_s + cpu_search_s), "unit": "genomes/s", "cores": cores, "kind": "port",
+                               "sample": "%d of the step's query genomes: oracle sketch %.2fs + oracle parallel_search (same graph, ef=%d) %.2fs, OpenMP over genomes/queries"
+                                         % (ns, cpu_sketch_s, ef, cpu_search_s),
+                               "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,13 +340,26 @@ def main():
     ap.add_argument("--kmer", type=int, default=21)
     ap.add_argument("--sketch-size", type=int, default=18000)
     ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--cpu-sample", type=int, default=512)
+    # request workload (BASELINE configs[2])
+    ap.add_argument("--db-genomes", type=int, default=300000)
+    ap.add_argument("--queries", type=int, default=10000, help="query genomes per GPU (resident in HBM)")
+    ap.add_argument("--queries-per-step", type=int, default=2500)
+    ap.add_argument("--knbn", type=int, default=50)
+    ap.add_argument("--ef-search", type=int, default=5000, help="gsearch hard-codes 5000 (src/bin/gsearch.rs:893)")
+    ap.add_argument("--max-nb-conn", type=int, default=128)
+    ap.add_argument("--ef-construction", type=int, default=1600)
+    ap.add_argument("--scale-modify", type=float, default=0.25)
+    ap.add_argument("--per-root", type=int, default=100)
+    ap.add_argument("--build-chunk", type=int, default=8192)
+    ap.add_argument("--cpu-sample-queries", type=int, default=256)
+    ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     torch, rank, world, local = dist_init(args.gpus)
     if args.workload == "sketch":
         run_sketch(args, torch, rank, world, local)
     else:
-        raise SystemExit("request workload: see bench_request (not wired yet)")
+        run_request(args, torch, rank, world, local)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

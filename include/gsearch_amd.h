@@ -164,10 +164,14 @@ uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluation
 /*   splitmix64 finaliser of (seed*0x9e3779b97f4a7c15 + g*0xbf58476d1ce4e5b9 + w)  (see gs_synth.hip) */
 int gs_synth_dna_dev(gs_ctx *, uint64_t seed, uint64_t first_genome, uint64_t n_genomes, uint64_t len_bases,
                      void *seq_dev /* n_genomes * ceil(len/32)*8 bytes */);
-/* sketch-level database: n_roots random signatures, `per_root` members each, member slot kept from its
- * root with probability J(member) ~ U[j_lo, j_hi], else re-randomised. Row r = root r/per_root. */
+/* related genomes: genome g = root genome number hash(seed,g) mod n_roots with iid substitutions at rate
+ * mu(g) ~ U[mu_lo, mu_hi] (Jaccard to the root ~ p/(2-p), p=(1-mu)^k). Same layout as gs_synth_dna_dev. */
+int gs_synth_dna_family_dev(gs_ctx *, uint64_t seed, uint64_t first_genome, uint64_t n_genomes, uint64_t len_bases,
+                            uint64_t n_roots, double mu_lo, double mu_hi, void *seq_dev);
+/* sketch-level database: n_roots random root signatures; row r belongs to root hash(seed,r) mod n_roots
+ * and keeps each root slot with probability J(r) ~ U[j_lo, j_hi], else draws its own value. */
 int gs_synth_sigs_dev(gs_ctx *, int kind, uint32_t m, uint64_t seed, uint64_t first_row, uint64_t n_rows,
-                      uint64_t per_root, double j_lo, double j_hi, void *sigs_dev /* n_rows x m */);
+                      uint64_t n_roots, double j_lo, double j_hi, void *sigs_dev /* n_rows x m */);
 
 #ifdef __cplusplus
 }

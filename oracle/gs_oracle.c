@@ -79,6 +79,20 @@ static inline uint64_t rng_uint(rng_t *g, uint64_t n)
     }
 }
 
+/* test hooks: expose the PRNG restatement so tests can pin it against the published reference vectors
+ * of SplitMix64 / xoshiro256++ / fxhash (tests/test_oracle_kat.py) */
+void go_test_splitmix(uint64_t seed, uint32_t n, uint64_t *out) { uint64_t x = seed; for (uint32_t i = 0; i < n; i++) out[i] = splitmix64(&x); }
+void go_test_xoshiro(const uint64_t *state4, uint32_t n, uint64_t *out)
+{
+    rng_t g; memcpy(g.s, state4, 32);
+    for (uint32_t i = 0; i < n; i++) out[i] = rng_next64(&g);
+}
+void go_test_seeded(uint64_t seed, uint32_t n, uint64_t *out) { rng_t g; rng_seed(&g, seed); for (uint32_t i = 0; i < n; i++) out[i] = rng_next64(&g); }
+uint64_t go_test_fx(uint64_t v, int hasher_bits, int value_bits) { return hasher_bits == 64 ? fx64(v) : fx32(v, value_bits); }
+uint64_t go_test_uint(uint64_t seed, uint64_t n) { rng_t g; rng_seed(&g, seed); return rng_uint(&g, n); }
+double go_test_u64f(uint64_t seed) { rng_t g; rng_seed(&g, seed); return rng_u64f(&g); }
+float go_test_u32f(uint64_t seed) { rng_t g; rng_seed(&g, seed); return (float)rng_r23(&g) * 0x1.0p-23f; }
+
 /* ------------------------------------------------------------------------------------------ */
 /* SPEC 1: parameters, sequences, k-mers                                                       */
 /* ------------------------------------------------------------------------------------------ */
@@ -873,6 +887,35 @@ int go_bruteforce_topk(int kind, uint32_t m, const void *db, uint64_t n, const v
         }
         free(keys);
     }
+    return 0;
+}
+
+/* load a graph in the export layout (used to hand a device-built graph to the CPU baseline / parity check) */
+int go_index_import(go_index *ix, const void *sigs, uint64_t n, const uint8_t *levels, int64_t entry, const uint32_t *deg0,
+                    const uint32_t *nbr0, const uint32_t *cnt0, const int32_t *upidx, const uint32_t *degU, const uint32_t *nbrU,
+                    const uint32_t *cntU)
+{
+    if (!ix || ix->n != 0 || n == 0) return -1;
+    uint32_t M = ix->M, ML = ix->max_layer;
+    ix->cap = n;
+    ix->data = (uint8_t *)malloc(ix->row * n);
+    ix->nodes = (node_t *)malloc(sizeof(node_t) * n);
+    memcpy(ix->data, sigs, ix->row * n);
+    ix->top = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        node_t *nd = &ix->nodes[i];
+        node_alloc(ix, nd, levels[i]);
+        nd->deg[0] = deg0[i];
+        for (uint32_t t = 0; t < deg0[i]; t++) nd->nbr[0][t] = KEY(cnt0[i * 2 * M + t], nbr0[i * 2 * M + t]);
+        for (int L = 1; L <= levels[i]; L++) {
+            uint64_t u = (uint64_t)upidx[i];
+            nd->deg[L] = degU[u * ML + (uint32_t)(L - 1)];
+            for (uint32_t t = 0; t < nd->deg[L]; t++)
+                nd->nbr[L][t] = KEY(cntU[(u * ML + (uint32_t)(L - 1)) * M + t], nbrU[(u * ML + (uint32_t)(L - 1)) * M + t]);
+        }
+        if (levels[i] > ix->top) ix->top = levels[i];
+    }
+    ix->n = n; ix->entry = entry;
     return 0;
 }
 

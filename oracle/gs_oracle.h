@@ -77,7 +77,19 @@ int      go_bruteforce_topk(int kind, uint32_t m, const void *db, uint64_t n, co
 int      go_index_export(const go_index *, uint8_t *levels, int64_t *entry, uint32_t *deg0, uint32_t *nbr0,
                          uint32_t *cnt0, int32_t *upidx, uint64_t *n_upper, uint32_t *degU, uint32_t *nbrU,
                          uint32_t *cntU);
+int      go_index_import(go_index *, const void *sigs, uint64_t n, const uint8_t *levels, int64_t entry, const uint32_t *deg0,
+                         const uint32_t *nbr0, const uint32_t *cnt0, const int32_t *upidx, const uint32_t *degU,
+                         const uint32_t *nbrU, const uint32_t *cntU);
 uint64_t go_index_total_evals(const go_index *);       /* distance evaluations spent in insert so far */
+
+/* ---- test hooks (PRNG restatement vs published reference vectors) ---- */
+void     go_test_splitmix(uint64_t seed, uint32_t n, uint64_t *out);
+void     go_test_xoshiro(const uint64_t *state4, uint32_t n, uint64_t *out);
+void     go_test_seeded(uint64_t seed, uint32_t n, uint64_t *out);
+uint64_t go_test_fx(uint64_t v, int hasher_bits, int value_bits);
+uint64_t go_test_uint(uint64_t seed, uint64_t n);
+double   go_test_u64f(uint64_t seed);
+float    go_test_u32f(uint64_t seed);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,91 @@
+"""Known-answer tests that pin the CPU oracle to PUBLISHED material (the reference itself has no tests):
+ * SplitMix64 / xoshiro256++ reference vectors (Vigna's reference code; the xoshiro vector is the one the
+   rand_xoshiro crate tests against), fxhash constants;
+ * the distance -> ANI table of the reference README (README.md:231-242) against reformat.rs:80-86.
+"""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+
+
+def _hooks():
+    L = O.lib()
+    L.go_test_splitmix.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+    L.go_test_xoshiro.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.go_test_seeded.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+    L.go_test_fx.argtypes = [C.c_uint64, C.c_int, C.c_int]
+    L.go_test_fx.restype = C.c_uint64
+    L.go_test_uint.argtypes = [C.c_uint64, C.c_uint64]
+    L.go_test_uint.restype = C.c_uint64
+    L.go_test_u64f.argtypes = [C.c_uint64]
+    L.go_test_u64f.restype = C.c_double
+    L.go_test_u32f.argtypes = [C.c_uint64]
+    L.go_test_u32f.restype = C.c_float
+    return L
+
+
+def test_splitmix64_reference_vector():
+    out = np.zeros(5, np.uint64)
+    _hooks().go_test_splitmix(1234567, 5, out.ctypes.data_as(C.c_void_p))
+    assert out.tolist() == [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431, 16408922859458223821]
+
+
+def test_xoshiro256plusplus_reference_vector():
+    st = np.array([1, 2, 3, 4], np.uint64)
+    out = np.zeros(10, np.uint64)
+    _hooks().go_test_xoshiro(st.ctypes.data_as(C.c_void_p), 10, out.ctypes.data_as(C.c_void_p))
+    assert out.tolist() == [41943041, 58720359, 3588806011781223, 3591011842654386, 9228616714210784205, 9973669472204895162,
+                            14011001112246962877, 12406186145184390807, 15849039046786891736, 10450023813501588000]
+
+
+def test_seed_from_u64_is_splitmix_then_xoshiro():
+    L = _hooks()
+    sm = np.zeros(4, np.uint64)
+    L.go_test_splitmix(42, 4, sm.ctypes.data_as(C.c_void_p))
+    a, b = np.zeros(6, np.uint64), np.zeros(6, np.uint64)
+    L.go_test_xoshiro(sm.ctypes.data_as(C.c_void_p), 6, a.ctypes.data_as(C.c_void_p))
+    L.go_test_seeded(42, 6, b.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(a, b)
+
+
+def test_fxhash_constants():
+    L = _hooks()
+    assert L.go_test_fx(1, 64, 64) == 0x517cc1b727220a95
+    assert L.go_test_fx(3, 64, 64) == (3 * 0x517cc1b727220a95) % 2 ** 64
+    assert L.go_test_fx(1, 32, 32) == 0x9e3779b9
+    # u64 through FxHasher32 = two 32-bit writes, low word first
+    h = (1 * 0x9e3779b9) % 2 ** 32
+    h = ((((h << 5) | (h >> 27)) & 0xFFFFFFFF) ^ 2) * 0x9e3779b9 % 2 ** 32
+    assert L.go_test_fx((2 << 32) | 1, 32, 64) == h
+
+
+def test_uniform_samplers_follow_rand08():
+    L = _hooks()
+    first = np.zeros(1, np.uint64)
+    for seed in (0, 1, 2 ** 63 + 12345):
+        L.go_test_seeded(seed, 1, first.ctypes.data_as(C.c_void_p))
+        x = int(first[0])
+        assert L.go_test_u64f(seed) == (x >> 12) * 2.0 ** -52
+        assert L.go_test_u32f(seed) == np.float32((x >> 41) * 2.0 ** -23)
+        for n in (1, 7, 18000, 2 ** 31 + 11):
+            assert L.go_test_uint(seed, n) == (x * n) >> 64      # rejection zone misses w.p. n/2^64
+
+
+README_ANI_TABLE = [  # README.md:231-242, `reformat 16 1`: displayed distance (3 digits) -> ANI
+    (5.40e-01, 97.1126), (8.22e-01, 92.5276), (8.71e-01, 90.7837), (8.76e-01, 90.5424), (8.78e-01, 90.4745),
+    (8.79e-01, 90.4108), (8.79e-01, 90.398), (8.82e-01, 90.2678), (8.83e-01, 90.2361), (8.86e-01, 90.1098)]
+
+
+def test_ani_matches_readme_table():
+    # the table prints the distance rounded to 3 digits while ANI was computed from the unrounded value:
+    # the published ANI must lie between the ANI of the two rounding bounds
+    for d, ani in README_ANI_TABLE:
+        lo, hi = O.ani(d + 0.0005, 16, 1), O.ani(d - 0.0005, 16, 1)
+        assert lo - 1e-4 <= ani <= hi + 1e-4, (d, ani, lo, hi)
+    # closed forms of reformat.rs:80-86
+    for d in (0.0, 0.3, 0.54, 0.99):
+        j = 1.0 - d
+        assert abs(O.ani(d, 21, 1) - (1.0 + np.log(2 * j / (1 + j)) / 21) * 100.0) < 1e-9
+        assert abs(O.ani(d, 21, 2) - (2 * j / (1 + j)) ** (1.0 / 21) * 100.0) < 1e-9
