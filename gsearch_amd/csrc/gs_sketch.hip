@@ -11,6 +11,7 @@
 // k-mer through the element hash into an m-slot min table held in LDS (ds_min_u32). HBM traffic is the
 // algorithmic minimum: each packed word is read once (plus an L1/L2-served halo word) and m slots written.
 #include <math.h>
+#include <algorithm>
 #include <vector>
 #include "gs_internal.hpp"
 #include "gs_spec.hpp"
@@ -39,13 +40,22 @@ __global__ void k_unit_prefix(const uint64_t *rec_start, const uint64_t *rec_len
     gen_units[g] = acc;
 }
 
-struct OphEmit {
-    uint32_t *table; uint32_t m; uint64_t zone;
+// level-0 candidate of every slot-min sketcher (SPEC 3.1 / 3.2): element hash -> (key, slot) -> min.
+//   optdens, revoptdens, super : key = 23-bit mantissa of U32f          (T = u32)
+//   super2 / u32               : key = next32                            (T = u32)
+//   super2 / u64               : key = next64                            (T = u64)
+template <int ALGO, int VBITS, typename T, bool LDS_TABLE>
+struct MinEmit {
+    T *table; uint32_t m; uint64_t zone;
     __device__ __forceinline__ void operator()(uint64_t v) const
     {
-        uint32_t r, b;
-        oph_draw(fx64(v), m, zone, r, b);
-        atomicMin(&table[b], r);
+        uint64_t o1; uint32_t b;
+        two_draw(elem_hash<ALGO, VBITS>(v), m, zone, o1, b);
+        T key;
+        if (ALGO == ALGO_SUPER2) key = sizeof(T) == 8 ? (T)o1 : (T)(o1 >> 32);
+        else key = (T)(o1 >> 41);
+        if (LDS_TABLE) atomicMin(&table[b], key);
+        else if (key < table[b]) atomicMin(&table[b], key);      // stale (larger) reads only cost a redundant atomic
     }
 };
 
@@ -113,28 +123,30 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
     }
 }
 
-// ---- optdens / revoptdens main kernel (SPEC 3.1) --------------------------------------------------
-template <bool AA, bool LDS_TABLE>
-__global__ __launch_bounds__(SK_THREADS) void k_sketch_oph(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
+// ---- main kernel of optdens / revoptdens / super / super2: per-slot minimum over all k-mers (SPEC 3.1, 3.2 level 0)
+template <bool AA, bool LDS_TABLE, int ALGO, int VBITS, typename T>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
                                                             const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
                                                             const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
-                                                            uint32_t k, uint32_t m, uint64_t zone, uint32_t *__restrict__ table_out)
+                                                            uint32_t k, uint32_t m, uint64_t zone, T *__restrict__ table_out)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_table[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw_table[];
+    T *s_table = (T *)s_raw_table;
+    const T EMPTY = (T)~(T)0;
     const uint64_t g = blockIdx.y;
     const uint32_t part = blockIdx.x, parts = gridDim.x;
-    uint32_t *gtab = table_out + g * (uint64_t)m;
-    uint32_t *table = LDS_TABLE ? s_table : gtab;
+    T *gtab = table_out + g * (uint64_t)m;
+    T *table = LDS_TABLE ? s_table : gtab;
     if (LDS_TABLE) {
-        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s_table[i] = GS_EMPTY32;
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s_table[i] = EMPTY;
         __syncthreads();
     }
-    OphEmit emit{table, m, zone};
+    MinEmit<ALGO, VBITS, T, LDS_TABLE> emit{table, m, zone};
     walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
     if (LDS_TABLE) {
         __syncthreads();
         if (parts == 1) { for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) gtab[i] = s_table[i]; }
-        else { for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) { uint32_t v = s_table[i]; if (v != GS_EMPTY32) atomicMin(&gtab[i], v); } }
+        else { for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) { T v = s_table[i]; if (v != EMPTY) atomicMin(&gtab[i], v); } }
     }
 }
 
@@ -190,41 +202,196 @@ __global__ __launch_bounds__(256) void k_oph_finish(const uint32_t *__restrict__
     }
 }
 
+// ---- super / super2 finish: every slot filled at level 0 (always true at BASELINE sizes) -> done; otherwise the genome
+// is flagged for the exact sequential walk below.
+template <int ALGO, typename T>
+__global__ __launch_bounds__(256) void k_smh_finish(const T *__restrict__ table, uint32_t m, void *__restrict__ sig, uint8_t *__restrict__ cold)
+{
+    __shared__ uint32_t s_filled;
+    const uint64_t g = blockIdx.x;
+    const T *slot = table + g * (uint64_t)m;
+    const T EMPTY = (T)~(T)0;
+    if (threadIdx.x == 0) s_filled = 0;
+    __syncthreads();
+    uint32_t loc = 0;
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) loc += (slot[i] != EMPTY);
+    if (loc) atomicAdd(&s_filled, loc);
+    __syncthreads();
+    if (threadIdx.x == 0) cold[g] = s_filled != m;
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        if (ALGO == ALGO_SUPER) ((float *)sig)[g * (uint64_t)m + i] = slot[i] == EMPTY ? INFINITY : 0.0f + (float)slot[i] * 0x1.0p-23f;
+        else ((T *)sig)[g * (uint64_t)m + i] = slot[i];
+    }
+}
+
+// ---- cold path of super / super2: Ertl's SuperMinHash walk (SPEC 3.2) executed exactly, one lane per genome.
+// Only genomes with fewer than ~m ln m distinct k-mers get here (plasmids, test inputs).
+struct SmhScratch { uint32_t *lvl, *perm, *hist, *q; uint64_t *rr; uint8_t *filled; };
+template <int ALGO, int VBITS, typename T>
+struct SmhSeqEmit {
+    SmhScratch s; uint32_t m; uint32_t *a; uint32_t *item;
+    __device__ void operator()(uint64_t v) const
+    {
+        Rng g; g.seed(elem_hash<ALGO, VBITS>(v));
+        const uint32_t it = (*item)++;
+        for (uint32_t j = 0; j <= *a; j++) {
+            uint64_t r;
+            if (ALGO == ALGO_SUPER) r = g.r23();
+            else r = sizeof(T) == 8 ? g.next64() : (uint64_t)g.next32();
+            const uint64_t range = (uint64_t)(m - j);
+            const uint32_t t = j + (uint32_t)rng_uint(g, range, uint_zone(range));
+            if (s.q[j] != it) { s.q[j] = it; s.perm[j] = j; }
+            if (s.q[t] != it) { s.q[t] = it; s.perm[t] = t; }
+            const uint32_t tmp = s.perm[j]; s.perm[j] = s.perm[t]; s.perm[t] = tmp;
+            const uint32_t sl = s.perm[j];
+            const bool better = !s.filled[sl] || j < s.lvl[sl] || (j == s.lvl[sl] && r < s.rr[sl]);
+            if (better) {
+                const uint32_t jp = s.lvl[sl];
+                s.filled[sl] = 1; s.lvl[sl] = j; s.rr[sl] = r;
+                if (j < jp) { s.hist[jp]--; s.hist[j]++; while (s.hist[*a] == 0) (*a)--; }
+            }
+        }
+    }
+};
+template <bool AA, class Emit>
+__device__ void walk_genome_seq(const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len, uint64_t r0, uint64_t r1, uint32_t k, const Emit &emit)
+{
+    for (uint64_t r = r0; r < r1; r++) {
+        const uint64_t rb = rec_start[r], len = rec_len[r];
+        if (len < k) continue;
+        if (!AA) {
+            const uint64_t mask = k == 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1);
+            uint64_t fwd = 0, rc = 0;
+            for (uint64_t i = 0; i < len; i++) {
+                const uint64_t a = rb + i;
+                const uint64_t c = (seq[a >> 2] >> (6 - 2 * (a & 3))) & 3;
+                fwd = ((fwd << 2) | c) & mask;
+                rc = (rc >> 2) | ((3 - c) << (2 * (k - 1)));
+                if (i + 1 >= k) emit((fwd < rc ? fwd : rc) & mask);
+            }
+        } else {
+            const uint64_t mask = ((uint64_t)1 << (5 * k)) - 1;
+            uint64_t val = 0;
+            for (uint64_t i = 0; i < len; i++) {
+                val = ((val << 5) | c_aa_code[seq[rb + i] & 31]) & mask;
+                if (i + 1 >= k) emit(val);
+            }
+        }
+    }
+}
+template <bool AA, int ALGO, int VBITS, typename T>
+__global__ void k_smh_cold(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
+                           const uint64_t *__restrict__ genome_rec_off, const uint32_t *__restrict__ cold_list, uint32_t ncold, uint32_t k, uint32_t m,
+                           uint8_t *__restrict__ scratch, void *__restrict__ sig)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncold) return;
+    const uint64_t g = cold_list[c];
+    uint8_t *base = scratch + (uint64_t)c * 32 * m;
+    SmhScratch s;
+    s.rr = (uint64_t *)base; s.lvl = (uint32_t *)(base + 8 * (uint64_t)m); s.perm = s.lvl + m; s.hist = s.perm + m; s.q = s.hist + m;
+    s.filled = (uint8_t *)(s.q + m);
+    for (uint32_t i = 0; i < m; i++) { s.lvl[i] = m - 1; s.rr[i] = ~(uint64_t)0; s.q[i] = 0xFFFFFFFFu; s.hist[i] = 0; s.filled[i] = 0; }
+    s.hist[m - 1] = m;
+    uint32_t a = m - 1, item = 0;
+    SmhSeqEmit<ALGO, VBITS, T> emit{s, m, &a, &item};
+    walk_genome_seq<AA>(seq, rec_start, rec_len, genome_rec_off[g], genome_rec_off[g + 1], k, emit);
+    for (uint32_t i = 0; i < m; i++) {
+        if (ALGO == ALGO_SUPER) ((float *)sig)[g * (uint64_t)m + i] = s.filled[i] ? (float)s.lvl[i] + (float)(uint32_t)s.rr[i] * 0x1.0p-23f : INFINITY;
+        else ((T *)sig)[g * (uint64_t)m + i] = s.filled[i] ? (T)s.rr[i] : (T)~(T)0;
+    }
+}
+
+// launch geometry shared by the slot-min sketchers
+struct MinGeom { uint32_t parts; bool use_lds; size_t lds; };
+static MinGeom min_geom(gs_ctx *c, uint32_t m, size_t esz, uint64_t n_genomes, uint64_t avg_units)
+{
+    MinGeom g;
+    g.lds = (size_t)m * esz;
+    g.use_lds = g.lds <= 160 * 1024 - 256;
+    g.parts = 1;
+    if (n_genomes < (uint64_t)2 * c->n_cu) {
+        g.parts = (uint32_t)((2 * (uint64_t)c->n_cu + n_genomes - 1) / n_genomes);
+        uint64_t maxp = avg_units / SK_THREADS + 1;       // at least one full sweep per part
+        if (g.parts > maxp) g.parts = (uint32_t)maxp;
+        if (g.parts < 1) g.parts = 1;
+    }
+    return g;
+}
+
+template <int ALGO, int VBITS, typename T>
+static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len,
+                      const uint64_t *rec_upre, const uint64_t *genome_rec_off, const uint64_t *gen_units, uint64_t n_genomes,
+                      uint64_t avg_units, T *table)
+{
+    const uint32_t m = p->sketch_size;
+    const uint64_t zone = uint_zone(m);
+    const MinGeom ge = min_geom(c, m, sizeof(T), n_genomes, avg_units);
+    if (!ge.use_lds || ge.parts > 1) GS_HIP_CHECK(hipMemsetAsync(table, 0xFF, (size_t)n_genomes * m * sizeof(T), c->stream));
+    const bool aa = p->data_t == GS_DATA_AA;
+    const size_t lds = ge.lds;
+    for (uint64_t g0 = 0; g0 < n_genomes; g0 += 65535) {       // grid.y limit
+        uint64_t ng = n_genomes - g0 < 65535 ? n_genomes - g0 : 65535;
+        dim3 grid(ge.parts, (uint32_t)ng), block(SK_THREADS);
+        const uint64_t *gro = genome_rec_off + g0; const uint64_t *gu = gen_units + g0;
+        T *tab = table + g0 * m;
+        ProfScope ps(c, FAM_SKETCH);
+#define GS_LAUNCH_MIN(AAV, LDSV)                                                                                        \
+    do {                                                                                                                \
+        auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T>;                                                            \
+        if (LDSV) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, block, LDSV ? lds : 0, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, p->k, m, zone, tab); \
+    } while (0)
+        if (aa) { if (ge.use_lds) GS_LAUNCH_MIN(true, true); else GS_LAUNCH_MIN(true, false); }
+        else    { if (ge.use_lds) GS_LAUNCH_MIN(false, true); else GS_LAUNCH_MIN(false, false); }
+#undef GS_LAUNCH_MIN
+        GS_HIP_CHECK(hipGetLastError());
+    }
+    return GS_OK;
+}
+
+// super / super2 driver: level-0 pass, finish, then the exact cold walk for the (rare) genomes with empty slots
+template <int ALGO, int VBITS, typename T>
+static int run_smh(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len,
+                   const uint64_t *rec_upre, const uint64_t *genome_rec_off, const uint64_t *gen_units, uint64_t n_genomes, uint64_t avg_units,
+                   void *sig_out)
+{
+    const uint32_t m = p->sketch_size;
+    DevBuf table, cold;
+    int rc;
+    if ((rc = table.alloc((size_t)n_genomes * m * sizeof(T)))) return rc;
+    if ((rc = cold.alloc(n_genomes))) return rc;
+    if ((rc = launch_min<ALGO, VBITS, T>(c, p, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, n_genomes, avg_units, table.as<T>()))) return rc;
+    hipLaunchKernelGGL((k_smh_finish<ALGO, T>), dim3((uint32_t)n_genomes), dim3(256), 0, c->stream, table.as<T>(), m, sig_out, cold.as<uint8_t>());
+    GS_HIP_CHECK(hipGetLastError());
+    std::vector<uint8_t> h(n_genomes);
+    GS_HIP_CHECK(hipMemcpyAsync(h.data(), cold.p, n_genomes, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> list;
+    for (uint64_t g = 0; g < n_genomes; g++) if (h[g]) list.push_back((uint32_t)g);
+    const bool aa = p->data_t == GS_DATA_AA;
+    for (size_t l0 = 0; l0 < list.size(); l0 += 4096) {
+        const uint32_t nc = (uint32_t)std::min<size_t>(4096, list.size() - l0);
+        DevBuf dl, scratch;
+        if ((rc = dl.alloc(4 * (size_t)nc))) return rc;
+        if ((rc = scratch.alloc((size_t)nc * 32 * m))) return rc;
+        GS_HIP_CHECK(hipMemcpyAsync(dl.p, list.data() + l0, 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
+        if (aa) hipLaunchKernelGGL((k_smh_cold<true, ALGO, VBITS, T>), dim3((nc + 63) / 64), dim3(64), 0, c->stream, seq, rec_start, rec_len, genome_rec_off, dl.as<uint32_t>(), nc, p->k, m, scratch.as<uint8_t>(), sig_out);
+        else hipLaunchKernelGGL((k_smh_cold<false, ALGO, VBITS, T>), dim3((nc + 63) / 64), dim3(64), 0, c->stream, seq, rec_start, rec_len, genome_rec_off, dl.as<uint32_t>(), nc, p->k, m, scratch.as<uint8_t>(), sig_out);
+        GS_HIP_CHECK(hipGetLastError());
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return GS_OK;
+}
+
 static int launch_oph(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len,
                       const uint64_t *rec_upre, const uint64_t *genome_rec_off, const uint64_t *gen_units, uint64_t n_genomes,
                       uint64_t avg_units, uint32_t *table, uint32_t *win, float *sig)
 {
     const uint32_t m = p->sketch_size;
     const uint64_t zone = uint_zone(m);
-    const size_t lds = (size_t)m * 4;
-    const bool use_lds = lds <= 160 * 1024 - 256;
-    uint32_t parts = 1;
-    if (n_genomes < (uint64_t)2 * c->n_cu) {
-        parts = (uint32_t)((2 * (uint64_t)c->n_cu + n_genomes - 1) / n_genomes);
-        uint64_t maxp = avg_units / SK_THREADS + 1;       // at least one full sweep per part
-        if (parts > maxp) parts = (uint32_t)maxp;
-        if (parts < 1) parts = 1;
-    }
-    if (!use_lds || parts > 1) GS_HIP_CHECK(hipMemsetAsync(table, 0xFF, (size_t)n_genomes * m * 4, c->stream));
-    const bool aa = p->data_t == GS_DATA_AA;
-    // grid.y is limited to 65535: chunk the genome dimension
-    for (uint64_t g0 = 0; g0 < n_genomes; g0 += 65535) {
-        uint64_t ng = n_genomes - g0 < 65535 ? n_genomes - g0 : 65535;
-        dim3 grid(parts, (uint32_t)ng), block(SK_THREADS);
-        const uint64_t *gro = genome_rec_off + g0; const uint64_t *gu = gen_units + g0;
-        uint32_t *tab = table + g0 * m;
-        ProfScope ps(c, FAM_SKETCH);
-#define GS_LAUNCH_OPH(AAV, LDSV)                                                                                        \
-    do {                                                                                                                \
-        auto kern = k_sketch_oph<AAV, LDSV>;                                                                            \
-        if (LDSV) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, block, LDSV ? lds : 0, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, p->k, m, zone, tab); \
-    } while (0)
-        if (aa) { if (use_lds) GS_LAUNCH_OPH(true, true); else GS_LAUNCH_OPH(true, false); }
-        else    { if (use_lds) GS_LAUNCH_OPH(false, true); else GS_LAUNCH_OPH(false, false); }
-#undef GS_LAUNCH_OPH
-        GS_HIP_CHECK(hipGetLastError());
-    }
+    int rc = launch_min<ALGO_OPTDENS, 64, uint32_t>(c, p, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, n_genomes, avg_units, table);
+    if (rc) return rc;
     if (p->algo == GS_ALGO_OPTDENS)
         hipLaunchKernelGGL(k_oph_finish<ALGO_OPTDENS>, dim3((uint32_t)n_genomes), dim3(256), 0, c->stream, table, m, zone, win, sig);
     else
@@ -258,6 +425,24 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
                         n_genomes, avg_units, table.as<uint32_t>(), win.as<uint32_t>(), (float *)sig_out);
         if (rc) return rc;
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));   // scratch lifetime
+        return GS_OK;
+    }
+    if (p->algo == GS_ALGO_SUPER || p->algo == GS_ALGO_SUPER2) {
+        DevBuf upre, gunits;
+        rc = upre.alloc(8 * (n_rec + 1)); if (rc) return rc;
+        rc = gunits.alloc(8 * n_genomes); if (rc) return rc;
+        hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 255) / 256)), dim3(256), 0, c->stream, rec_start, rec_len,
+                           genome_rec_off, n_genomes, p->k, upre.as<uint64_t>(), gunits.as<uint64_t>());
+        GS_HIP_CHECK(hipGetLastError());
+        const uint64_t avg_units = (p->data_t == GS_DATA_AA ? seq_bytes / 32 : seq_bytes / 8) / n_genomes + 1;
+        const uint8_t *sq = (const uint8_t *)seq;
+        const uint64_t *up = upre.as<uint64_t>(), *gu = gunits.as<uint64_t>();
+        const int vb = gs_value_bits(p);
+        if (p->algo == GS_ALGO_SUPER) rc = run_smh<ALGO_SUPER, 64, uint32_t>(c, p, sq, rec_start, rec_len, up, genome_rec_off, gu, n_genomes, avg_units, sig_out);
+        else if (vb == 32) rc = run_smh<ALGO_SUPER2, 32, uint32_t>(c, p, sq, rec_start, rec_len, up, genome_rec_off, gu, n_genomes, avg_units, sig_out);
+        else rc = run_smh<ALGO_SUPER2, 64, uint64_t>(c, p, sq, rec_start, rec_len, up, genome_rec_off, gu, n_genomes, avg_units, sig_out);
+        if (rc) return rc;
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         return GS_OK;
     }
     GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "sketch algo %u is not implemented on the device yet", p->algo);

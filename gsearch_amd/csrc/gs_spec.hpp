@@ -83,13 +83,13 @@ GS_HD uint64_t rng_uint(Rng &g, uint64_t n, uint64_t zone)
 // ---- the two-draw fast path of optdens (SPEC 3.1): r = U32f bits, b = Uint(m) ---------------------
 // Only s0,s1,s3 are needed for two outputs; the full generator is re-run in the (probability m/2^64)
 // rejection case so that the result is exactly the sequential definition.
-GS_HD void oph_draw(uint64_t h, uint32_t m, uint64_t zone, uint32_t &r23, uint32_t &bin)
+// two_draw: first output o1 (the r draw: U32f bits = o1>>41, next32 = o1>>32, next64 = o1) and b = Uint(m) from the second.
+GS_HD void two_draw(uint64_t h, uint32_t m, uint64_t zone, uint64_t &o1, uint32_t &bin)
 {
     uint64_t s0 = splitmix_mix(h + GS_GAMMA);
     uint64_t s1 = splitmix_mix(h + 2 * GS_GAMMA);
     uint64_t s3 = splitmix_mix(h + 4 * GS_GAMMA);
-    uint64_t o1 = rotl64(s0 + s3, 23) + s0;
-    r23 = (uint32_t)(o1 >> 41);
+    o1 = rotl64(s0 + s3, 23) + s0;
     uint64_t n3 = s3 ^ s1;           // s3 after the first step, before rotation
     uint64_t n0 = s0 ^ n3;           // s0 after the first step
     uint64_t o2 = rotl64(n0 + rotl64(n3, 45), 23) + n0;
@@ -97,6 +97,12 @@ GS_HD void oph_draw(uint64_t h, uint32_t m, uint64_t zone, uint32_t &r23, uint32
     if (__builtin_expect(lo <= zone, 1)) { bin = (uint32_t)mulhi64(o2, (uint64_t)m); return; }
     Rng g; g.seed(h); (void)g.next64();
     bin = (uint32_t)rng_uint(g, (uint64_t)m, zone);
+}
+GS_HD void oph_draw(uint64_t h, uint32_t m, uint64_t zone, uint32_t &r23, uint32_t &bin)
+{
+    uint64_t o1;
+    two_draw(h, m, zone, o1, bin);
+    r23 = (uint32_t)(o1 >> 41);
 }
 
 }  // namespace gs

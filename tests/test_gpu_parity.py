@@ -175,3 +175,41 @@ def test_parallel_insert_matches_oracle(gpu_ctx, dtype, m, M, efc, B, scale, n_r
     ids, dist, cnt, ev = hn.search_arrays(q, 10, 50)
     oids, odist, ocnt, oev = oix.parallel_search(q, 10, 50)
     assert np.array_equal(ids, oids) and np.array_equal(dist, odist) and np.array_equal(ev, oev)
+
+
+@pytest.mark.parametrize("k,m,algo,data", [(21, 2000, "super", "dna"), (21, 2000, "super2", "dna"), (16, 1024, "super2", "dna"), (14, 300, "super2", "dna"),
+                                           (7, 1000, "super2", "aa"), (5, 640, "super2", "aa"), (7, 24000, "super2", "aa"), (12, 512, "super", "aa")])
+def test_sketch_super_matches_oracle(gpu_ctx, k, m, algo, data):
+    """SuperMinHash / SuperMinHash2: level-0 parallel pass (every slot filled) — config 5 is (7, 24000, super2, aa)"""
+    import gsearch_amd as G
+    rng = np.random.default_rng(k * 7 + m)
+    if data == "dna":
+        fam = H.family(rng, 150000 if m <= 2000 else 60000, [0.01, 0.05])
+        genomes = [[H.dna_ascii(g)] for g in fam]
+        genomes.append([H.dna_ascii(fam[0])[:70000], b"ACGTNN", H.dna_ascii(fam[1])[1000:90000]])
+    else:
+        n = 600000 if m > 10000 else 120000
+        fam = H.family(rng, n, [0.02], alphabet=20)
+        genomes = [[H.aa_ascii(g)] for g in fam]
+        genomes.append([H.aa_ascii(fam[0])[:n // 2] + b"*X", H.aa_ascii(fam[1])[10:n - 7]])
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, algo, data))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(k, m, algo, genomes, data)
+    assert got.dtype == ref.dtype
+    assert np.array_equal(_bits(got), _bits(ref))
+
+
+@pytest.mark.parametrize("algo,data,k", [("super", "dna", 21), ("super2", "dna", 21), ("super2", "dna", 12), ("super2", "aa", 7)])
+def test_sketch_super_cold_path_matches_oracle(gpu_ctx, algo, data, k):
+    """few k-mers, many slots: slots stay empty after level 0 -> exact sequential walk on the device"""
+    import gsearch_amd as G
+    rng = np.random.default_rng(17)
+    if data == "dna":
+        genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (30, 500, 3000)] + [[b"ACGT"]]
+    else:
+        genomes = [[H.aa_ascii(rng.integers(0, 20, n))] for n in (20, 400, 2500)] + [[b"MK"]]
+    genomes.append([H.dna_ascii(H.rand_dna(rng, 40000))] if data == "dna" else [H.aa_ascii(rng.integers(0, 20, 40000))])
+    sk = G.sketcher_for(G.SeqSketcherParams(k, 1024, algo, data))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(k, 1024, algo, genomes, data)
+    assert np.array_equal(_bits(got), _bits(ref))
