@@ -21,60 +21,122 @@ __device__ __forceinline__ uint32_t word_ne(uint32_t a, uint32_t b)
     return a != b ? 1u : 0u;
 }
 
-constexpr int HT = 64;      // tile edge (queries and candidates)
+// ---- dense tile kernel ------------------------------------------------------------------------------
+// 128 x 128 outputs per workgroup (256 lanes, 8 x 8 per lane), K-chunks of 32 words double-buffered through LDS.
+// Per pair-element: one v_cmp_ne + one v_addc_co (the carry-in IS the mismatch bit) — 2 VALU instructions, which is
+// what bounds the kernel (it reads every candidate word once per 128 queries, so HBM traffic is ~1/128 of the
+// algorithmic bytes). Lane (tx,ty) owns query rows ty+16i and candidate rows tx+16j: with the 33-word LDS row
+// pitch every ds_read_b32 of a wavefront is conflict-free (distinct banks across tx, broadcast across ty).
+constexpr int HT = 128;     // tile edge (queries and candidates)
 constexpr int HKW = 32;     // words per K-chunk
+constexpr int HP = HKW + 1; // LDS row pitch in words
 
+// one query value against 8 candidate values: 8 x (v_cmp_ne ; v_addc_co). A single asm statement so that hipcc does
+// not put a hazard s_nop between the pairs (it cannot see inside asm); VALU->VALU VCC forwarding needs no wait state.
+#define GS_CMP8(OP)                                                                                                   \
+    asm volatile(OP " vcc, %8, %9\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"                                           \
+                 OP " vcc, %8, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"                                          \
+                 OP " vcc, %8, %11\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"                                          \
+                 OP " vcc, %8, %12\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"                                          \
+                 OP " vcc, %8, %13\n\tv_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"                                          \
+                 OP " vcc, %8, %14\n\tv_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"                                          \
+                 OP " vcc, %8, %15\n\tv_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"                                          \
+                 OP " vcc, %8, %16\n\tv_addc_co_u32 %7, vcc, 0, %7, vcc"                                              \
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])       \
+                 : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])       \
+                 : "vcc")
 template <int KIND>
+__device__ __forceinline__ void cmp_acc8(uint32_t (&c)[8], uint32_t a, const uint32_t (&b)[8])
+{
+    if (KIND == GS_KIND_F32) GS_CMP8("v_cmp_neq_f32");
+    else GS_CMP8("v_cmp_ne_u32");
+}
+__device__ __forceinline__ void cmp_acc8_64(uint32_t (&c)[8], uint64_t a, const uint64_t (&b)[8])
+{
+    GS_CMP8("v_cmp_ne_u64");
+}
+
+template <int KIND, bool VEC4>
 __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict__ Q, uint64_t nq, uint64_t strideQ, const uint32_t *__restrict__ C, uint64_t nc,
                                                       uint64_t strideC, uint32_t m, float *__restrict__ out, uint32_t *__restrict__ out_cnt)
 {
     constexpr int EW = ElemCmp<KIND>::EW;
-    __shared__ uint32_t sq[HT][HKW + 1];
-    __shared__ uint32_t sc[HT][HKW + 1];
+    __shared__ uint32_t sq[2][HT * HP];
+    __shared__ uint32_t sc[2][HT * HP];
     const uint64_t q0 = (uint64_t)blockIdx.y * HT, c0 = (uint64_t)blockIdx.x * HT;
     const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const uint64_t roww = (uint64_t)m * EW;          // words per row
-    uint32_t cnt[4][4] = {};
-    for (uint64_t w0 = 0; w0 < roww; w0 += HKW) {
-        // stage 64 query rows + 64 candidate rows x 32 words; rows past the end are clamped (results discarded),
-        // words past the row end read as 0 on both sides (equal)
-        const uint32_t lw = threadIdx.x & 31, lr = threadIdx.x >> 5;
-        const bool wv = (w0 + lw) < roww;
+    uint32_t cnt[8][8];
 #pragma unroll
-        for (int i = 0; i < HT / 8; i++) {
-            uint32_t r = lr + 8 * i;
-            uint64_t qr = q0 + r < nq ? q0 + r : nq - 1;
-            uint64_t cr = c0 + r < nc ? c0 + r : nc - 1;
-            sq[r][lw] = wv ? Q[qr * strideQ + w0 + lw] : 0u;
-            sc[r][lw] = wv ? C[cr * strideC + w0 + lw] : 0u;
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) cnt[i][j] = 0;
+
+    // staging: 128 rows x 32 words per operand = 1024 x 16 B; lane handles 4 + 4 of them
+    uint4 rq[4], rc[4];
+    auto stage_load = [&](uint64_t w0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t idx = threadIdx.x + 256 * i, r = idx >> 3, kq = (idx & 7) * 4;
+            const uint64_t qr = q0 + r < nq ? q0 + r : nq - 1, cr = c0 + r < nc ? c0 + r : nc - 1;   // clamped rows: results discarded
+            const uint32_t *pq = Q + qr * strideQ + w0 + kq, *pc = C + cr * strideC + w0 + kq;
+            if (VEC4 && w0 + kq + 4 <= roww) { rq[i] = *(const uint4 *)pq; rc[i] = *(const uint4 *)pc; }
+            else {
+                uint32_t a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const bool v = w0 + kq + e < roww; a[e] = v ? pq[e] : 0u; b[e] = v ? pc[e] : 0u; }   // past the row end: equal on both sides
+                rq[i] = make_uint4(a[0], a[1], a[2], a[3]); rc[i] = make_uint4(b[0], b[1], b[2], b[3]);
+            }
         }
-        __syncthreads();
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t idx = threadIdx.x + 256 * i, r = idx >> 3, kq = (idx & 7) * 4;
+            uint32_t *dq = &sq[buf][r * HP + kq], *dc = &sc[buf][r * HP + kq];
+            dq[0] = rq[i].x; dq[1] = rq[i].y; dq[2] = rq[i].z; dq[3] = rq[i].w;
+            dc[0] = rc[i].x; dc[1] = rc[i].y; dc[2] = rc[i].z; dc[3] = rc[i].w;
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+    for (uint64_t w0 = 0; w0 < roww; w0 += HKW) {
+        const bool more = w0 + HKW < roww;
+        if (more) stage_load(w0 + HKW);              // global loads in flight during the compare block
+        const uint32_t *pa = &sq[cur][ty * HP], *pb = &sc[cur][tx * HP];
 #pragma unroll 4
         for (int kk = 0; kk < HKW; kk += EW) {
-            uint32_t a[4][EW], b[4][EW];
+            if (EW == 1) {
+                uint32_t a[8], b[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 8; i++) { a[i] = pa[i * 16 * HP + kk]; b[i] = pb[i * 16 * HP + kk]; }
 #pragma unroll
-                for (int e = 0; e < EW; e++) { a[i][e] = sq[ty * 4 + i][kk + e]; b[i][e] = sc[tx * 4 + i][kk + e]; }
+                for (int i = 0; i < 8; i++) cmp_acc8<KIND>(cnt[i], a[i], b);
+            } else {
+                uint64_t a[8], b[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint32_t ne = word_ne<KIND>(a[i][0], b[j][0]);
-                    if (EW == 2) ne |= (a[i][EW - 1] != b[j][EW - 1]) ? 1u : 0u;
-                    cnt[i][j] += ne;
+                for (int i = 0; i < 8; i++) {
+                    a[i] = (uint64_t)pa[i * 16 * HP + kk] | ((uint64_t)pa[i * 16 * HP + kk + 1] << 32);
+                    b[i] = (uint64_t)pb[i * 16 * HP + kk] | ((uint64_t)pb[i * 16 * HP + kk + 1] << 32);
                 }
+#pragma unroll
+                for (int i = 0; i < 8; i++) cmp_acc8_64(cnt[i], a[i], b);
+            }
         }
+        if (more) stage_store(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
     const float fm = (float)m;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint64_t qi = q0 + ty * 4 + i;
+    for (int i = 0; i < 8; i++) {
+        const uint64_t qi = q0 + ty + 16 * i;
         if (qi >= nq) continue;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint64_t cj = c0 + tx * 4 + j;
+        for (int j = 0; j < 8; j++) {
+            const uint64_t cj = c0 + tx + 16 * j;
             if (cj < nc) { if (out) out[qi * nc + cj] = (float)cnt[i][j] / fm; else out_cnt[qi * nc + cj] = cnt[i][j]; }
         }
     }
@@ -113,9 +175,12 @@ int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t
     GS_REQUIRE(grid.y <= 65535, GS_ERR_INVALID, "too many query rows for one call (max %d)", 65535 * HT);
     ProfScope ps(c, FAM_HAMMING);
     const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
-    if (kind == GS_KIND_F32) hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_F32>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt);
-    else if (kind == GS_KIND_U32) hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_U32>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt);
-    else hipLaunchKernelGGL(k_hamming_qxc<GS_KIND_U64>, grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt);
+    const bool vec4 = (strideQ_bytes % 16 == 0) && (strideC_bytes % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)C % 16 == 0);
+#define GS_LAUNCH_QXC(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V>), grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt)
+    if (kind == GS_KIND_F32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_F32, true); else GS_LAUNCH_QXC(GS_KIND_F32, false); }
+    else if (kind == GS_KIND_U32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_U32, true); else GS_LAUNCH_QXC(GS_KIND_U32, false); }
+    else { if (vec4) GS_LAUNCH_QXC(GS_KIND_U64, true); else GS_LAUNCH_QXC(GS_KIND_U64, false); }
+#undef GS_LAUNCH_QXC
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

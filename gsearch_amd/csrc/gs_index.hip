@@ -16,6 +16,7 @@
 // search_layer in closed form and merge the accepted keys into R and C with one in-LDS parallel merge.
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "gs_internal.hpp"
@@ -103,9 +104,17 @@ __device__ __forceinline__ uint32_t chunk_mismatch_wave(const uint4 &a, const ui
 }
 
 // Ecnt[e] = mismatch count between query row q and data row Eid[e], e < ne. All lanes call.
+// `matrow` != nullptr: the counts of this query against every node were precomputed by the dense tile kernel
+// (DESIGN.md 3.5 "dense mode") and are simply looked up.
 template <int KIND>
-__device__ __forceinline__ void block_distances(const IndexDev &ix, const uint4 *__restrict__ q, const uint32_t *Eid, uint32_t ne, uint32_t *Ecnt)
+__device__ __forceinline__ void block_distances(const IndexDev &ix, const uint4 *__restrict__ q, const uint32_t *Eid, uint32_t ne, uint32_t *Ecnt,
+                                                const uint32_t *__restrict__ matrow = nullptr)
 {
+    if (matrow) {
+        for (uint32_t e = threadIdx.x; e < ne; e += ST) Ecnt[e] = matrow[Eid[e]];
+        __syncthreads();
+        return;
+    }
     for (uint32_t e = threadIdx.x; e < ne; e += ST) Ecnt[e] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
@@ -148,7 +157,8 @@ __device__ __forceinline__ void node_neighbours(const IndexDev &ix, uint32_t nod
 // result sorted ascending by (count,id). `vis` = this workgroup's visited bitmap (cleared by the caller).
 template <int KIND>
 __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t *vis,
-                                                       uint32_t ep, uint32_t ep_cnt, uint32_t ef, int L, uint64_t &evals)
+                                                       uint32_t ep, uint32_t ep_cnt, uint32_t ef, int L, uint64_t &evals,
+                                                       const uint32_t *__restrict__ matrow = nullptr)
 {
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t capC = 2 * ef + maxdeg + 64;
@@ -183,7 +193,7 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
         if (ne == 0) continue;
         evals += ne;
         // ---- all distances of this expansion (HBM-bound part)
-        block_distances<KIND>(ix, q, S.Eid, ne, S.Ecnt);
+        block_distances<KIND>(ix, q, S.Eid, ne, S.Ecnt, matrow);
         // ---- closed form of the sequential accept rule (DESIGN.md "accept rule"):
         //      e_i accepted  <=>  #{x in R : c(x) <= c_i} + #{j < i : c_j <= c_i}  <  ef
         uint64_t mykey = ~(uint64_t)0; bool acc = false;
@@ -223,7 +233,7 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
 // greedy descent on one upper layer (hnsw_rs::search outer loop, SPEC 5)
 template <int KIND>
 __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t &ep,
-                                                   uint32_t &ep_cnt, int L, uint64_t &evals)
+                                                   uint32_t &ep_cnt, int L, uint64_t &evals, const uint32_t *__restrict__ matrow = nullptr)
 {
     for (;;) {
         const uint32_t *nbr; uint32_t deg;
@@ -233,7 +243,7 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
         if (threadIdx.x == 0) S.scal[0] = ~(uint64_t)0;
         __syncthreads();
         evals += deg;
-        block_distances<KIND>(ix, q, S.Eid, deg, S.Ecnt);
+        block_distances<KIND>(ix, q, S.Eid, deg, S.Ecnt, matrow);
         if (threadIdx.x < deg && S.Ecnt[threadIdx.x] < ep_cnt) atomicMin((unsigned long long *)&S.scal[0], (unsigned long long)KEY(S.Ecnt[threadIdx.x], threadIdx.x));
         __syncthreads();
         const uint64_t best = S.scal[0];
@@ -260,7 +270,7 @@ __device__ __forceinline__ SearchLds carve_lds(uint8_t *base, uint32_t ef, uint3
 
 template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *__restrict__ queries, uint64_t nq, uint32_t knbn, uint32_t ef,
-                                                     uint32_t *__restrict__ visited, uint32_t vis_words, unsigned long long *__restrict__ counter,
+                                                     const uint32_t *__restrict__ mat, uint32_t *__restrict__ visited, uint32_t vis_words, unsigned long long *__restrict__ counter,
                                                      uint64_t *__restrict__ ids_out, float *__restrict__ dist_out, uint32_t *__restrict__ count_out,
                                                      uint64_t *__restrict__ evals_out)
 {
@@ -276,16 +286,17 @@ __global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *
         const uint64_t qi = S.scal[1];
         if (qi >= nq) break;
         const uint4 *q = (const uint4 *)(queries + qi * ix.stride);
+        const uint32_t *matrow = mat ? mat + qi * ix.n : nullptr;
         for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
         uint64_t evals = 1;
         // distance to the entry point
         if (threadIdx.x == 0) S.Eid[0] = (uint32_t)ix.entry;
         __syncthreads();
-        block_distances<KIND>(ix, q, S.Eid, 1, S.Ecnt);
+        block_distances<KIND>(ix, q, S.Eid, 1, S.Ecnt, matrow);
         uint32_t ep = (uint32_t)ix.entry, ep_cnt = S.Ecnt[0];
         __syncthreads();
-        for (int L = ix.top; L >= 1; L--) greedy_layer_block<KIND>(ix, q, S, ep, ep_cnt, L, evals);
-        const uint32_t nR = search_layer_block<KIND>(ix, q, S, vis, ep, ep_cnt, efs, 0, evals);
+        for (int L = ix.top; L >= 1; L--) greedy_layer_block<KIND>(ix, q, S, ep, ep_cnt, L, evals, matrow);
+        const uint32_t nR = search_layer_block<KIND>(ix, q, S, vis, ep, ep_cnt, efs, 0, evals, matrow);
         const uint32_t nout = nR < knbn ? nR : knbn;
         for (uint32_t i = threadIdx.x; i < knbn; i += ST) {
             if (i < nout) { ids_out[qi * knbn + i] = KID(S.R[i]); dist_out[qi * knbn + i] = (float)KCNT(S.R[i]) / (float)ix.m; }
@@ -344,7 +355,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
 
 template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint32_t nb, const uint8_t *__restrict__ blevels,
-                                                   const uint32_t *__restrict__ cntmat, uint32_t efc, uint32_t ef_lds, int extend,
+                                                   const uint32_t *__restrict__ cntmat, const uint32_t *__restrict__ mat, uint32_t efc, uint32_t ef_lds, int extend,
                                                    uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ plan_keys,
                                                    uint32_t *__restrict__ plan_n, unsigned long long *__restrict__ evals_total)
 {
@@ -358,14 +369,15 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
     uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
     uint64_t evals = 0;
     const bool have_graph = ix.n > 0;
+    const uint32_t *matrow = mat ? mat + (uint64_t)i * ix.n : nullptr;
     uint32_t ep = 0, ep_cnt = 0;
     if (have_graph) {
         if (threadIdx.x == 0) S.Eid[0] = (uint32_t)ix.entry;
         __syncthreads();
-        block_distances<KIND>(ix, q, S.Eid, 1, S.Ecnt);
+        block_distances<KIND>(ix, q, S.Eid, 1, S.Ecnt, matrow);
         ep = (uint32_t)ix.entry; ep_cnt = S.Ecnt[0]; evals++;
         __syncthreads();
-        for (int L = ix.top; L > lv; L--) greedy_layer_block<KIND>(ix, q, S, ep, ep_cnt, L, evals);
+        for (int L = ix.top; L > lv; L--) greedy_layer_block<KIND>(ix, q, S, ep, ep_cnt, L, evals, matrow);
     }
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int L = lv; L >= 0; L--) {
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
         if (have_graph && L <= ix.top) {
             for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
             __syncthreads();
-            nW = search_layer_block<KIND>(ix, q, S, vis, ep, ep_cnt, efc, L, evals);
+            nW = search_layer_block<KIND>(ix, q, S, vis, ep, ep_cnt, efc, L, evals, matrow);
             ep = KID(S.R[0]); ep_cnt = KCNT(S.R[0]);
         }
         // batch-mates of sufficient level join the candidates (their distances come from the tile kernel)
@@ -510,6 +522,10 @@ struct gs_index {
     gs::DevBuf blevels, cntmat, plan_keys, plan_n, inbox, inbox_cnt, touched, ntouched, evals_dev;
     uint64_t inbox_lists = 0;
     uint64_t insert_evals = 0;
+    // dense mode: count matrix of a query / insert batch against every node, and the running
+    // fraction of the graph a traversal evaluates (negative = not measured yet)
+    gs::DevBuf mat;
+    double search_frac = -1.0, insert_frac = -1.0;
 };
 
 namespace gs {
@@ -568,6 +584,57 @@ static int upload_rows(gs_ctx *c, void *dst, uint64_t stride, const void *src, s
     return GS_OK;
 }
 
+// ---- distance-evaluation strategy -----------------------------------------------------
+// gather: every evaluation streams one candidate row from HBM (72 kB at s=18000) — right when a traversal touches a
+//         small part of the graph;
+// dense : the counts of the whole query batch against EVERY node are produced first by the tile kernel (each row is
+//         read once per 128 queries, VALU-bound), the traversal then only looks counts up — right when traversals
+//         flood the graph (ties at distance 1.0 with ef in the thousands: they evaluate most of the DB anyway).
+// Both give bit-identical results; GS_DIST_MODE=gather|dense|auto overrides the cost model.
+enum DistMode { MODE_AUTO = 0, MODE_GATHER = 1, MODE_DENSE = 2 };
+static DistMode env_mode()
+{
+    const char *e = getenv("GS_DIST_MODE");
+    if (!e) return MODE_AUTO;
+    if (!strcmp(e, "gather")) return MODE_GATHER;
+    if (!strcmp(e, "dense")) return MODE_DENSE;
+    return MODE_AUTO;
+}
+static bool dense_pays(const gs_index *ix, double frac)
+{
+    // measured on MI355X: gather sustains ~5.5e12 B/s of row bytes, the tile kernel ~1.6e13 element compares/s
+    const double gather = frac * (double)ix->rowbytes / 5.5e12;
+    const double dense = (double)ix->prm.m / (ix->prm.kind == GS_KIND_U64 ? 1.4e13 : 1.6e13);
+    return dense < gather;
+}
+
+static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, const uint32_t *mat, uint64_t *ids,
+                         float *dist, uint32_t *count, uint64_t *evals)
+{
+    gs_ctx *c = ix->ctx;
+    const uint32_t efs = std::max(ef, knbn);
+    const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
+    const size_t lds = search_lds_bytes(efs, maxdeg);
+    const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu);
+    GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
+    IndexDev d = index_dev(ix);
+    ProfScope ps(c, FAM_SEARCH);
+#define GS_LAUNCH_SEARCH(K)                                                                                               \
+    do {                                                                                                                  \
+        auto kern = k_hnsw_search<K>;                                                                                     \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST), lds, c->stream, d, q_padded_dev, nq, knbn, ef, mat,               \
+                           ix->visited.as<uint32_t>(), vis_words, ix->counter.as<unsigned long long>(), ids, dist, count, evals); \
+    } while (0)
+    if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_SEARCH(GS_KIND_F32);
+    else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_SEARCH(GS_KIND_U32);
+    else GS_LAUNCH_SEARCH(GS_KIND_U64);
+#undef GS_LAUNCH_SEARCH
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
 static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
                       uint32_t *count, uint64_t *evals)
 {
@@ -580,25 +647,44 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     GS_REQUIRE(2 * (size_t)efs + maxdeg + 64 <= (size_t)SMAXI * ST, GS_ERR_UNSUPPORTED, "ef=%u too large for the in-LDS merge", efs);
     GS_REQUIRE(maxdeg <= ST, GS_ERR_UNSUPPORTED, "max_nb_conn too large");
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
-    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu);
     int rc;
     if ((rc = ix->visited.ensure((size_t)4 * vis_words * c->n_cu))) return rc;
     if ((rc = ix->counter.ensure(64))) return rc;
-    GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
-    IndexDev d = index_dev(ix);
-    ProfScope ps(c, FAM_SEARCH);
-#define GS_LAUNCH_SEARCH(K)                                                                                               \
-    do {                                                                                                                  \
-        auto kern = k_hnsw_search<K>;                                                                                     \
-        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST), lds, c->stream, d, (const uint8_t *)q_padded_dev, nq, knbn, ef,   \
-                           ix->visited.as<uint32_t>(), vis_words, ix->counter.as<unsigned long long>(), ids, dist, count, evals); \
-    } while (0)
-    if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_SEARCH(GS_KIND_F32);
-    else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_SEARCH(GS_KIND_U32);
-    else GS_LAUNCH_SEARCH(GS_KIND_U64);
-#undef GS_LAUNCH_SEARCH
-    GS_HIP_CHECK(hipGetLastError());
+    const uint8_t *q = (const uint8_t *)q_padded_dev;
+    const DistMode mode = env_mode();
+    uint64_t done = 0;
+    DevBuf tmp_evals;
+    if (mode == MODE_AUTO && ix->search_frac < 0 && nq >= 256 && ix->n >= 4096) {
+        // probe: the first queries go the gather way and tell which fraction of the graph a traversal evaluates
+        const uint64_t np = 128;
+        uint64_t *ev = evals;
+        if (!ev) { if ((rc = tmp_evals.alloc(8 * np))) return rc; ev = tmp_evals.as<uint64_t>(); }
+        if ((rc = search_launch(ix, q, np, knbn, ef, nullptr, ids, dist, count, ev))) return rc;
+        std::vector<uint64_t> h(np);
+        GS_HIP_CHECK(hipMemcpyAsync(h.data(), ev, 8 * np, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        double sum = 0; for (uint64_t v : h) sum += (double)v;
+        ix->search_frac = sum / (double)np / (double)ix->n;
+        done = np;
+    }
+    const uint64_t rest = nq - done;
+    bool dense = mode == MODE_DENSE || (mode == MODE_AUTO && ix->search_frac >= 0 && rest >= 128 && dense_pays(ix, ix->search_frac));
+    if (!dense) {
+        if (rest) return search_launch(ix, q + done * ix->stride, rest, knbn, ef, nullptr, ids + done * knbn, dist + done * knbn,
+                                       count ? count + done : nullptr, evals ? evals + done : nullptr);
+        return GS_OK;
+    }
+    uint64_t QB = ((uint64_t)4 << 30) / (4 * ix->n);
+    QB = std::max<uint64_t>(128, QB / 128 * 128);
+    QB = std::min<uint64_t>(QB, rest);
+    if ((rc = ix->mat.ensure((size_t)4 * QB * ix->n))) return rc;
+    for (uint64_t q0 = done; q0 < nq; q0 += QB) {
+        const uint64_t nb = std::min(QB, nq - q0);
+        if ((rc = hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, q + q0 * ix->stride, nb, ix->stride, ix->data.p, ix->n, ix->stride, nullptr,
+                                      ix->mat.as<uint32_t>()))) return rc;
+        if ((rc = search_launch(ix, q + q0 * ix->stride, nb, knbn, ef, ix->mat.as<uint32_t>(), ids + q0 * knbn, dist + q0 * knbn,
+                                count ? count + q0 : nullptr, evals ? evals + q0 : nullptr))) return rc;
+    }
     return GS_OK;
 }
 
@@ -815,6 +901,9 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     g.degU = ix->degU.as<uint32_t>(); g.nbrU = ix->nbrU.as<uint32_t>(); g.cntU = ix->cntU.as<uint32_t>();
     g.upidx = ix->upidx.as<int32_t>(); g.M = M; g.max_layer = ML; g.upper_base = ix->cap;
     ix->n_upper = nup;
+    const gs::DistMode mode = gs::env_mode();
+    unsigned long long seg_ev0 = ix->insert_evals; double seg_den = 0; uint32_t seg_batches = 0;
+    if ((rc = ix->mat.ensure((size_t)4 * B * (first + n)))) return rc;
     for (uint64_t b0 = first; b0 < first + n; b0 += B) {
         const uint32_t nb = (uint32_t)std::min<uint64_t>(B, first + n - b0);
         const uint8_t *blv = lv.data() + (b0 - first);
@@ -826,13 +915,28 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         gs::IndexDev d = gs::index_dev(ix);
         d.n = b0; d.entry = ix->entry; d.top = ix->top;                  // the graph frozen at batch start
         const uint32_t vw = (uint32_t)((b0 + 31) / 32);
+        // feedback for the cost model: every 8 batches measure which fraction of the graph an insertion evaluates
+        if (mode == gs::MODE_AUTO && b0 >= 4096 && (ix->insert_frac < 0 ? seg_batches >= 2 : seg_batches >= 32)) {
+            unsigned long long ev = 0;
+            GS_HIP_CHECK(hipMemcpyAsync(&ev, ix->evals_dev.p, 8, hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (seg_den > 0) ix->insert_frac = (double)(ev - seg_ev0) / seg_den;
+            seg_ev0 = ev; seg_den = 0; seg_batches = 0;
+        }
+        const bool dense = (mode == gs::MODE_DENSE && b0 > 0) || (mode == gs::MODE_AUTO && b0 >= 4096 && nb >= 64 && ix->insert_frac >= 0 && gs::dense_pays(ix, ix->insert_frac));
+        const uint32_t *matp = nullptr;
+        if (dense) {
+            if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, ix->data.p, b0, ix->stride, nullptr, ix->mat.as<uint32_t>()))) return rc;
+            matp = ix->mat.as<uint32_t>();
+        }
+        if (b0 >= 4096) { seg_den += (double)nb * (double)b0; seg_batches++; }
         {
             gs::ProfScope ps(c, gs::FAM_INSERT);
 #define GS_LAUNCH_PLAN(K)                                                                                                  \
     do {                                                                                                                   \
         auto kern = gs::k_hnsw_plan<K>;                                                                                    \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), efc, ef_lds, \
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), matp, efc, ef_lds, \
                            ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
                            ix->evals_dev.as<unsigned long long>());                                                        \
     } while (0)

@@ -213,3 +213,25 @@ def test_sketch_super_cold_path_matches_oracle(gpu_ctx, algo, data, k):
     got = sk.sketch_genomes(genomes)
     ref = _oracle_sketch(k, 1024, algo, genomes, data)
     assert np.array_equal(_bits(got), _bits(ref))
+
+
+@pytest.mark.parametrize("mode", ["dense", "gather"])
+def test_dense_and_gather_modes_are_identical(gpu_ctx, mode, monkeypatch):
+    """the dense (tile kernel + lookup) and gather (row streaming) evaluation strategies give the same graph and answers"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", mode)
+    db = H.synth_sig_db(20, 30, 300, 31, jlo=0.05, jhi=0.95)
+    oix = O.Index(np.float32, 300, 8, 40, seed=5)
+    hn = G.Hnsw.new(8, 10000, 16, 40, G.DistHamming(), seed=5, insert_batch=32)
+    hn.set_extend_candidates(True)
+    oix.parallel_insert(db, batch=32)
+    hn.parallel_insert(db)
+    g, og = hn.export_graph(), oix.export()
+    assert np.array_equal(g["deg0"], og["deg0"])
+    for i in range(len(db)):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d])
+    q = H.queries_from(db, 200, 8, frac=0.3)
+    ids, dist, cnt, ev = hn.search_arrays(q, 10, 100)
+    oids, odist, ocnt, oev = oix.parallel_search(q, 10, 100)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist) and np.array_equal(ev, oev)
