@@ -58,7 +58,7 @@ __device__ __forceinline__ void cmp_acc8_64(uint32_t (&c)[8], uint64_t a, const 
 
 template <int KIND, bool VEC4>
 __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict__ Q, uint64_t nq, uint64_t strideQ, const uint32_t *__restrict__ C, uint64_t nc,
-                                                      uint64_t strideC, uint32_t m, float *__restrict__ out, uint32_t *__restrict__ out_cnt)
+                                                      uint64_t strideC, uint32_t m, float *__restrict__ out, uint32_t *__restrict__ out_cnt, uint16_t *__restrict__ out_cnt16, uint64_t ld_out)
 {
     constexpr int EW = ElemCmp<KIND>::EW;
     __shared__ uint32_t sq[2][HT * HP];
@@ -137,7 +137,11 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint64_t cj = c0 + tx + 16 * j;
-            if (cj < nc) { if (out) out[qi * nc + cj] = (float)cnt[i][j] / fm; else out_cnt[qi * nc + cj] = cnt[i][j]; }
+            if (cj < nc) {
+                if (out) out[qi * ld_out + cj] = (float)cnt[i][j] / fm;
+                else if (out_cnt) out_cnt[qi * ld_out + cj] = cnt[i][j];
+                else out_cnt16[qi * ld_out + cj] = (uint16_t)cnt[i][j];
+            }
         }
     }
 }
@@ -165,18 +169,20 @@ __global__ __launch_bounds__(256) void k_hamming_pairs(const uint32_t *__restric
 }
 
 int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, uint64_t strideQ_bytes, const void *C, uint64_t nc,
-                        uint64_t strideC_bytes, float *out, uint32_t *out_cnt)
+                        uint64_t strideC_bytes, float *out, uint32_t *out_cnt, uint16_t *out_cnt16, uint64_t ld_out)
 {
     GS_REQUIRE(c && m > 0, GS_ERR_INVALID, "bad argument");
     GS_REQUIRE(kind == GS_KIND_F32 || kind == GS_KIND_U32 || kind == GS_KIND_U64, GS_ERR_UNSUPPORTED, "DistHamming kind %d not on the device path", kind);
     if (nq == 0 || nc == 0) return GS_OK;
-    GS_REQUIRE(Q && C && (out || out_cnt), GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(Q && C && (out || out_cnt || out_cnt16), GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(!out_cnt16 || m <= 65535, GS_ERR_INVALID, "16-bit counts need m <= 65535");
+    if (ld_out == 0) ld_out = nc;
     dim3 grid((uint32_t)((nc + HT - 1) / HT), (uint32_t)((nq + HT - 1) / HT)), block(256);
     GS_REQUIRE(grid.y <= 65535, GS_ERR_INVALID, "too many query rows for one call (max %d)", 65535 * HT);
     ProfScope ps(c, FAM_HAMMING);
     const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
     const bool vec4 = (strideQ_bytes % 16 == 0) && (strideC_bytes % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)C % 16 == 0);
-#define GS_LAUNCH_QXC(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V>), grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt)
+#define GS_LAUNCH_QXC(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V>), grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt, out_cnt16, ld_out)
     if (kind == GS_KIND_F32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_F32, true); else GS_LAUNCH_QXC(GS_KIND_F32, false); }
     else if (kind == GS_KIND_U32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_U32, true); else GS_LAUNCH_QXC(GS_KIND_U32, false); }
     else { if (vec4) GS_LAUNCH_QXC(GS_KIND_U64, true); else GS_LAUNCH_QXC(GS_KIND_U64, false); }
@@ -187,7 +193,7 @@ int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t
 static int hamming_qxc_dev(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc, float *out)
 {
     const uint64_t row = kind_bytes(kind) * (uint64_t)m;
-    return hamming_qxc_strided(c, kind, m, Q, nq, row, C, nc, row, out, nullptr);
+    return hamming_qxc_strided(c, kind, m, Q, nq, row, C, nc, row, out, nullptr, nullptr, nc);
 }
 
 }  // namespace gs

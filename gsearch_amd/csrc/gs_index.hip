@@ -37,6 +37,7 @@ struct IndexDev {
     uint32_t M, max_layer;
     const uint8_t *levels; const uint32_t *deg0; const uint32_t *nbr0;
     const int32_t *upidx; const uint32_t *degU; const uint32_t *nbrU;
+    const uint64_t *rowptr;      // pair cache: rowptr[a] -> uint16 counts of node a against every node b < a (0 = not cached)
     uint64_t n; int64_t entry; int top;
 };
 
@@ -108,7 +109,7 @@ __device__ __forceinline__ uint32_t chunk_mismatch_wave(const uint4 &a, const ui
 // (DESIGN.md 3.5 "dense mode") and are simply looked up.
 template <int KIND>
 __device__ __forceinline__ void block_distances(const IndexDev &ix, const uint4 *__restrict__ q, const uint32_t *Eid, uint32_t ne, uint32_t *Ecnt,
-                                                const uint32_t *__restrict__ matrow = nullptr)
+                                                const uint16_t *__restrict__ matrow = nullptr)
 {
     if (matrow) {
         for (uint32_t e = threadIdx.x; e < ne; e += ST) Ecnt[e] = matrow[Eid[e]];
@@ -158,7 +159,7 @@ __device__ __forceinline__ void node_neighbours(const IndexDev &ix, uint32_t nod
 template <int KIND>
 __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t *vis,
                                                        uint32_t ep, uint32_t ep_cnt, uint32_t ef, int L, uint64_t &evals,
-                                                       const uint32_t *__restrict__ matrow = nullptr)
+                                                       const uint16_t *__restrict__ matrow = nullptr)
 {
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t capC = 2 * ef + maxdeg + 64;
@@ -233,7 +234,7 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
 // greedy descent on one upper layer (hnsw_rs::search outer loop, SPEC 5)
 template <int KIND>
 __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t &ep,
-                                                   uint32_t &ep_cnt, int L, uint64_t &evals, const uint32_t *__restrict__ matrow = nullptr)
+                                                   uint32_t &ep_cnt, int L, uint64_t &evals, const uint16_t *__restrict__ matrow = nullptr)
 {
     for (;;) {
         const uint32_t *nbr; uint32_t deg;
@@ -270,7 +271,7 @@ __device__ __forceinline__ SearchLds carve_lds(uint8_t *base, uint32_t ef, uint3
 
 template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *__restrict__ queries, uint64_t nq, uint32_t knbn, uint32_t ef,
-                                                     const uint32_t *__restrict__ mat, uint32_t *__restrict__ visited, uint32_t vis_words, unsigned long long *__restrict__ counter,
+                                                     const uint16_t *__restrict__ mat, uint32_t *__restrict__ visited, uint32_t vis_words, unsigned long long *__restrict__ counter,
                                                      uint64_t *__restrict__ ids_out, float *__restrict__ dist_out, uint32_t *__restrict__ count_out,
                                                      uint64_t *__restrict__ evals_out)
 {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *
         const uint64_t qi = S.scal[1];
         if (qi >= nq) break;
         const uint4 *q = (const uint4 *)(queries + qi * ix.stride);
-        const uint32_t *matrow = mat ? mat + qi * ix.n : nullptr;
+        const uint16_t *matrow = mat ? mat + qi * ix.n : nullptr;
         for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
         uint64_t evals = 1;
         // distance to the entry point
@@ -330,7 +331,35 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
         bool accept = true;
         if (na > 0) {
             if (KCNT(e) >= ix.m) accept = false;        // c(e,s) <= m = c(x,e) for every s: always pruned
-            else {
+            else if (ix.rowptr && na <= ST) {
+                // pair cache: c(e,s) of two existing nodes was computed when the younger one was inserted
+                int conflict = 0, miss = 0;
+                if (threadIdx.x < na) {
+                    const uint32_t sid = KID(S.A[threadIdx.x]), eid = KID(e);
+                    const uint32_t hi = sid > eid ? sid : eid, lo = sid > eid ? eid : sid;
+                    const uint16_t *row = (const uint16_t *)ix.rowptr[hi];
+                    if (row) conflict = (uint32_t)row[lo] <= KCNT(e); else miss = 1;
+                }
+                const int any_miss = __syncthreads_or(miss);
+                if (!any_miss) { evals += na; if (__syncthreads_or(conflict)) accept = false; }
+                else {
+                    const uint4 *erow = (const uint4 *)(ix.data + (uint64_t)KID(e) * ix.stride);
+                    uint32_t ch = PLAN_CH0;
+                    for (uint32_t s0 = 0; s0 < na && accept; ) {
+                        uint32_t nch = na - s0 < ch ? na - s0 : ch;
+                        if (nch > maxdeg) nch = maxdeg;
+                        if (threadIdx.x < nch) S.Eid[threadIdx.x] = KID(S.A[s0 + threadIdx.x]);
+                        __syncthreads();
+                        block_distances<KIND>(ix, erow, S.Eid, nch, S.Ecnt);
+                        evals += nch;
+                        bool cf = false;
+                        for (uint32_t t = 0; t < nch; t++) cf |= (S.Ecnt[t] <= KCNT(e));
+                        __syncthreads();
+                        if (cf) accept = false;
+                        s0 += nch; ch = PLAN_CH1;
+                    }
+                }
+            } else {
                 const uint4 *erow = (const uint4 *)(ix.data + (uint64_t)KID(e) * ix.stride);
                 uint32_t ch = PLAN_CH0;
                 for (uint32_t s0 = 0; s0 < na && accept; ) {
@@ -355,7 +384,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
 
 template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint32_t nb, const uint8_t *__restrict__ blevels,
-                                                   const uint32_t *__restrict__ cntmat, const uint32_t *__restrict__ mat, uint32_t efc, uint32_t ef_lds, int extend,
+                                                   const uint32_t *__restrict__ cntmat, const uint16_t *__restrict__ mat, uint64_t mat_ld, uint32_t efc, uint32_t ef_lds, int extend,
                                                    uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ plan_keys,
                                                    uint32_t *__restrict__ plan_n, unsigned long long *__restrict__ evals_total)
 {
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
     uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
     uint64_t evals = 0;
     const bool have_graph = ix.n > 0;
-    const uint32_t *matrow = mat ? mat + (uint64_t)i * ix.n : nullptr;
+    const uint16_t *matrow = mat ? mat + (uint64_t)i * mat_ld : nullptr;
     uint32_t ep = 0, ep_cnt = 0;
     if (have_graph) {
         if (threadIdx.x == 0) S.Eid[0] = (uint32_t)ix.entry;
@@ -416,6 +445,15 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
         __syncthreads();
     }
     if (threadIdx.x == 0) atomicAdd(evals_total, (unsigned long long)evals);
+}
+
+// pair cache rows of one dense batch: columns [0,b0) come from the tile kernel, [b0,b0+nb) from the mates matrix
+__global__ void k_cache_rows(uint16_t *__restrict__ rowbase, uint64_t ld, uint64_t b0, uint32_t nb, const uint32_t *__restrict__ cntmat, uint64_t *__restrict__ rowptr)
+{
+    const uint32_t i = blockIdx.x;
+    uint16_t *row = rowbase + (uint64_t)i * ld;
+    for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) row[b0 + j] = (uint16_t)cntmat[(uint64_t)i * nb + j];
+    if (threadIdx.x == 0) rowptr[b0 + i] = (uint64_t)row;
 }
 
 // ---- phase 2: links -------------------------------------------------------------------------------
@@ -526,6 +564,12 @@ struct gs_index {
     // fraction of the graph a traversal evaluates (negative = not measured yet)
     gs::DevBuf mat;
     double search_frac = -1.0, insert_frac = -1.0;
+    // pair cache: the count rows the tile kernel produces for every inserted batch are KEPT (16 bit) so that
+    // the neighbour-selection heuristic looks pair distances up instead of streaming rows; 288 GB of HBM hold it up to ~500 k points
+    gs::DevBuf rowptr;
+    std::vector<gs::DevBuf *> slabs;
+    uint64_t pair_cache_bytes = 0, pair_cache_budget = 0;
+    ~gs_index() { for (auto *b : slabs) delete b; }
 };
 
 namespace gs {
@@ -537,7 +581,7 @@ static int index_reserve(gs_index *ix, uint64_t need, uint64_t need_upper)
     if (need > ix->cap) {
         uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap + ix->cap / 2, 1024));
         struct { DevBuf *b; size_t per; } arr[] = {
-            {&ix->data, (size_t)ix->stride}, {&ix->levels, 1}, {&ix->deg0, 4}, {&ix->nbr0, (size_t)8 * M}, {&ix->cnt0, (size_t)8 * M}, {&ix->upidx, 4}};
+            {&ix->data, (size_t)ix->stride}, {&ix->levels, 1}, {&ix->deg0, 4}, {&ix->nbr0, (size_t)8 * M}, {&ix->cnt0, (size_t)8 * M}, {&ix->upidx, 4}, {&ix->rowptr, 8}};
         for (auto &a : arr) {
             DevBuf nb;
             int rc = nb.alloc(a.per * ncap); if (rc) return rc;
@@ -571,6 +615,7 @@ static IndexDev index_dev(const gs_index *ix)
     d.M = ix->prm.max_nb_conn; d.max_layer = ix->prm.max_layer;
     d.levels = ix->levels.as<uint8_t>(); d.deg0 = ix->deg0.as<uint32_t>(); d.nbr0 = ix->nbr0.as<uint32_t>();
     d.upidx = ix->upidx.as<int32_t>(); d.degU = ix->degU.as<uint32_t>(); d.nbrU = ix->nbrU.as<uint32_t>();
+    d.rowptr = ix->rowptr.as<uint64_t>();
     d.n = ix->n; d.entry = ix->entry; d.top = ix->top;
     return d;
 }
@@ -608,7 +653,7 @@ static bool dense_pays(const gs_index *ix, double frac)
     return dense < gather;
 }
 
-static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, const uint32_t *mat, uint64_t *ids,
+static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t *ids,
                          float *dist, uint32_t *count, uint64_t *evals)
 {
     gs_ctx *c = ix->ctx;
@@ -668,21 +713,21 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
         done = np;
     }
     const uint64_t rest = nq - done;
-    bool dense = mode == MODE_DENSE || (mode == MODE_AUTO && ix->search_frac >= 0 && rest >= 128 && dense_pays(ix, ix->search_frac));
+    bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || (mode == MODE_AUTO && ix->search_frac >= 0 && rest >= 128 && dense_pays(ix, ix->search_frac)));
     if (!dense) {
         if (rest) return search_launch(ix, q + done * ix->stride, rest, knbn, ef, nullptr, ids + done * knbn, dist + done * knbn,
                                        count ? count + done : nullptr, evals ? evals + done : nullptr);
         return GS_OK;
     }
-    uint64_t QB = ((uint64_t)4 << 30) / (4 * ix->n);
+    uint64_t QB = ((uint64_t)4 << 30) / (2 * ix->n);
     QB = std::max<uint64_t>(128, QB / 128 * 128);
     QB = std::min<uint64_t>(QB, rest);
-    if ((rc = ix->mat.ensure((size_t)4 * QB * ix->n))) return rc;
+    if ((rc = ix->mat.ensure((size_t)2 * QB * ix->n))) return rc;
     for (uint64_t q0 = done; q0 < nq; q0 += QB) {
         const uint64_t nb = std::min(QB, nq - q0);
         if ((rc = hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, q + q0 * ix->stride, nb, ix->stride, ix->data.p, ix->n, ix->stride, nullptr,
-                                      ix->mat.as<uint32_t>()))) return rc;
-        if ((rc = search_launch(ix, q + q0 * ix->stride, nb, knbn, ef, ix->mat.as<uint32_t>(), ids + q0 * knbn, dist + q0 * knbn,
+                                      nullptr, ix->mat.as<uint16_t>(), ix->n))) return rc;
+        if ((rc = search_launch(ix, q + q0 * ix->stride, nb, knbn, ef, ix->mat.as<uint16_t>(), ids + q0 * knbn, dist + q0 * knbn,
                                 count ? count + q0 : nullptr, evals ? evals + q0 : nullptr))) return rc;
     }
     return GS_OK;
@@ -903,7 +948,14 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     ix->n_upper = nup;
     const gs::DistMode mode = gs::env_mode();
     unsigned long long seg_ev0 = ix->insert_evals; double seg_den = 0; uint32_t seg_batches = 0;
-    if ((rc = ix->mat.ensure((size_t)4 * B * (first + n)))) return rc;
+    const bool cnt16 = ix->prm.m <= 65535;
+    if (ix->pair_cache_budget == 0) {
+        const char *e = getenv("GS_PAIR_CACHE_GB");
+        ix->pair_cache_budget = e ? (uint64_t)(atof(e) * 1e9) : (uint64_t)(0.55 * (double)c->hbm_bytes);
+    }
+    const uint64_t slab_ld = gs::round_up(first + n, 8);
+    gs::DevBuf *slab = nullptr; uint64_t slab_first = 0;      // rows of this call's points, allocated at the first dense batch
+    bool slab_tried = false;
     for (uint64_t b0 = first; b0 < first + n; b0 += B) {
         const uint32_t nb = (uint32_t)std::min<uint64_t>(B, first + n - b0);
         const uint8_t *blv = lv.data() + (b0 - first);
@@ -911,7 +963,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         GS_HIP_CHECK(hipMemsetAsync(ix->plan_n.p, 0, (size_t)4 * nb * ML, c->stream));
         GS_HIP_CHECK(hipMemsetAsync(ix->ntouched.p, 0, 4, c->stream));
         const uint8_t *rows = ix->data.as<uint8_t>() + b0 * ix->stride;
-        if (nb > 1) { if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, rows, nb, ix->stride, nullptr, ix->cntmat.as<uint32_t>()))) return rc; }
+        if (nb > 1) { if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, rows, nb, ix->stride, nullptr, ix->cntmat.as<uint32_t>(), nullptr, nb))) return rc; }
         gs::IndexDev d = gs::index_dev(ix);
         d.n = b0; d.entry = ix->entry; d.top = ix->top;                  // the graph frozen at batch start
         const uint32_t vw = (uint32_t)((b0 + 31) / 32);
@@ -924,10 +976,26 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             seg_ev0 = ev; seg_den = 0; seg_batches = 0;
         }
         const bool dense = (mode == gs::MODE_DENSE && b0 > 0) || (mode == gs::MODE_AUTO && b0 >= 4096 && nb >= 64 && ix->insert_frac >= 0 && gs::dense_pays(ix, ix->insert_frac));
-        const uint32_t *matp = nullptr;
-        if (dense) {
-            if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, ix->data.p, b0, ix->stride, nullptr, ix->mat.as<uint32_t>()))) return rc;
-            matp = ix->mat.as<uint32_t>();
+        const uint16_t *matp = nullptr; uint64_t mat_ld = 0;
+        if (dense && cnt16) {
+            if (!slab_tried) {
+                slab_tried = true;
+                const uint64_t need = (first + n - b0) * slab_ld * 2;
+                if (ix->pair_cache_bytes + need <= ix->pair_cache_budget) {
+                    slab = new gs::DevBuf();
+                    if (slab->alloc(need) != GS_OK) { delete slab; slab = nullptr; }
+                    else { ix->slabs.push_back(slab); ix->pair_cache_bytes += need; slab_first = b0; }
+                }
+            }
+            uint16_t *out16;
+            if (slab) { out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld; mat_ld = slab_ld; }
+            else { if ((rc = ix->mat.ensure((size_t)2 * B * slab_ld))) return rc; out16 = ix->mat.as<uint16_t>(); mat_ld = slab_ld; }
+            if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, ix->data.p, b0, ix->stride, nullptr, nullptr, out16, mat_ld))) return rc;
+            if (slab) {
+                hipLaunchKernelGGL(gs::k_cache_rows, dim3(nb), dim3(256), 0, c->stream, out16, mat_ld, b0, nb, ix->cntmat.as<uint32_t>(), ix->rowptr.as<uint64_t>());
+                GS_HIP_CHECK(hipGetLastError());
+            }
+            matp = out16;
         }
         if (b0 >= 4096) { seg_den += (double)nb * (double)b0; seg_batches++; }
         {
@@ -936,7 +1004,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     do {                                                                                                                   \
         auto kern = gs::k_hnsw_plan<K>;                                                                                    \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), matp, efc, ef_lds, \
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), matp, mat_ld, efc, ef_lds, \
                            ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
                            ix->evals_dev.as<unsigned long long>());                                                        \
     } while (0)

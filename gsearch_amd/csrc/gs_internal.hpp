@@ -71,10 +71,10 @@ struct ProfScope {   // brackets one kernel launch with events when profiling is
     }
 };
 
-// dense Q x C DistHamming tile kernel with arbitrary row strides (bytes); writes f32 distances (out) or, when out is
-// null, integer mismatch counts (out_cnt). Defined in gs_hamming.hip.
+// dense Q x C DistHamming tile kernel with arbitrary row strides (bytes); writes exactly one of: f32 distances (out),
+// 32-bit mismatch counts (out_cnt), 16-bit mismatch counts (out_cnt16); ld_out = output row pitch in elements (0 -> nc).
 int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, uint64_t strideQ_bytes, const void *C, uint64_t nc,
-                        uint64_t strideC_bytes, float *out, uint32_t *out_cnt);
+                        uint64_t strideC_bytes, float *out, uint32_t *out_cnt, uint16_t *out_cnt16, uint64_t ld_out);
 
 inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }
 inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
