@@ -239,7 +239,8 @@ def run_request(args, torch, rank, world, local):
     dist_t = torch.empty((qps, knbn), dtype=torch.float32, device="cuda")
     cnt_t = torch.empty((qps,), dtype=torch.int32, device="cuda")
     ev_t = torch.zeros((qps,), dtype=torch.int64, device="cuda")
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the all-gather runs even with one rank
+    if use_dist:
         import torch.distributed as dist
         all_ids = torch.empty((world * qps, knbn), dtype=torch.int64, device="cuda")
         all_dist = torch.empty((world * qps, knbn), dtype=torch.float32, device="cuda")
@@ -250,7 +251,7 @@ def run_request(args, torch, rank, world, local):
         b = i % nsteps_q
         sketch_dev(d_qseq + b * qps * gbytes, qps, d_qsig, d_rs, d_rl, d_goff)
         chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, qps, knbn, ef, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), ev_t.data_ptr()))
-        if world > 1:      # RCCL all-gather of the per-rank top-k blocks (ids + distances), SURVEY 8e
+        if use_dist:       # RCCL all-gather of the per-rank top-k blocks (ids + distances), SURVEY 8e
             dist.all_gather_into_tensor(all_ids, ids_t)
             dist.all_gather_into_tensor(all_dist, dist_t)
 
@@ -306,7 +307,9 @@ def run_request(args, torch, rank, world, local):
                            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                            "note": ("dense mode: the tile kernel reads each candidate row once per 128 queries, so the algorithmic bytes (72 kB per "
                                     "evaluated pair) exceed physical HBM traffic and frac > 1; its binding resource is VALU issue (valu_frac)")
-                                   if dom["kernel"] == "k_hamming_qxc" else "gather mode: one 72 kB row streamed per evaluation"}
+                                   if dom["kernel"] == "k_hamming_qxc" else
+                                   ("dense mode traversal: counts are looked up in the tile kernel's matrix, the 72 kB/evaluation figure is nominal" if tile_n
+                                    else "gather mode: one 72 kB row streamed from HBM per evaluation")}
         out["kernels"] = kernels
         # ---- parity / recall / CPU baseline on a bounded sample of the last step's queries
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -381,8 +384,8 @@ def main():
         run_sketch(args, torch, rank, world, local)
     else:
         run_request(args, torch, rank, world, local)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

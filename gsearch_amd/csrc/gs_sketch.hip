@@ -13,6 +13,7 @@
 #include <math.h>
 #include <algorithm>
 #include <vector>
+#include <hipcub/hipcub.hpp>
 #include "gs_internal.hpp"
 #include "gs_spec.hpp"
 
@@ -47,7 +48,7 @@ __global__ void k_unit_prefix(const uint64_t *rec_start, const uint64_t *rec_len
 template <int ALGO, int VBITS, typename T, bool LDS_TABLE>
 struct MinEmit {
     T *table; uint32_t m; uint64_t zone;
-    __device__ __forceinline__ void operator()(uint64_t v) const
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t /*rec*/, uint64_t /*pos*/) const
     {
         uint64_t o1; uint32_t b;
         two_draw(elem_hash<ALGO, VBITS>(v), m, zone, o1, b);
@@ -95,7 +96,7 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
                 fwd = ((fwd << 2) | c) & mask;
                 rc = (rc >> 2) | ((3 - c) << rcshift);
                 uint64_t a = a0 + j;
-                if (a >= first_valid && a < re) emit((fwd < rc ? fwd : rc) & mask);
+                if (a >= first_valid && a < re) emit((fwd < rc ? fwd : rc) & mask, lo, a);
             }
         } else {
             const uint64_t *w64 = (const uint64_t *)seq;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
                     uint32_t ch = (uint32_t)(x & 0xFF); x >>= 8;
                     val = ((val << 5) | c_aa_code[ch & 31]) & mask;
                     uint64_t a = a0 + q * 8 + j;
-                    if (a >= first_valid && a < re) emit(val);
+                    if (a >= first_valid && a < re) emit(val, lo, a);
                 }
             }
         }
@@ -400,6 +401,324 @@ static int launch_oph(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
     return GS_OK;
 }
 
+// =====================================================================================================
+// prob (ProbMinHash3a, SPEC 3.3): multiset of canonical k-mers -> weighted per-slot argmin of (h, v).
+//   1. every k-mer value is written to a buffer (composite key = genome-in-chunk << vbits | value), one global radix sort,
+//      run-length encode -> distinct elements with their multiplicity w;
+//   2. pass i = 1,2,..: every element still alive (w^-1 (i-1) <= max_b q[b]) replays its generator up to its i-th point
+//      h = w^-1 (i-1) + w^-1 TE, slot b, and atomically lowers q[b]; the winners (h == q[b]) then race for the smallest v.
+//      At genome sizes of interest all m slots are filled in pass 1 and only k-mers repeated >~ 30 times see pass 2.
+// The result is the exact per-slot argmin of SPEC 3.3 (pruning is sound in any order).
+// =====================================================================================================
+struct ProbConst { double lambda, c1, c2, c3; };
+__device__ __forceinline__ double em1_spec(double z)
+{
+    double t = 1.0 + z / 6.0;
+    t = 1.0 + (z / 5.0) * t;
+    t = 1.0 + (z / 4.0) * t;
+    t = 1.0 + (z / 3.0) * t;
+    t = 1.0 + (z / 2.0) * t;
+    return z * t;
+}
+__device__ __forceinline__ double texp_sample(const ProbConst &t, Rng &g)
+{
+    double x = t.c1 * g.u64f();
+    if (x < 1.0) return x;
+    for (;;) {
+        x = g.u64f();
+        if (x < t.c2) return x;
+        double y = 0.5 * g.u64f();
+        if (y > 1.0 - x) { x = 1.0 - x; y = 1.0 - y; }
+        if (x <= t.c3 * (1.0 - y)) return x;
+        if (y * t.c1 <= 1.0 - x) return x;
+        if ((y * t.c1) * t.lambda <= em1_spec(t.lambda * (1.0 - x))) return x;
+    }
+}
+#define GS_INF_BITS 0x7FF0000000000000ULL
+
+// k-mers per record -> exclusive prefix inside each genome
+__global__ void k_kmer_prefix(const uint64_t *rec_len, const uint64_t *genome_rec_off, uint64_t n_genomes, uint32_t k, uint64_t *rec_kpre, uint64_t *gen_kmers)
+{
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_genomes) return;
+    uint64_t acc = 0;
+    for (uint64_t r = genome_rec_off[g]; r < genome_rec_off[g + 1]; r++) { rec_kpre[r] = acc; uint64_t len = rec_len[r]; if (len >= k) acc += len - k + 1; }
+    gen_kmers[g] = acc;
+}
+struct ValueEmit {
+    uint64_t *out; const uint64_t *rec_start; const uint64_t *rec_kpre; uint64_t base; uint64_t tag; uint32_t k;
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t rec, uint64_t pos) const
+    {
+        out[base + rec_kpre[rec] + (pos - rec_start[rec] - (k - 1))] = tag | v;
+    }
+};
+template <bool AA>
+__global__ __launch_bounds__(SK_THREADS) void k_emit_values(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
+                                                             const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ rec_kpre,
+                                                             const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
+                                                             const uint64_t *__restrict__ gen_base, uint64_t g0, uint32_t k, uint32_t vbits, uint64_t *__restrict__ out)
+{
+    const uint64_t gl = blockIdx.y, g = g0 + gl;
+    ValueEmit emit{out, rec_start, rec_kpre, gen_base[gl], vbits >= 64 ? 0 : (gl << vbits), k};
+    walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, blockIdx.x, gridDim.x, emit);
+}
+__global__ void k_prob_init(uint64_t *q, uint64_t *qprev, uint64_t *sig, uint64_t *sigpass, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        q[i] = GS_INF_BITS; qprev[i] = GS_INF_BITS; sig[i] = ~(uint64_t)0; sigpass[i] = ~(uint64_t)0;
+    }
+}
+__global__ void k_prob_wmax(const uint64_t *ukey, const uint32_t *ucnt, uint64_t ne, uint32_t vbits, uint32_t *wmax)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x)
+        atomicMax(&wmax[vbits >= 64 ? 0 : (ukey[e] >> vbits)], ucnt[e]);
+}
+// pass `it`, phase A: i-th point of every live element -> q[b] = min
+__global__ void k_prob_point(const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ ucnt, uint64_t ne, uint32_t vbits, uint32_t m, uint64_t zone,
+                             ProbConst pc, uint32_t it, const double *__restrict__ qmax, uint64_t *__restrict__ q, uint64_t *__restrict__ cand_h,
+                             uint32_t *__restrict__ cand_b)
+{
+    const uint64_t vmask = vbits >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << vbits) - 1);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = ukey[e];
+        const uint64_t gl = vbits >= 64 ? 0 : (key >> vbits), v = key & vmask;
+        const double winv = 1.0 / (double)ucnt[e];
+        const double base = winv * (double)(it - 1);
+        uint32_t b = 0xFFFFFFFFu; uint64_t hb = 0;
+        if (!(base > qmax[gl])) {
+            Rng rg; rg.seed(v);                                 // prob: identity element hash (SPEC 2)
+            double x = 0;
+            for (uint32_t t = 0; t < it; t++) { x = texp_sample(pc, rg); b = (uint32_t)rng_uint(rg, (uint64_t)m, zone); }
+            const double h = base + winv * x;
+            hb = (uint64_t)__double_as_longlong(h);             // h >= 0: the bit pattern orders like the value
+            uint64_t *slot = q + gl * (uint64_t)m + b;
+            if (hb < *slot) atomicMin((unsigned long long *)slot, (unsigned long long)hb);
+        }
+        cand_b[e] = b; cand_h[e] = hb;
+    }
+}
+// after pass 1: elements that can still reach a slot (w^-1 <= max q) are compacted into a list with their generator state,
+// so that later passes touch only them and never replay
+__global__ void k_prob_compact(const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ ucnt, uint64_t ne, uint32_t vbits, uint32_t m, uint64_t zone,
+                               ProbConst pc, const double *__restrict__ qmax, uint32_t cap, uint32_t *__restrict__ n_act, uint64_t *__restrict__ akey,
+                               uint32_t *__restrict__ acnt, uint64_t *__restrict__ astate)
+{
+    const uint64_t vmask = vbits >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << vbits) - 1);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = ukey[e];
+        const uint64_t gl = vbits >= 64 ? 0 : (key >> vbits);
+        const double winv = 1.0 / (double)ucnt[e];
+        if (winv * 1.0 > qmax[gl]) continue;
+        const uint32_t pos = atomicAdd(n_act, 1u);
+        if (pos >= cap) continue;                                  // overflow: the host falls back to replay mode
+        Rng rg; rg.seed(key & vmask);
+        (void)texp_sample(pc, rg); (void)rng_uint(rg, (uint64_t)m, zone);
+        akey[pos] = key; acnt[pos] = ucnt[e];
+        astate[pos] = rg.s0; astate[(uint64_t)cap + pos] = rg.s1; astate[2 * (uint64_t)cap + pos] = rg.s2; astate[3 * (uint64_t)cap + pos] = rg.s3;
+    }
+}
+__global__ void k_prob_point_list(const uint64_t *__restrict__ akey, const uint32_t *__restrict__ acnt, uint32_t na, uint32_t cap, uint32_t vbits, uint32_t m,
+                                  uint64_t zone, ProbConst pc, uint32_t it, const double *__restrict__ qmax, uint64_t *__restrict__ q, uint64_t *__restrict__ astate,
+                                  uint64_t *__restrict__ cand_h, uint32_t *__restrict__ cand_b)
+{
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < na; e += gridDim.x * blockDim.x) {
+        const uint64_t key = akey[e];
+        const uint64_t gl = vbits >= 64 ? 0 : (key >> vbits);
+        const double winv = 1.0 / (double)acnt[e];
+        const double base = winv * (double)(it - 1);
+        uint32_t b = 0xFFFFFFFFu; uint64_t hb = 0;
+        if (!(base > qmax[gl])) {
+            Rng rg; rg.s0 = astate[e]; rg.s1 = astate[(uint64_t)cap + e]; rg.s2 = astate[2 * (uint64_t)cap + e]; rg.s3 = astate[3 * (uint64_t)cap + e];
+            const double x = texp_sample(pc, rg);
+            b = (uint32_t)rng_uint(rg, (uint64_t)m, zone);
+            astate[e] = rg.s0; astate[(uint64_t)cap + e] = rg.s1; astate[2 * (uint64_t)cap + e] = rg.s2; astate[3 * (uint64_t)cap + e] = rg.s3;
+            const double h = base + winv * x;
+            hb = (uint64_t)__double_as_longlong(h);
+            uint64_t *slot = q + gl * (uint64_t)m + b;
+            if (hb < *slot) atomicMin((unsigned long long *)slot, (unsigned long long)hb);
+        }
+        cand_b[e] = b; cand_h[e] = hb;
+    }
+}
+// phase B: among the points that reached the slot minimum the smallest value wins
+__global__ void k_prob_claim(const uint64_t *__restrict__ ukey, uint64_t ne, uint32_t vbits, uint32_t m, const uint64_t *__restrict__ q,
+                             const uint64_t *__restrict__ cand_h, const uint32_t *__restrict__ cand_b, uint64_t *__restrict__ sigpass)
+{
+    const uint64_t vmask = vbits >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << vbits) - 1);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = cand_b[e];
+        if (b == 0xFFFFFFFFu) continue;
+        const uint64_t key = ukey[e], gl = vbits >= 64 ? 0 : (key >> vbits);
+        if (cand_h[e] == q[gl * (uint64_t)m + b]) atomicMin((unsigned long long *)&sigpass[gl * (uint64_t)m + b], (unsigned long long)(key & vmask));
+    }
+}
+// phase C (one workgroup per genome): fold the pass winners into sig, recompute max_b q[b], decide whether the genome is done
+__global__ __launch_bounds__(256) void k_prob_fold(uint32_t m, uint32_t it, uint64_t *__restrict__ q, uint64_t *__restrict__ qprev, uint64_t *__restrict__ sig,
+                                                    uint64_t *__restrict__ sigpass, const uint32_t *__restrict__ wmax, double *__restrict__ qmax,
+                                                    uint32_t *__restrict__ n_active)
+{
+    __shared__ unsigned long long s_max;
+    const uint64_t g = blockIdx.x;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    unsigned long long loc = 0;
+    for (uint32_t b = threadIdx.x; b < m; b += blockDim.x) {
+        const uint64_t i = g * (uint64_t)m + b;
+        const uint64_t sp = sigpass[i], qq = q[i];
+        if (sp != ~(uint64_t)0) { if (qq != qprev[i]) sig[i] = sp; else if (sp < sig[i]) sig[i] = sp; sigpass[i] = ~(uint64_t)0; }
+        qprev[i] = qq;
+        if (qq > loc) loc = qq;
+    }
+    atomicMax(&s_max, loc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double qm = __longlong_as_double((long long)s_max);
+        qmax[g] = qm;
+        const uint32_t w = wmax[g];
+        if (w > 0 && !((1.0 / (double)w) * (double)it > qm)) atomicAdd(n_active, 1u);      // some element may still reach a slot in pass it+1
+    }
+}
+template <typename T>
+__global__ void k_prob_write(const uint64_t *__restrict__ q, const uint64_t *__restrict__ sig, uint64_t n, T *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = q[i] == GS_INF_BITS ? (T)0 : (T)sig[i];
+}
+
+static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, uint64_t seq_bytes, const uint64_t *rec_start, const uint64_t *rec_len,
+                    uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out)
+{
+    const uint32_t m = p->sketch_size, k = p->k;
+    const bool aa = p->data_t == GS_DATA_AA;
+    const uint32_t vbits = aa ? 5 * k : 2 * k;
+    const int sigbits = gs_value_bits(p);
+    const uint64_t zone = uint_zone(m);
+    ProbConst pc;
+    pc.lambda = log((double)m / (double)(m - 1));
+    pc.c1 = expm1(pc.lambda) / pc.lambda;
+    pc.c2 = log(2.0 / (1.0 + exp(-pc.lambda))) / pc.lambda;
+    pc.c3 = (1.0 - exp(-pc.lambda)) / pc.lambda;
+    int rc;
+    DevBuf upre, gunits, kpre, gkm;
+    if ((rc = upre.alloc(8 * (n_rec + 1)))) return rc;
+    if ((rc = gunits.alloc(8 * n_genomes))) return rc;
+    if ((rc = kpre.alloc(8 * (n_rec + 1)))) return rc;
+    if ((rc = gkm.alloc(8 * n_genomes))) return rc;
+    const uint32_t gb = (uint32_t)((n_genomes + 255) / 256);
+    hipLaunchKernelGGL(k_unit_prefix, dim3(gb), dim3(256), 0, c->stream, rec_start, rec_len, genome_rec_off, n_genomes, k, upre.as<uint64_t>(), gunits.as<uint64_t>());
+    hipLaunchKernelGGL(k_kmer_prefix, dim3(gb), dim3(256), 0, c->stream, rec_len, genome_rec_off, n_genomes, k, kpre.as<uint64_t>(), gkm.as<uint64_t>());
+    GS_HIP_CHECK(hipGetLastError());
+    std::vector<uint64_t> hk(n_genomes);
+    GS_HIP_CHECK(hipMemcpyAsync(hk.data(), gkm.p, 8 * n_genomes, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    // chunks of genomes: the composite sort key needs log2(chunk) spare bits; memory bounds the k-mer count
+    const uint64_t max_items = (uint64_t)3 << 28;                       // ~8e8 k-mers per chunk (6.4 GB of keys, twice)
+    const uint64_t max_g = vbits >= 64 ? 1 : std::min<uint64_t>((uint64_t)1 << std::min<uint32_t>(64 - vbits, 16), 65535);
+    const size_t row = (size_t)m * (sigbits / 8);
+    for (uint64_t g0 = 0; g0 < n_genomes;) {
+        uint64_t ng = 0, T = 0;
+        std::vector<uint64_t> base;
+        while (g0 + ng < n_genomes && ng < max_g && (ng == 0 || T + hk[g0 + ng] <= max_items)) { base.push_back(T); T += hk[g0 + ng]; ng++; }
+        GS_REQUIRE(T < ((uint64_t)1 << 31), GS_ERR_UNSUPPORTED, "a single genome with more than 2^31 k-mers is not supported by the prob sketcher");
+        DevBuf dbase, q, qprev, sig, sigpass, wmax, qmax, nact;
+        if ((rc = dbase.alloc(8 * ng))) return rc;
+        if ((rc = q.alloc(8 * ng * m))) return rc;
+        if ((rc = qprev.alloc(8 * ng * m))) return rc;
+        if ((rc = sig.alloc(8 * ng * m))) return rc;
+        if ((rc = sigpass.alloc(8 * ng * m))) return rc;
+        if ((rc = wmax.alloc(4 * ng))) return rc;
+        if ((rc = qmax.alloc(8 * ng))) return rc;
+        if ((rc = nact.alloc(64))) return rc;
+        GS_HIP_CHECK(hipMemcpyAsync(dbase.p, base.data(), 8 * ng, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_prob_init, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), ng * (uint64_t)m);
+        GS_HIP_CHECK(hipMemsetAsync(wmax.p, 0, 4 * ng, c->stream));
+        {   // qmax = +inf
+            std::vector<double> inf(ng, INFINITY);
+            GS_HIP_CHECK(hipMemcpyAsync(qmax.p, inf.data(), 8 * ng, hipMemcpyHostToDevice, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        if (T > 0) {
+            DevBuf vals, sorted, ukey, ucnt, nruns, tmp, candh, candb;
+            if ((rc = vals.alloc(8 * T))) return rc;
+            if ((rc = sorted.alloc(8 * T))) return rc;
+            const uint64_t avg_units = (aa ? seq_bytes / 32 : seq_bytes / 8) / n_genomes + 1;
+            uint32_t parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(avg_units / SK_THREADS + 1, (4 * (uint64_t)c->n_cu + ng - 1) / ng));
+            {
+                ProfScope ps(c, FAM_SKETCH);
+                dim3 grid(parts, (uint32_t)ng), block(SK_THREADS);
+                if (aa) hipLaunchKernelGGL(k_emit_values<true>, grid, block, 0, c->stream, seq, rec_start, rec_len, upre.as<uint64_t>(), kpre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), dbase.as<uint64_t>(), g0, k, vbits, vals.as<uint64_t>());
+                else hipLaunchKernelGGL(k_emit_values<false>, grid, block, 0, c->stream, seq, rec_start, rec_len, upre.as<uint64_t>(), kpre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), dbase.as<uint64_t>(), g0, k, vbits, vals.as<uint64_t>());
+                GS_HIP_CHECK(hipGetLastError());
+            }
+            int endbit = 64;
+            if (vbits < 64) { endbit = (int)vbits; uint64_t x = ng - 1; while (x) { endbit++; x >>= 1; } if (endbit > 64) endbit = 64; }
+            size_t tb = 0;
+            GS_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, vals.as<uint64_t>(), sorted.as<uint64_t>(), (int)T, 0, endbit, c->stream));
+            if ((rc = tmp.alloc(tb))) return rc;
+            GS_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, vals.as<uint64_t>(), sorted.as<uint64_t>(), (int)T, 0, endbit, c->stream));
+            // distinct elements + multiplicities (re-use `vals` for the unique keys)
+            if ((rc = ucnt.alloc(4 * T))) return rc;
+            if ((rc = nruns.alloc(64))) return rc;
+            size_t tb2 = 0;
+            GS_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, sorted.as<uint64_t>(), vals.as<uint64_t>(), ucnt.as<uint32_t>(), nruns.as<uint32_t>(), (int)T, c->stream));
+            if (tb2 > tb) { if ((rc = tmp.alloc(tb2))) return rc; }
+            GS_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb2, sorted.as<uint64_t>(), vals.as<uint64_t>(), ucnt.as<uint32_t>(), nruns.as<uint32_t>(), (int)T, c->stream));
+            uint32_t ne32 = 0;
+            GS_HIP_CHECK(hipMemcpyAsync(&ne32, nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            const uint64_t ne = ne32;
+            sorted.release();
+            if ((rc = candh.alloc(8 * ne))) return rc;
+            if ((rc = candb.alloc(4 * ne))) return rc;
+            const uint32_t eg = (uint32_t)std::min<uint64_t>((ne + 255) / 256, (uint64_t)c->n_cu * 16);
+            hipLaunchKernelGGL(k_prob_wmax, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ucnt.as<uint32_t>(), ne, vbits, wmax.as<uint32_t>());
+            const uint32_t ACT_CAP = 1u << 24;                       // 16 M live elements keep their generator state (0.5 GB)
+            DevBuf akey, acnt, astate, nlist;
+            uint32_t n_list = 0; bool use_list = false;
+            for (uint32_t it = 1;; it++) {
+                GS_HIP_CHECK(hipMemsetAsync(nact.p, 0, 4, c->stream));
+                if (!use_list) {
+                    hipLaunchKernelGGL(k_prob_point, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ucnt.as<uint32_t>(), ne, vbits, m, zone, pc, it, qmax.as<double>(),
+                                       q.as<uint64_t>(), candh.as<uint64_t>(), candb.as<uint32_t>());
+                    hipLaunchKernelGGL(k_prob_claim, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ne, vbits, m, q.as<uint64_t>(), candh.as<uint64_t>(), candb.as<uint32_t>(), sigpass.as<uint64_t>());
+                } else {
+                    const uint32_t lg = std::max<uint32_t>(1, std::min<uint32_t>((n_list + 255) / 256, (uint32_t)c->n_cu * 16));
+                    hipLaunchKernelGGL(k_prob_point_list, dim3(lg), dim3(256), 0, c->stream, akey.as<uint64_t>(), acnt.as<uint32_t>(), n_list, ACT_CAP, vbits, m, zone, pc, it,
+                                       qmax.as<double>(), q.as<uint64_t>(), astate.as<uint64_t>(), candh.as<uint64_t>(), candb.as<uint32_t>());
+                    hipLaunchKernelGGL(k_prob_claim, dim3(lg), dim3(256), 0, c->stream, akey.as<uint64_t>(), (uint64_t)n_list, vbits, m, q.as<uint64_t>(), candh.as<uint64_t>(), candb.as<uint32_t>(), sigpass.as<uint64_t>());
+                }
+                hipLaunchKernelGGL(k_prob_fold, dim3((uint32_t)ng), dim3(256), 0, c->stream, m, it, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(),
+                                   wmax.as<uint32_t>(), qmax.as<double>(), nact.as<uint32_t>());
+                GS_HIP_CHECK(hipGetLastError());
+                uint32_t na = 0;
+                GS_HIP_CHECK(hipMemcpyAsync(&na, nact.p, 4, hipMemcpyDeviceToHost, c->stream));
+                GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+                if (na == 0) break;
+                if (it == 1) {      // survivors of pass 1 -> compact list with generator state (falls back to replay when it overflows)
+                    if ((rc = nlist.alloc(64))) return rc;
+                    if ((rc = akey.alloc(8 * (size_t)ACT_CAP))) return rc;
+                    if ((rc = acnt.alloc(4 * (size_t)ACT_CAP))) return rc;
+                    if ((rc = astate.alloc(32 * (size_t)ACT_CAP))) return rc;
+                    GS_HIP_CHECK(hipMemsetAsync(nlist.p, 0, 4, c->stream));
+                    hipLaunchKernelGGL(k_prob_compact, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ucnt.as<uint32_t>(), ne, vbits, m, zone, pc, qmax.as<double>(), ACT_CAP,
+                                       nlist.as<uint32_t>(), akey.as<uint64_t>(), acnt.as<uint32_t>(), astate.as<uint64_t>());
+                    GS_HIP_CHECK(hipGetLastError());
+                    GS_HIP_CHECK(hipMemcpyAsync(&n_list, nlist.p, 4, hipMemcpyDeviceToHost, c->stream));
+                    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+                    use_list = n_list <= ACT_CAP;
+                }
+            }
+        }
+        uint8_t *dst = (uint8_t *)sig_out + row * g0;
+        if (sigbits == 32) hipLaunchKernelGGL(k_prob_write<uint32_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint32_t *)dst);
+        else hipLaunchKernelGGL(k_prob_write<uint64_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint64_t *)dst);
+        GS_HIP_CHECK(hipGetLastError());
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        g0 += ng;
+    }
+    return GS_OK;
+}
+
 // everything on the device; scratch owned by the call (freed after the stream drains)
 static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint64_t seq_bytes, const uint64_t *rec_start,
                            const uint64_t *rec_len, uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out)
@@ -445,7 +764,13 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         return GS_OK;
     }
-    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "sketch algo %u is not implemented on the device yet", p->algo);
+    if (p->algo == GS_ALGO_PROB3A) {
+        rc = run_prob(c, p, (const uint8_t *)seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off, n_genomes, sig_out);
+        if (rc) return rc;
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return GS_OK;
+    }
+    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "sketch algo %u is not implemented on the device", p->algo);
 }
 
 }  // namespace gs

@@ -235,3 +235,27 @@ def test_dense_and_gather_modes_are_identical(gpu_ctx, mode, monkeypatch):
     ids, dist, cnt, ev = hn.search_arrays(q, 10, 100)
     oids, odist, ocnt, oev = oix.parallel_search(q, 10, 100)
     assert np.array_equal(ids, oids) and np.array_equal(dist, odist) and np.array_equal(ev, oev)
+
+
+@pytest.mark.parametrize("k,m,data", [(21, 2000, "dna"), (16, 1024, "dna"), (12, 300, "dna"), (32, 500, "dna"), (7, 800, "aa"), (5, 256, "aa")])
+def test_sketch_prob_matches_oracle(gpu_ctx, k, m, data):
+    """ProbMinHash3a: weighted multiset sketch — repeats matter"""
+    import gsearch_amd as G
+    rng = np.random.default_rng(k + m)
+    if data == "dna":
+        fam = H.family(rng, 60000, [0.01, 0.05])
+        rep = H.dna_ascii(fam[0])[:300] * 60                     # a heavy repeat: multiplicities up to 60
+        genomes = [[H.dna_ascii(g)] for g in fam]
+        genomes.append([H.dna_ascii(fam[0])[:30000] + rep, b"ACGTNN", H.dna_ascii(fam[1])[1000:40000], rep])
+        genomes.append([b"A" * 500])                             # a single distinct k-mer with weight 480
+        genomes.append([H.dna_ascii(H.rand_dna(rng, 60))])       # a handful of k-mers: many passes
+        genomes.append([b"ACG"])                                 # nothing
+    else:
+        fam = H.family(rng, 40000, [0.02], alphabet=20)
+        rep = H.aa_ascii(fam[0])[:100] * 30
+        genomes = [[H.aa_ascii(g)] for g in fam] + [[H.aa_ascii(fam[0])[:9000] + rep + b"*", rep], [b"MKV"], [H.aa_ascii(rng.integers(0, 20, 40))]]
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "prob", data))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(k, m, "prob", genomes, data)
+    assert got.dtype == ref.dtype
+    assert np.array_equal(got, ref)
