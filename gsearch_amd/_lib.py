@@ -67,6 +67,7 @@ SYMBOLS = {
     "gs_index_create": (_i, [_vp, C.POINTER(IndexParams), C.POINTER(_vp)]),
     "gs_index_destroy": (None, [_vp]),
     "gs_index_nb_point": (_u64, [_vp]),
+    "gs_index_get_params": (_i, [_vp, C.POINTER(IndexParams)]),
     "gs_index_parallel_insert": (_i, [_vp, _vp, _u64]),
     "gs_index_parallel_insert_dev": (_i, [_vp, _vp, _u64]),
     "gs_index_parallel_search": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),

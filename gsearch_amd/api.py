@@ -407,5 +407,22 @@ class Hnsw:
         check(self.ctx.L.gs_index_get_data(self.h, first, n, _p(out)))
         return out
 
+    def file_dump(self, path):
+        """Hnsw::file_dump counterpart (own format, dumpload.rs:31)"""
+        check(self.ctx.L.gs_index_save(self.h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path, ctx=None):
+        """HnswIo::load_hnsw counterpart (reloadhnsw.rs:41-51)"""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(ctx.L.gs_index_load(ctx.h, str(path).encode(), C.byref(h)))
+        self = cls.__new__(cls)
+        self.ctx, self.h = ctx, h
+        self.prm = IndexParams()
+        check(ctx.L.gs_index_get_params(h, C.byref(self.prm)))
+        self.dtype = KIND_DTYPE[self.prm.kind]
+        return self
+
     def insert_evals(self):
         return 0 if self.h is None else self.ctx.L.gs_index_insert_evals(self.h)

@@ -764,6 +764,12 @@ void gs_index_destroy(gs_index *ix)
 }
 uint64_t gs_index_nb_point(const gs_index *ix) { return ix ? ix->n : 0; }
 uint64_t gs_index_insert_evals(const gs_index *ix) { return ix ? ix->insert_evals : 0; }
+int gs_index_get_params(const gs_index *ix, gs_index_params *out)
+{
+    GS_REQUIRE(ix && out, GS_ERR_INVALID, "null argument");
+    *out = ix->prm;
+    return GS_OK;
+}
 
 int gs_index_import(gs_index *ix, const void *sigs, uint64_t n, const uint8_t *levels, int64_t entry, const uint32_t *deg0,
                     const uint32_t *nbr0, const uint32_t *cnt0, const int32_t *upidx, uint64_t n_upper, const uint32_t *degU,
@@ -1074,15 +1080,67 @@ int gs_index_bruteforce_search(gs_index *ix, const void *queries, uint64_t nq, u
     return GS_OK;
 }
 
+/* own binary dump (role of Hnsw::file_dump / HnswIo::load_hnsw, dumpload.rs:31, reloadhnsw.rs:41-51):
+ *   "GSAMDIX1" | gs_index_params | n, n_upper, entry, top (u64,u64,i64,i64) | signatures (dense rows) | levels | deg0 | nbr0 | cnt0 |
+ *   upidx | degU | nbrU | cntU   (the export layout of gs_index_export) */
 int gs_index_save(gs_index *ix, const char *path)
 {
     GS_REQUIRE(ix && path, GS_ERR_INVALID, "null argument");
-    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "gs_index_save not implemented yet");
+    GS_REQUIRE(ix->n > 0, GS_ERR_STATE, "nothing to save");
+    FILE *f = fopen(path, "wb");
+    GS_REQUIRE(f, GS_ERR_IO, "cannot open %s for writing", path);
+    const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
+    const uint64_t n = ix->n, U = ix->n_upper;
+    int rc = GS_OK;
+    const char magic[8] = {'G', 'S', 'A', 'M', 'D', 'I', 'X', '1'};
+    uint64_t hdr[4] = {n, U, (uint64_t)ix->entry, (uint64_t)(int64_t)ix->top};
+    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&ix->prm, sizeof(ix->prm), 1, f) == 1 && fwrite(hdr, 8, 4, f) == 4;
+    const uint64_t CH = 4096;
+    std::vector<uint8_t> buf(ix->rowbytes * CH);
+    for (uint64_t r0 = 0; ok && r0 < n; r0 += CH) {
+        const uint64_t nr = std::min(CH, n - r0);
+        if ((rc = gs_index_get_data(ix, r0, nr, buf.data()))) break;
+        ok = fwrite(buf.data(), ix->rowbytes, nr, f) == nr;
+    }
+    if (ok && rc == GS_OK) {
+        std::vector<uint8_t> lv(n); std::vector<uint32_t> d0(n), n0(n * 2 * M), c0(n * 2 * M); std::vector<int32_t> up(n);
+        std::vector<uint32_t> dU(std::max<uint64_t>(U, 1) * ML), nU(std::max<uint64_t>(U, 1) * ML * M), cU(std::max<uint64_t>(U, 1) * ML * M);
+        rc = gs_index_export(ix, lv.data(), nullptr, d0.data(), n0.data(), c0.data(), up.data(), nullptr, dU.data(), nU.data(), cU.data());
+        if (rc == GS_OK)
+            ok = fwrite(lv.data(), 1, n, f) == n && fwrite(d0.data(), 4, n, f) == n && fwrite(n0.data(), 4, n * 2 * M, f) == n * 2 * M &&
+                 fwrite(c0.data(), 4, n * 2 * M, f) == n * 2 * M && fwrite(up.data(), 4, n, f) == n && fwrite(dU.data(), 4, U * ML, f) == U * ML &&
+                 fwrite(nU.data(), 4, U * ML * M, f) == U * ML * M && fwrite(cU.data(), 4, U * ML * M, f) == U * ML * M;
+    }
+    fclose(f);
+    if (rc) return rc;
+    GS_REQUIRE(ok, GS_ERR_IO, "short write to %s", path);
+    return GS_OK;
 }
 int gs_index_load(gs_ctx *c, const char *path, gs_index **out)
 {
     GS_REQUIRE(c && path && out, GS_ERR_INVALID, "null argument");
-    GS_REQUIRE(false, GS_ERR_UNSUPPORTED, "gs_index_load not implemented yet");
+    FILE *f = fopen(path, "rb");
+    GS_REQUIRE(f, GS_ERR_IO, "cannot open %s", path);
+    char magic[8]; gs_index_params prm; uint64_t hdr[4];
+    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GSAMDIX1", 8) && fread(&prm, sizeof(prm), 1, f) == 1 && fread(hdr, 8, 4, f) == 4;
+    if (!ok) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s is not a gsearch_amd index dump", path); }
+    const uint64_t n = hdr[0], U = hdr[1];
+    const uint32_t M = prm.max_nb_conn, ML = prm.max_layer;
+    const size_t rowbytes = gs::kind_bytes(prm.kind) * (size_t)prm.m;
+    std::vector<uint8_t> sigs(rowbytes * n), lv(n); std::vector<uint32_t> d0(n), n0(n * 2 * M), c0(n * 2 * M); std::vector<int32_t> up(n);
+    std::vector<uint32_t> dU(std::max<uint64_t>(U, 1) * ML), nU(std::max<uint64_t>(U, 1) * ML * M), cU(std::max<uint64_t>(U, 1) * ML * M);
+    ok = fread(sigs.data(), rowbytes, n, f) == n && fread(lv.data(), 1, n, f) == n && fread(d0.data(), 4, n, f) == n &&
+         fread(n0.data(), 4, n * 2 * M, f) == n * 2 * M && fread(c0.data(), 4, n * 2 * M, f) == n * 2 * M && fread(up.data(), 4, n, f) == n &&
+         fread(dU.data(), 4, U * ML, f) == U * ML && fread(nU.data(), 4, U * ML * M, f) == U * ML * M && fread(cU.data(), 4, U * ML * M, f) == U * ML * M;
+    fclose(f);
+    GS_REQUIRE(ok, GS_ERR_IO, "%s is truncated", path);
+    gs_index *ix = nullptr;
+    int rc = gs_index_create(c, &prm, &ix);
+    if (rc) return rc;
+    rc = gs_index_import(ix, sigs.data(), n, lv.data(), (int64_t)hdr[2], d0.data(), n0.data(), c0.data(), up.data(), U, dU.data(), nU.data(), cU.data());
+    if (rc) { gs_index_destroy(ix); return rc; }
+    *out = ix;
+    return GS_OK;
 }
 
 }  // extern "C"

@@ -129,6 +129,7 @@ typedef struct {
 int      gs_index_create(gs_ctx *, const gs_index_params *, gs_index **out);
 void     gs_index_destroy(gs_index *);
 uint64_t gs_index_nb_point(const gs_index *);
+int      gs_index_get_params(const gs_index *, gs_index_params *out);
 /* parallel_insert(&[(&Vec<Sig>, usize)]): ids are assigned nb_point.. in input order (dnasketch.rs:429-433) */
 int      gs_index_parallel_insert(gs_index *, const void *sigs, uint64_t n);
 int      gs_index_parallel_insert_dev(gs_index *, const void *sigs_dev, uint64_t n);

@@ -259,3 +259,27 @@ def test_sketch_prob_matches_oracle(gpu_ctx, k, m, data):
     ref = _oracle_sketch(k, m, "prob", genomes, data)
     assert got.dtype == ref.dtype
     assert np.array_equal(got, ref)
+
+
+def test_index_dump_and_reload(gpu_ctx, tmp_path):
+    """file_dump / load round trip (own format): identical graph, data and answers; `add` continues on the reloaded index"""
+    import gsearch_amd as G
+    db = H.synth_sig_db(12, 25, 200, 41, dtype=np.uint64, jlo=0.05, jhi=0.95)
+    hn = G.Hnsw.new(8, 10000, 16, 40, G.DistHamming(), dtype=np.uint64, seed=3, insert_batch=16)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db[:200])
+    path = tmp_path / "hnswdump.gsamd"
+    hn.file_dump(path)
+    h2 = G.Hnsw.load(path)
+    assert h2.get_nb_point() == 200
+    g1, g2 = hn.export_graph(), h2.export_graph()
+    for key in ("levels", "deg0", "upidx"):
+        assert np.array_equal(g1[key], g2[key])
+    assert np.array_equal(hn.get_data(), h2.get_data())
+    q = H.queries_from(db, 20, 3)
+    a, b = hn.search_arrays(q, 5, 40), h2.search_arrays(q, 5, 40)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    hn.parallel_insert(db[200:])
+    h2.parallel_insert(db[200:])
+    a, b = hn.search_arrays(q, 5, 40), h2.search_arrays(q, 5, 40)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
