@@ -1,4 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) must equal the CPU oracle bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -283,3 +285,37 @@ def test_index_dump_and_reload(gpu_ctx, tmp_path):
     h2.parallel_insert(db[200:])
     a, b = hn.search_arrays(q, 5, 40), h2.search_arrays(q, 5, 40)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_cpp_host_mirror(gpu_ctx, tmp_path):
+    """the C++ mirror of the reference's call sequence (include/gsearch_amd.hpp, tohnsw + request) gives the Python path's answers"""
+    import subprocess
+    import gsearch_amd as G
+    rng = np.random.default_rng(77)
+    roots = [H.rand_dna(rng, 30000) for _ in range(4)]
+    db = [H.dna_ascii(H.mutate(rng, roots[i % 4], 0.01 * (1 + i // 4))) for i in range(24)]
+    qs = [H.dna_ascii(H.mutate(rng, roots[i], 0.02)) for i in range(4)]
+    for name, seqs in (("db.fa", db), ("q.fa", qs)):
+        with open(tmp_path / name, "w") as f:
+            for i, s in enumerate(seqs):
+                f.write(">g%d\n" % i)
+                for o in range(0, len(s), 80):
+                    f.write(s[o:o + 80].decode() + "\n")
+    exe = os.path.join(os.path.dirname(G.SO_PATH), "tohnsw_request_demo")
+    k, s, M, efc, ef, knbn = 21, 2000, 8, 32, 64, 5
+    out = subprocess.run([exe, str(tmp_path / "db.fa"), str(tmp_path / "q.fa")] + [str(x) for x in (k, s, M, efc, ef, knbn)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    # python path
+    sk = G.OptDensHashSketch.new(G.SeqSketcherParams(k, s, "optdens"))
+    hn = G.Hnsw.new(M, 1500000, 16, efc, G.DistHamming(), seed=1)
+    hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+    hn.parallel_insert(sk.sketch_genomes([[g] for g in db]))
+    res = hn.parallel_search(sk.sketch_genomes([[q] for q in qs]), knbn, ef)
+    want = []
+    for i, r in enumerate(res):
+        for nb in r:
+            if nb.distance < 0.99:
+                want.append(("g%d" % nb.d_id, "%.5E" % nb.distance))
+    got = [(ln.split("\t")[6].strip(), ln.split("\t")[3]) for ln in out.stdout.splitlines() if ln.startswith("query_id:")]
+    assert got == want and len(got) >= 8
