@@ -26,6 +26,12 @@ DTYPE_KIND = {v: k for k, v in KIND_DTYPE.items()}
 
 Neighbour = namedtuple("Neighbour", ["d_id", "distance"])   # hnsw_rs::Neighbour fields gsearch reads (answer.rs:42,55-57)
 
+# At interpreter exit the HIP runtime may already be torn down when Python finalises leftover objects: destroying device
+# objects then would call into a dead runtime. After this flag is set __del__ becomes a no-op (the OS reclaims everything).
+_exiting = [False]
+import atexit  # noqa: E402
+atexit.register(lambda: _exiting.__setitem__(0, True))
+
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
@@ -47,7 +53,8 @@ class Context:
 
     def __del__(self):
         try:
-            self.close()
+            if not _exiting[0]:
+                self.close()
         except Exception:
             pass
 
@@ -332,7 +339,8 @@ class Hnsw:
 
     def __del__(self):
         try:
-            self.close()
+            if not _exiting[0]:
+                self.close()
         except Exception:
             pass
 

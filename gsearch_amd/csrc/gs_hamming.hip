@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
     constexpr int EW = ElemCmp<KIND>::EW;
     __shared__ uint32_t sq[2][HT * HP];
     __shared__ uint32_t sc[2][HT * HP];
-    const uint64_t q0 = (uint64_t)blockIdx.y * HT, c0 = (uint64_t)blockIdx.x * HT;
+    // query tiles on the FAST grid dimension: blocks that share a candidate tile are dispatched together, so the candidate rows
+    // come from HBM once and from L2 / Infinity Cache for the other query tiles
+    const uint64_t q0 = (uint64_t)blockIdx.x * HT, c0 = (uint64_t)blockIdx.y * HT;
     const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const uint64_t roww = (uint64_t)m * EW;          // words per row
     uint32_t cnt[8][8];
@@ -177,8 +179,8 @@ int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t
     GS_REQUIRE(Q && C && (out || out_cnt || out_cnt16), GS_ERR_INVALID, "null argument");
     GS_REQUIRE(!out_cnt16 || m <= 65535, GS_ERR_INVALID, "16-bit counts need m <= 65535");
     if (ld_out == 0) ld_out = nc;
-    dim3 grid((uint32_t)((nc + HT - 1) / HT), (uint32_t)((nq + HT - 1) / HT)), block(256);
-    GS_REQUIRE(grid.y <= 65535, GS_ERR_INVALID, "too many query rows for one call (max %d)", 65535 * HT);
+    dim3 grid((uint32_t)((nq + HT - 1) / HT), (uint32_t)((nc + HT - 1) / HT)), block(256);
+    GS_REQUIRE(grid.y <= 65535, GS_ERR_INVALID, "too many candidate rows for one call (max %d)", 65535 * HT);
     ProfScope ps(c, FAM_HAMMING);
     const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
     const bool vec4 = (strideQ_bytes % 16 == 0) && (strideC_bytes % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)C % 16 == 0);

@@ -164,8 +164,11 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t capC = 2 * ef + maxdeg + 64;
     uint32_t nR = 1, nC = 1, headC = 0;
-    if (threadIdx.x == 0) { S.R[0] = KEY(ep_cnt, ep); S.C[0] = KEY(ep_cnt, ep); atomicOr(&vis[ep >> 5], 1u << (ep & 31)); }
+    if (threadIdx.x == 0) { S.R[0] = KEY(ep_cnt, ep); S.C[0] = KEY(ep_cnt, ep); __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __syncthreads();
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // software prefetch of the NEXT candidate's adjacency (valid unless this expansion inserts a closer candidate)
+    uint64_t pre_c = ~(uint64_t)0; uint32_t pre_id = 0, pre_deg = 0;
     for (;;) {
         if (headC >= nC) break;
         const uint64_t c = S.C[headC];
@@ -173,51 +176,59 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
         if (KCNT(c) > dmax) break;
         headC++;
         // ---- gather unvisited neighbours of c, in stored order
-        const uint32_t *nbr; uint32_t deg;
-        node_neighbours(ix, KID(c), L, nbr, deg);
-        uint32_t id = 0; bool unv = false;
+        uint32_t id, deg;
+        if (pre_c == c) { id = pre_id; deg = pre_deg; }
+        else {
+            const uint32_t *nbr;
+            node_neighbours(ix, KID(c), L, nbr, deg);
+            id = threadIdx.x < maxdeg ? nbr[threadIdx.x] : 0;      // lists are allocated to full width: in-bounds past deg
+        }
+        bool unv = false; uint32_t cntv = 0;
         if (threadIdx.x < deg) {
-            id = nbr[threadIdx.x];
-            uint32_t bit = 1u << (id & 31);
-            uint32_t old = atomicOr(&vis[id >> 5], bit);
+            const uint32_t bit = 1u << (id & 31);
+            if (matrow) cntv = matrow[id];                           // dense mode: the lookup overlaps the visited test
+            // the bitmap is private to this workgroup: workgroup scope keeps the RMW in the XCD's L2 (device scope went to memory:
+            // rocprof WRITE_SIZE showed ~146 B of HBM writes per evaluation)
+            const uint32_t old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             unv = !(old & bit);
         }
+        if (headC < nC) {                                            // issue the next candidate's adjacency loads now
+            pre_c = S.C[headC];
+            const uint32_t *nbr2;
+            node_neighbours(ix, KID(pre_c), L, nbr2, pre_deg);
+            pre_id = threadIdx.x < maxdeg ? nbr2[threadIdx.x] : 0;
+        } else pre_c = ~(uint64_t)0;
         const uint64_t bal = __ballot(unv);
-        const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
         if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t off = 0, ne = 0;
 #pragma unroll
         for (int w = 0; w < ST / 64; w++) { uint32_t x = S.wsum[w]; if (w < (int)wv) off += x; ne += x; }
-        if (unv) S.Eid[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = id;
+        if (unv) { const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1)); S.Eid[pos] = id; if (matrow) S.Ecnt[pos] = cntv; }
         __syncthreads();
         if (ne == 0) continue;
         evals += ne;
-        // ---- all distances of this expansion (HBM-bound part)
-        block_distances<KIND>(ix, q, S.Eid, ne, S.Ecnt, matrow);
+        // ---- all distances of this expansion (gather mode: the HBM-bound part)
+        if (!matrow) block_distances<KIND>(ix, q, S.Eid, ne, S.Ecnt);
         // ---- closed form of the sequential accept rule (DESIGN.md "accept rule"):
         //      e_i accepted  <=>  #{x in R : c(x) <= c_i} + #{j < i : c_j <= c_i}  <  ef
         uint64_t mykey = ~(uint64_t)0; bool acc = false;
         if (threadIdx.x < ne) {
             const uint32_t ci = S.Ecnt[threadIdx.x];
-            uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu) );          // keys < (ci,max) ; ids never reach 2^32-1
-            for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
+            uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu));           // keys < (ci,max) ; ids never reach 2^32-1
+            if (le < ef) for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
             acc = le < ef;
             if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
         }
+        const uint32_t na = (uint32_t)__syncthreads_count(acc);       // (also orders the reads above before the next writes)
+        if (na == 0) continue;
         if (threadIdx.x < maxdeg) S.A[threadIdx.x] = mykey;          // unsorted staging (~0 = rejected)
-        const uint64_t abal = __ballot(acc);
-        if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(abal);
         __syncthreads();
-        uint32_t na = 0;
-#pragma unroll
-        for (int w = 0; w < ST / 64; w++) na += S.wsum[w];
         uint32_t rank = 0;
         if (acc) for (uint32_t j = 0; j < ne; j++) rank += (S.A[j] < mykey);
         __syncthreads();
         if (acc) S.A[rank] = mykey;                                  // sorted ascending, dense in [0,na)
         __syncthreads();
-        if (na == 0) continue;
         // ---- R <- ef smallest of R u A ; C <- live C u A ; drop dead tail of C
         nR = block_merge(S.R, 0, nR, S.A, na, ef);
         nC = block_merge(S.C, headC, nC, S.A, na, capC);
