@@ -311,6 +311,14 @@ def run_request(args, torch, rank, world, local):
                                    ("dense mode traversal: counts are looked up in the tile kernel's matrix, the 72 kB/evaluation figure is nominal" if tile_n
                                     else "gather mode: one 72 kB row streamed from HBM per evaluation")}
         out["kernels"] = kernels
+        # physical HBM traffic per launch from the committed rocprofv3 PMC summary of this same workload (separate --pmc passes)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom["kernel"])
+            if pmc and N == 300000 and qps == 2500 and m == 18000:
+                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+        except Exception:
+            pass
         # ---- parity / recall / CPU baseline on a bounded sample of the last step's queries
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
