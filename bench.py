@@ -345,13 +345,14 @@ def run_request(args, torch, rank, world, local):
         oids, odist, ocnt, oev = oix.parallel_search(qsig, knbn, ef, nthreads=min(cores, ns))
         cpu_search_s = time.perf_counter() - t0
         ids_ok = bool(np.array_equal(oids, ids_g)) and bool(np.array_equal(odist.view(np.uint32), dist_g.view(np.uint32)))
+        evals_ok = bool(np.array_equal(oev, ev_t.cpu().numpy().view(np.uint64)[:ns]))
         # (c) recall@knbn against exhaustive search (tie-aware: a neighbour counts if it is within the k-th exact distance)
         nb = min(ns, 32)
         bi, bd = hn.bruteforce_search(qsig[:nb], knbn)
         rec_gpu = float(np.mean([(dist_g[i] <= bd[i, -1]).mean() for i in range(nb)]))
         rec_cpu = float(np.mean([(odist[i] <= bd[i, -1]).mean() for i in range(nb)]))
         ani_err = float(max(abs(G.ani(float(d), k) - O.ani(float(d), k)) for d in dist_g[0][: min(knbn, 8)]))
-        out["parity_checked"] = {"queries": ns, "sketch_bit_exact_vs_oracle": sketch_ok, "neighbour_ids_and_distances_equal_oracle": ids_ok,
+        out["parity_checked"] = {"queries": ns, "sketch_bit_exact_vs_oracle": sketch_ok, "neighbour_ids_and_distances_equal_oracle": ids_ok, "dist_evaluation_counts_equal_oracle": evals_ok,
                                  "max_ani_abs_err": ani_err}
         out["recall_at_%d" % knbn] = {"gpu": rec_gpu, "cpu_oracle": rec_cpu, "queries": nb, "reference": "exhaustive DistHamming top-k, tie-aware"}
         out["cpu_baseline"] = {"value": ns / (cpu_sketch_s + cpu_search_s), "unit": "genomes/s", "cores": min(cores, ns), "kind": "port",

@@ -266,6 +266,206 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
     }
 }
 
+// ======================================================================================================
+// Dense-mode traversal: all counts of the query against every node are in `matrow`, so an iteration is pure
+// latency (adjacency load, visited test, lookup). To overlap that latency the kernel runs THREE 512-lane workgroups per CU:
+// R stays in LDS (8 ef bytes), the candidate array C lives in global memory (ping-pong buffers, read through a 64-key LDS
+// window; it is only rewritten when an expansion accepts something — rare once R is saturated by ties).
+// Semantics identical to search_layer_block (same closed-form accept rule, same merges, same pruning of dead candidates).
+// ======================================================================================================
+constexpr int DT = 512;           // lanes per dense-mode workgroup
+constexpr int DWIN = 64;          // keys of C mirrored in LDS
+constexpr int DMAXI = 16;         // staged R keys per lane in a merge (ef <= DMAXI*DT)
+struct DenseLds { uint64_t *R, *A, *W; uint32_t *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
+__host__ __device__ inline size_t dense_lds_bytes(uint32_t ef, uint32_t maxdeg)
+{
+    return 8 * (size_t)ef + 8 * (size_t)maxdeg + 8 * DWIN + 4 * (size_t)maxdeg * 2 + 4 * ((size_t)maxdeg + 8) + 4 * (DT / 64) + 64 + 64;
+}
+__device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t ef, uint32_t maxdeg)
+{
+    DenseLds S;
+    S.R = (uint64_t *)base; base += 8 * (size_t)ef;
+    S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
+    S.W = (uint64_t *)base; base += 8 * DWIN;
+    S.scal = (uint64_t *)base; base += 64;
+    S.Eid = (uint32_t *)base; base += 4 * (size_t)maxdeg;
+    S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
+    S.hist = (uint32_t *)base; base += 4 * ((size_t)maxdeg + 8);
+    S.wsum = (uint32_t *)base;
+    return S;
+}
+// in-LDS merge of sorted A into sorted R[0..n) keeping `keep` keys (DT lanes)
+__device__ __forceinline__ uint32_t dense_merge_R(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep)
+{
+    uint64_t kv[DMAXI]; uint32_t pos[DMAXI];
+#pragma unroll
+    for (int it = 0; it < DMAXI; it++) {
+        const uint32_t idx = threadIdx.x + it * DT;
+        pos[it] = 0xFFFFFFFFu; kv[it] = 0;
+        if (idx < n) { const uint64_t k = keys[idx]; kv[it] = k; pos[it] = idx + lower_bound_keys(A, na, k); }
+    }
+    uint64_t ak = 0; uint32_t apos = 0xFFFFFFFFu;
+    if (threadIdx.x < na) { ak = A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(keys, n, ak); }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < DMAXI; it++) if (pos[it] < keep) keys[pos[it]] = kv[it];
+    if (apos < keep) keys[apos] = ak;
+    __syncthreads();
+    const uint32_t tot = n + na;
+    return tot < keep ? tot : keep;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat,
+                                                           uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ cbuf, uint32_t capC,
+                                                           unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
+                                                           uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    const uint32_t maxdeg = 2 * ix.M;
+    const uint32_t efs = ef > knbn ? ef : knbn;
+    DenseLds S = carve_dense(s_raw, efs, maxdeg);
+    uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
+    uint64_t *Cb[2] = {cbuf + (uint64_t)blockIdx.x * 2 * capC, cbuf + (uint64_t)blockIdx.x * 2 * capC + capC};
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.scal[1] = atomicAdd(counter, 1ull);
+        __syncthreads();
+        const uint64_t qi = S.scal[1];
+        if (qi >= nq) break;
+        const uint16_t *matrow = mat + qi * ix.n;
+        for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
+        uint64_t evals = 1;
+        uint32_t ep = (uint32_t)ix.entry, ep_cnt = matrow[ep];
+        // greedy descent on the upper layers (hnsw_rs::search outer loop)
+        for (int L = ix.top; L >= 1; L--) {
+            for (;;) {
+                const uint32_t *nbr; uint32_t deg;
+                node_neighbours(ix, ep, L, nbr, deg);
+                if (deg == 0) break;
+                if (threadIdx.x == 0) S.scal[0] = ~(uint64_t)0;
+                __syncthreads();
+                evals += deg;
+                if (threadIdx.x < deg) { const uint32_t c = matrow[nbr[threadIdx.x]]; if (c < ep_cnt) atomicMin((unsigned long long *)&S.scal[0], (unsigned long long)KEY(c, threadIdx.x)); }
+                __syncthreads();
+                const uint64_t best = S.scal[0];
+                __syncthreads();
+                if (best == ~(uint64_t)0) break;
+                ep = nbr[KID(best)]; ep_cnt = KCNT(best);
+            }
+        }
+        // ---- search_layer on layer 0
+        int cur = 0;
+        uint32_t nR = 1, nC = 1, headC = 0, wbase = 0, wn = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            S.R[0] = KEY(ep_cnt, ep); Cb[0][0] = KEY(ep_cnt, ep);
+            __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        uint64_t pre_c = ~(uint64_t)0; uint32_t pre_id = 0, pre_deg = 0;
+        for (;;) {
+            if (headC >= nC) break;
+            if (headC - wbase >= wn) {                              // refill the LDS window of C
+                __syncthreads();
+                wbase = headC; wn = nC - headC < (uint32_t)DWIN ? nC - headC : (uint32_t)DWIN;
+                if (threadIdx.x < wn) S.W[threadIdx.x] = Cb[cur][headC + threadIdx.x];
+                __syncthreads();
+            }
+            const uint64_t c = S.W[headC - wbase];
+            const uint32_t dmax = (nR == efs) ? KCNT(S.R[efs - 1]) : INF_CNT;
+            if (KCNT(c) > dmax) break;
+            headC++;
+            uint32_t id, deg;
+            if (pre_c == c) { id = pre_id; deg = pre_deg; }
+            else { const uint32_t *nbr = ix.nbr0 + (uint64_t)KID(c) * maxdeg; deg = ix.deg0[KID(c)]; id = threadIdx.x < maxdeg ? nbr[threadIdx.x] : 0; }
+            bool unv = false; uint32_t cntv = 0;
+            if (threadIdx.x < deg) {
+                const uint32_t bit = 1u << (id & 31);
+                cntv = matrow[id];
+                const uint32_t old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unv = !(old & bit);
+            }
+            if (headC < nC && headC - wbase < wn) {                 // prefetch the next candidate's adjacency
+                pre_c = S.W[headC - wbase];
+                pre_deg = ix.deg0[KID(pre_c)];
+                pre_id = threadIdx.x < maxdeg ? ix.nbr0[(uint64_t)KID(pre_c) * maxdeg + threadIdx.x] : 0;
+            } else pre_c = ~(uint64_t)0;
+            const uint64_t bal = __ballot(unv);
+            if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t off = 0, ne = 0;
+#pragma unroll
+            for (int w = 0; w < DT / 64; w++) { const uint32_t x = S.wsum[w]; if (w < (int)wv) off += x; ne += x; }
+            if (unv) { const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1)); S.Eid[pos] = id; S.Ecnt[pos] = cntv; }
+            __syncthreads();
+            if (ne == 0) continue;
+            evals += ne;
+            uint64_t mykey = ~(uint64_t)0; bool acc = false;
+            if (threadIdx.x < ne) {
+                const uint32_t ci = S.Ecnt[threadIdx.x];
+                uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu));
+                if (le < efs) for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
+                acc = le < efs;
+                if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
+            }
+            const uint32_t na = (uint32_t)__syncthreads_count(acc);
+            if (na == 0) continue;
+            if (threadIdx.x < maxdeg) S.A[threadIdx.x] = mykey;
+            __syncthreads();
+            uint32_t rank = 0;
+            if (acc) for (uint32_t j = 0; j < ne; j++) rank += (S.A[j] < mykey);
+            __syncthreads();
+            if (acc) S.A[rank] = mykey;
+            if (threadIdx.x <= na) S.hist[threadIdx.x] = 0;
+            __syncthreads();
+            // R <- ef smallest of R u A
+            nR = dense_merge_R(S.R, nR, S.A, na, efs);
+            const uint32_t dnew = (nR == efs) ? KCNT(S.R[efs - 1]) : INF_CNT;
+            // C <- live C u A into the other buffer; hist[t] = #live C keys whose lower bound in A is t
+            const uint32_t live = nC - headC;
+            uint64_t *src = Cb[cur] + headC, *dst = Cb[cur ^ 1];
+            uint32_t alive_loc = 0;
+            for (uint32_t idx = threadIdx.x; idx < live; idx += DT) {
+                const uint64_t k = src[idx];
+                const uint32_t lb = lower_bound_keys(S.A, na, k);
+                const uint32_t pos = idx + lb;
+                if (pos < capC) dst[pos] = k;
+                atomicAdd(&S.hist[lb], 1u);
+                alive_loc += (KCNT(k) <= dnew);
+            }
+            if (threadIdx.x < na) alive_loc += (KCNT(S.A[threadIdx.x]) <= dnew);
+            __syncthreads();                                        // hist complete before the A positions are derived from it
+            // wave sums of the alive counts
+            uint32_t wsumv = alive_loc;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wsumv += __shfl_down(wsumv, o);
+            if (lane == 0) S.wsum[wv] = wsumv;
+            if (threadIdx.x < na) {
+                uint32_t below = 0;
+                for (uint32_t t = 0; t <= threadIdx.x; t++) below += S.hist[t];
+                const uint32_t pos = threadIdx.x + below;
+                if (pos < capC) dst[pos] = S.A[threadIdx.x];
+            }
+            __syncthreads();
+            uint32_t alive = 0;
+#pragma unroll
+            for (int w = 0; w < DT / 64; w++) alive += S.wsum[w];
+            uint32_t tot = live + na; if (tot > capC) tot = capC;
+            nC = (nR == efs && alive < tot) ? alive : tot;
+            cur ^= 1; headC = 0; wbase = 0; wn = 0; pre_c = ~(uint64_t)0;
+        }
+        __syncthreads();
+        const uint32_t nout = nR < knbn ? nR : knbn;
+        for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
+            if (i < nout) { ids_out[qi * knbn + i] = KID(S.R[i]); dist_out[qi * knbn + i] = (float)KCNT(S.R[i]) / (float)ix.m; }
+            else { ids_out[qi * knbn + i] = ~(uint64_t)0; dist_out[qi * knbn + i] = INFINITY; }
+        }
+        if (threadIdx.x == 0) { if (count_out) count_out[qi] = nout; if (evals_out) evals_out[qi] = evals; }
+    }
+}
+
 __device__ __forceinline__ SearchLds carve_lds(uint8_t *base, uint32_t ef, uint32_t maxdeg)
 {
     SearchLds S;
@@ -566,7 +766,7 @@ struct gs_index {
     uint64_t n = 0, cap = 0; int64_t entry = -1; int top = -1;
     uint64_t n_upper = 0, cap_upper = 0;
     gs::DevBuf data, levels, deg0, nbr0, cnt0, upidx, degU, nbrU, cntU;
-    gs::DevBuf visited, counter;
+    gs::DevBuf visited, counter, cbuf;
     // insert scratch
     gs::DevBuf blevels, cntmat, plan_keys, plan_n, inbox, inbox_cnt, touched, ntouched, evals_dev;
     uint64_t inbox_lists = 0;
@@ -664,12 +864,46 @@ static bool dense_pays(const gs_index *ix, double frac)
     return dense < gather;
 }
 
+static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t *ids, float *dist, uint32_t *count,
+                               uint64_t *evals)
+{
+    gs_ctx *c = ix->ctx;
+    const uint32_t efs = std::max(ef, knbn);
+    const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
+    const size_t lds = dense_lds_bytes(efs, maxdeg);
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024 - 1024) / lds));
+    const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
+    const uint32_t capC = 2 * efs + maxdeg + 64;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu * per_cu);
+    int rc;
+    if ((rc = ix->visited.ensure((size_t)4 * vis_words * c->n_cu * 3))) return rc;
+    if ((rc = ix->cbuf.ensure((size_t)16 * capC * c->n_cu * 3))) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
+    IndexDev d = index_dev(ix);
+    ProfScope ps(c, FAM_SEARCH);
+#define GS_LAUNCH_DSEARCH(K)                                                                                              \
+    do {                                                                                                                  \
+        auto kern = k_hnsw_search_dense<K>;                                                                               \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, ix->visited.as<uint32_t>(), vis_words, \
+                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals);  \
+    } while (0)
+    if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_DSEARCH(GS_KIND_F32);
+    else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_DSEARCH(GS_KIND_U32);
+    else GS_LAUNCH_DSEARCH(GS_KIND_U64);
+#undef GS_LAUNCH_DSEARCH
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
 static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t *ids,
                          float *dist, uint32_t *count, uint64_t *evals)
 {
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
+    if (mat && maxdeg <= (uint32_t)DT && efs <= (uint32_t)(DMAXI * DT) && dense_lds_bytes(efs, maxdeg) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
+        return search_launch_dense(ix, nq, knbn, ef, mat, ids, dist, count, evals);
     const size_t lds = search_lds_bytes(efs, maxdeg);
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu);

@@ -319,3 +319,26 @@ def test_cpp_host_mirror(gpu_ctx, tmp_path):
                 want.append(("g%d" % nb.d_id, "%.5E" % nb.distance))
     got = [(ln.split("\t")[6].strip(), ln.split("\t")[3]) for ln in out.stdout.splitlines() if ln.startswith("query_id:")]
     assert got == want and len(got) >= 5
+
+
+def test_three_evaluation_strategies_agree_with_oracle(gpu_ctx, monkeypatch):
+    """gather / dense (LDS-resident C) / dense (3 workgroups per CU, C in global memory): same ids, distances AND the same
+    number of DistHamming evaluations as the oracle, on a graph with real merges (ef well below the reachable set)."""
+    import gsearch_amd as G
+    db = H.synth_sig_db(60, 50, 256, 77, jlo=0.02, jhi=0.9)
+    oix = O.Index(np.float32, 256, 16, 64, seed=9)
+    oix.parallel_insert(db, batch=64)
+    hn = G.Hnsw.new(16, 100000, 16, 64, G.DistHamming(), seed=9, insert_batch=64)
+    hn.set_extend_candidates(True)
+    hn.import_graph(db, oix.export())
+    q = H.queries_from(db, 300, 5, frac=0.25)
+    want = oix.parallel_search(q, 20, 400)
+    for mode, legacy in (("gather", None), ("dense", "1"), ("dense", None)):
+        monkeypatch.setenv("GS_DIST_MODE", mode)
+        if legacy:
+            monkeypatch.setenv("GS_DENSE_LEGACY", legacy)
+        else:
+            monkeypatch.delenv("GS_DENSE_LEGACY", raising=False)
+        got = hn.search_arrays(q, 20, 400)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), mode
+        assert np.array_equal(got[3], want[3]), (mode, legacy, "evaluation counts")
