@@ -58,6 +58,8 @@ SYMBOLS = {
     "gs_value_bits": (_i, [_PP]),
     "gs_sketch_batch": (_i, [_vp, _PP, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp]),
     "gs_sketch_batch_dev": (_i, [_vp, _PP, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp]),
+    "gs_fasta_scan": (_i, [_vp, _u64, _i, _u64, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "gs_pack_fasta_dev": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp]),
     "gs_pack_dna": (_u64, [_vp, _u64, _vp, _u64]),
     "gs_filter_aa": (_u64, [_vp, _u64, _vp]),
     "gs_hamming_qxc": (_i, [_vp, _i, _u32, _vp, _u64, _vp, _u64, _vp]),

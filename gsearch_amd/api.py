@@ -225,6 +225,62 @@ class _SeqSketcher:
         return self.sketch_packed(seq, rs, rl, np.array(goff, dtype=np.uint64))
 
 
+def fasta_scan(text, skip_capsid=True):
+    """record boundaries of a FASTA text (bytes): list of (id, seq_begin, seq_end) — the reader side of dnafiles.rs:43-193"""
+    L = _lib.load()
+    buf = np.frombuffer(text, dtype=np.uint8)
+    n = C.c_uint64()
+    check(L.gs_fasta_scan(_p(buf) if len(buf) else None, len(buf), int(skip_capsid), 0, None, None, None, None, C.byref(n)))
+    nr = n.value
+    sb, se, ib = np.zeros(nr, np.uint64), np.zeros(nr, np.uint64), np.zeros(nr, np.uint64)
+    il = np.zeros(nr, np.uint32)
+    check(L.gs_fasta_scan(_p(buf) if len(buf) else None, len(buf), int(skip_capsid), nr, _p(sb), _p(se), _p(ib), _p(il), C.byref(n)))
+    return [(bytes(text[int(ib[i]):int(ib[i]) + int(il[i])]).decode("ascii", "replace"), int(sb[i]), int(se[i])) for i in range(nr)]
+
+
+def sketch_fasta_files(sketcher, files, skip_capsid=True):
+    """files: list of FASTA texts (bytes), one genome each -> ((n_files, m) signatures, (rec_start, rec_len, packed)).
+    Record splitting on the host, filtering + 2-bit packing + sketching on the device; one signature per file, k-mers never
+    span records (by-sequence mode, dnasketch.rs:348-363)."""
+    ctx, L = sketcher.ctx, sketcher.ctx.L
+    text = b"".join(files)
+    offs = np.cumsum([0] + [len(f) for f in files])
+    sb, se, goff = [], [], [0]
+    for fi, f in enumerate(files):
+        recs = fasta_scan(f, skip_capsid)
+        for _, b, e in recs:
+            sb.append(int(offs[fi]) + b)
+            se.append(int(offs[fi]) + e)
+        goff.append(len(sb))
+    nrec = len(sb)
+    sb, se = np.array(sb, dtype=np.uint64), np.array(se, dtype=np.uint64)
+    tbuf = np.frombuffer(text, dtype=np.uint8)
+    d_text = ctx.alloc(len(tbuf) + 64)
+    pbytes = len(tbuf) // 4 + 8 * nrec + 128
+    d_packed = ctx.alloc(pbytes)
+    try:
+        ctx.upload(d_text, tbuf)
+        ctx.memset(d_packed, 0, pbytes)
+        rs, rl = np.zeros(max(nrec, 1), np.uint64), np.zeros(max(nrec, 1), np.uint64)
+        check(L.gs_pack_fasta_dev(ctx.h, d_text, len(tbuf), _p(sb), _p(se), nrec, d_packed, _p(rs), _p(rl)))
+        m = sketcher.params.c.sketch_size
+        ng = len(files)
+        goff = np.array(goff, dtype=np.uint64)
+        d_rs, d_rl, d_go = ctx.alloc(8 * max(nrec, 1)), ctx.alloc(8 * max(nrec, 1)), ctx.alloc(8 * (ng + 1))
+        d_sig = ctx.alloc(ng * m * sketcher.sig_dtype().itemsize)
+        try:
+            ctx.upload(d_rs, rs); ctx.upload(d_rl, rl); ctx.upload(d_go, goff)
+            check(L.gs_sketch_batch_dev(ctx.h, C.byref(sketcher.params.c), d_packed, pbytes // 8 * 8, d_rs, d_rl, nrec, d_go, ng, d_sig))
+            out = ctx.download(d_sig, (ng, m), sketcher.sig_dtype())
+        finally:
+            for p_ in (d_rs, d_rl, d_go, d_sig):
+                ctx.free(p_)
+        return out, (rs[:nrec], rl[:nrec], ctx.download(d_packed, (pbytes,), np.uint8))
+    finally:
+        ctx.free(d_text)
+        ctx.free(d_packed)
+
+
 class OptDensHashSketch(_SeqSketcher):
     ALGO_NAME = "optdens"
 
@@ -287,6 +343,41 @@ class DistHamming:
 def ani(distance, kmer_size, model=1):
     """reformat.rs:80-86 calculate_ani."""
     return _lib.load().gs_ani(float(distance), int(kmer_size), int(model))
+
+
+def bindash_distance(hamming_distance, kmer_size):
+    """bindash.rs:93-99 compute_distance: j = 1 - d ; 1 - (2j/(1+j))^(1/k), with the f32 powf the reference uses."""
+    j = np.float32(1.0) - np.float32(hamming_distance)
+    frac = np.float32(2.0) * j / (np.float32(1.0) + j)
+    return float(1.0 - float(np.power(frac, np.float32(1.0) / np.float32(kmer_size), dtype=np.float32)))
+
+
+class ReqAnswer:
+    """src/answer.rs:18-76 — text record of one request; only neighbours with distance < threshold are written
+    (out_threshold = 0.99, dnarequest.rs:83). `seqdict` = list of (path, fasta_id, length) indexed by d_id."""
+
+    def __init__(self, rank, req_item, neighbours):
+        self.rank, self.req_item, self.neighbours = rank, req_item, neighbours
+
+    def dump(self, seqdict, threshold, out):
+        if not any(n.distance <= threshold for n in self.neighbours):
+            return 0
+        path, fasta_id, length = self.req_item
+        out.write("\n%d\t%s\tfasta_id:\t%s\tlength:\t%d" % (self.rank, path, fasta_id, length))
+        nb_match = 0
+        for n in self.neighbours:
+            if n.distance < threshold:
+                nb_match += 1
+                dpath, dfid, dlen = seqdict[n.d_id]
+                out.write("\nquery_id:\t%s\tdistance:\t%s\tanswer_fasta_path\t%s\t%s \t answer_seq_len:\t %d"
+                          % (path, _rust_5e(n.distance), dpath, dfid, dlen))
+        return nb_match
+
+
+def _rust_5e(x):
+    """Rust's {:.5E}: mantissa with 5 decimals, exponent without padding or plus sign (6.07500E-1)"""
+    mant, exp = ("%.5E" % x).split("E")
+    return "%sE%d" % (mant, int(exp))
 
 
 # ----------------------------------------------------------------------------------------------------------

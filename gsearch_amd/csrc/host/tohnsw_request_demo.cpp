@@ -12,6 +12,16 @@
 
 using namespace gsearch;
 
+// Rust's {:.5E} (answer.rs:58-63): mantissa with 5 decimals, exponent without padding or '+' sign, e.g. 6.07500E-1
+static std::string rust_5e(float x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%.5E", (double)x);
+    std::string s(buf);
+    const size_t e = s.find('E');
+    return s.substr(0, e) + "E" + std::to_string(std::stoi(s.substr(e + 1)));
+}
+
 static std::vector<std::pair<std::string, Record>> read_fasta(const char *path)
 {
     std::vector<std::pair<std::string, Record>> out;
@@ -60,7 +70,7 @@ int main(int argc, char **argv)
             std::printf("\n%zu\t%s\tfasta_id:\t%s\tlength:\t%zu", i, argv[2], qs[i].first.c_str(), qs[i].second.size());
             for (auto &n : knn[i])
                 if (n.distance < threshold)
-                    std::printf("\nquery_id:\t%s\tdistance:\t%.5E\tanswer_fasta_path\t%s\t%s \t answer_seq_len:\t %zu", argv[2], n.distance, argv[1], db[n.d_id].first.c_str(), db[n.d_id].second.size());
+                    std::printf("\nquery_id:\t%s\tdistance:\t%s\tanswer_fasta_path\t%s\t%s \t answer_seq_len:\t %zu", argv[2], rust_5e(n.distance).c_str(), argv[1], db[n.d_id].first.c_str(), db[n.d_id].second.size());
         }
         std::printf("\n");
     } catch (const std::exception &e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }

@@ -91,6 +91,17 @@ int gs_sketch_batch(gs_ctx *, const gs_sketch_params *, const void *seq, uint64_
 int gs_sketch_batch_dev(gs_ctx *, const gs_sketch_params *, const void *seq_dev, uint64_t seq_bytes,
                         const uint64_t *rec_start_dev, const uint64_t *rec_len_dev, uint64_t n_rec,
                         const uint64_t *genome_rec_off_dev, uint64_t n_genomes, void *sig_out_dev);
+/* ---- FASTA ingest: the reader side of src/dna/dnafiles.rs:43-193 for already-decompressed text ---- */
+/* host: record boundaries. Record r = sequence text bytes [seq_begin[r], seq_end[r]) (newlines included) and the header's first
+ * word [id_begin[r], +id_len[r]). Records whose id contains "capsid" are skipped when skip_capsid != 0 (dnafiles.rs:67).
+ * Arrays may be NULL / cap 0 to count only; *n_rec_out = number of records kept. */
+int gs_fasta_scan(const char *buf, uint64_t n, int skip_capsid, uint64_t cap, uint64_t *seq_begin, uint64_t *seq_end,
+                  uint64_t *id_begin, uint32_t *id_len, uint64_t *n_rec_out);
+/* device: filter + case-fold + 2-bit pack the text of n_rec records (Sequence::encode_and_add, dnafiles.rs:70-71,148-149; every
+ * non-ACGT byte, newlines included, is dropped). text_dev: raw text; seq_begin/seq_end: HOST offsets from gs_fasta_scan;
+ * packed_dev: ZEROED device buffer >= n_bytes/4 + 8*n_rec + 64 bytes; rec_start_out/rec_len_out: HOST, ready for gs_sketch_batch_dev. */
+int gs_pack_fasta_dev(gs_ctx *, const void *text_dev, uint64_t n_bytes, const uint64_t *seq_begin, const uint64_t *seq_end,
+                      uint64_t n_rec, void *packed_dev, uint64_t *rec_start_out, uint64_t *rec_len_out);
 /* ASCII helpers for hosts that do not pack themselves (Sequence::encode_and_add, dnafiles.rs:70-71) */
 uint64_t gs_pack_dna(const uint8_t *ascii, uint64_t n, uint8_t *packed_zeroed, uint64_t base_off);
 uint64_t gs_filter_aa(const uint8_t *ascii, uint64_t n, uint8_t *out);

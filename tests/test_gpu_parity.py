@@ -312,13 +312,14 @@ def test_cpp_host_mirror(gpu_ctx, tmp_path):
     hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
     hn.parallel_insert(sk.sketch_genomes([[g] for g in db]))
     res = hn.parallel_search(sk.sketch_genomes([[q] for q in qs]), knbn, ef)
-    want = []
+    # the reference's text output (ReqAnswer::dump, answer.rs:35-76) produced by the Python mirror must equal the C++ mirror's
+    import io
+    seqdict = [(str(tmp_path / "db.fa"), "g%d" % i, len(db[i])) for i in range(len(db))]
+    buf = io.StringIO()
     for i, r in enumerate(res):
-        for nb in r:
-            if nb.distance < 0.99:
-                want.append(("g%d" % nb.d_id, "%.5E" % nb.distance))
-    got = [(ln.split("\t")[6].strip(), ln.split("\t")[3]) for ln in out.stdout.splitlines() if ln.startswith("query_id:")]
-    assert got == want and len(got) >= 5
+        G.ReqAnswer(i, (str(tmp_path / "q.fa"), "g%d" % i, len(qs[i])), r).dump(seqdict, 0.99, buf)
+    assert out.stdout == buf.getvalue() + "\n"
+    assert out.stdout.count("query_id:") >= 5
 
 
 def test_three_evaluation_strategies_agree_with_oracle(gpu_ctx, monkeypatch):
@@ -342,3 +343,43 @@ def test_three_evaluation_strategies_agree_with_oracle(gpu_ctx, monkeypatch):
         got = hn.search_arrays(q, 20, 400)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), mode
         assert np.array_equal(got[3], want[3]), (mode, legacy, "evaluation counts")
+
+
+def test_fasta_ingest_pack_and_sketch(gpu_ctx):
+    """f2: FASTA text -> record scan (host) -> filter/case-fold/2-bit pack (device) -> sketch, against the oracle's encode + sketch"""
+    import gsearch_amd as G
+    rng = np.random.default_rng(91)
+
+    def fasta(records, width):
+        out = []
+        for name, s in records:
+            out.append(b">" + name + b" some description\n")
+            out += [s[o:o + width] + b"\n" for o in range(0, len(s), width)]
+        return b"".join(out)
+
+    g1 = H.dna_ascii(H.rand_dna(rng, 50000))
+    g2 = H.dna_ascii(H.rand_dna(rng, 33333))
+    files = [
+        fasta([(b"chr1", g1[:20000] + b"NNNNNRYKM" + g1[20000:30000].lower()), (b"phage_capsid_gene", g1[30000:31000]), (b"chr2", g1[31000:]), (b"tiny", b"ACG")], 60),
+        fasta([(b"contig%d" % i, g2[i * 3000:(i + 1) * 3000 + 17]) for i in range(11)], 80),
+        b">only_header\n",
+        fasta([(b"single", g2)], 70).replace(b"\n", b"\r\n"),
+    ]
+    sk = G.OptDensHashSketch.new(G.SeqSketcherParams(21, 1500, "optdens"))
+    sig, (rs, rl, packed) = G.sketch_fasta_files(sk, files)
+    # oracle: same records (capsid record skipped like dnafiles.rs:67), encode_and_add semantics
+    genomes = []
+    for f in files:
+        genomes.append([f[b:e] for _, b, e in G.fasta_scan(f)])
+    assert [len(g) for g in genomes] == [3, 11, 1, 1]          # ">only_header" is one empty record
+    recs = [r for g in genomes for r in g]
+    oseq, ors, orl = O.pack_dna(recs)
+    assert np.array_equal(rl, orl)
+    for i in range(len(recs)):           # packed bytes of every record are identical (records start on different boundaries)
+        nb = (int(rl[i]) + 3) // 4
+        got = packed[int(rs[i]) // 4: int(rs[i]) // 4 + nb]
+        want = oseq[int(ors[i]) // 4: int(ors[i]) // 4 + nb]
+        assert np.array_equal(got, want), i
+    goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
+    ref = O.sketch_batch(O.params(21, 1500, "optdens"), oseq, ors, orl, goff)
+    assert np.array_equal(sig.view(np.uint32), ref.view(np.uint32))
