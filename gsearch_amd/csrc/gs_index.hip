@@ -316,7 +316,7 @@ __device__ __forceinline__ uint32_t dense_merge_R(uint64_t *keys, uint32_t n, co
 }
 
 template <int KIND>
-__global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat,
+__global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
                                                            uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
                                                            uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out)
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         __syncthreads();
         const uint64_t qi = S.scal[1];
         if (qi >= nq) break;
-        const uint16_t *matrow = mat + qi * ix.n;
+        const uint16_t *matrow = mat + qi * mat_ld;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
         uint64_t evals = 1;
         uint32_t ep = (uint32_t)ix.entry, ep_cnt = matrow[ep];
@@ -482,7 +482,7 @@ __device__ __forceinline__ SearchLds carve_lds(uint8_t *base, uint32_t ef, uint3
 
 template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *__restrict__ queries, uint64_t nq, uint32_t knbn, uint32_t ef,
-                                                     const uint16_t *__restrict__ mat, uint32_t *__restrict__ visited, uint32_t vis_words, unsigned long long *__restrict__ counter,
+                                                     const uint16_t *__restrict__ mat, uint64_t mat_ld, uint32_t *__restrict__ visited, uint32_t vis_words, unsigned long long *__restrict__ counter,
                                                      uint64_t *__restrict__ ids_out, float *__restrict__ dist_out, uint32_t *__restrict__ count_out,
                                                      uint64_t *__restrict__ evals_out)
 {
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(ST) void k_hnsw_search(IndexDev ix, const uint8_t *
         const uint64_t qi = S.scal[1];
         if (qi >= nq) break;
         const uint4 *q = (const uint4 *)(queries + qi * ix.stride);
-        const uint16_t *matrow = mat ? mat + qi * ix.n : nullptr;
+        const uint16_t *matrow = mat ? mat + qi * mat_ld : nullptr;
         for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
         uint64_t evals = 1;
         // distance to the entry point
@@ -777,6 +777,9 @@ struct gs_index {
     double search_frac = -1.0, insert_frac = -1.0;
     // pair cache: the count rows the tile kernel produces for every inserted batch are KEPT (16 bit) so that
     // the neighbour-selection heuristic looks pair distances up instead of streaming rows; 288 GB of HBM hold it up to ~500 k points
+    // column-major copy of the signatures for the match-join (gs_join.hip)
+    gs::DevBuf cols; uint64_t cols_cap = 0, cols_n = 0;
+    gs::DevBuf join_scratch[5];
     gs::DevBuf rowptr;
     std::vector<gs::DevBuf *> slabs;
     uint64_t pair_cache_bytes = 0, pair_cache_budget = 0;
@@ -864,8 +867,45 @@ static bool dense_pays(const gs_index *ix, double frac)
     return dense < gather;
 }
 
-static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t *ids, float *dist, uint32_t *count,
-                               uint64_t *evals)
+// ---- how the dense count matrix is produced: equi-join over a column-major copy (gs_join.hip) or the compare tile kernel
+static bool use_join(const gs_index *ix)
+{
+    const char *e = getenv("GS_DENSE_IMPL");
+    if (e && !strcmp(e, "tile")) return false;
+    return ix->prm.m <= 65535;
+}
+// column-major copy of the signatures of nodes [0, upto): rebuilt when the capacity changed, appended otherwise
+static int ensure_cols(gs_index *ix, uint64_t upto)
+{
+    gs_ctx *c = ix->ctx;
+    int rc;
+    if (ix->cols_cap != ix->cap || !ix->cols.p) {
+        if ((rc = ix->cols.alloc((size_t)ix->prm.m * ix->cap * ix->esz))) return rc;
+        ix->cols_cap = ix->cap; ix->cols_n = 0;
+    }
+    if (ix->cols_n < upto) {
+        if ((rc = rows_to_cols(c, ix->prm.kind, ix->prm.m, ix->data.as<uint8_t>() + ix->cols_n * ix->stride, ix->stride, upto - ix->cols_n, ix->cols.p, ix->cols_cap, ix->cols_n))) return rc;
+        ix->cols_n = upto;
+    }
+    return GS_OK;
+}
+// counts of nq padded query rows against nodes [0, n): out16[q * ld + e]
+static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_t n, uint16_t *out16, uint64_t ld)
+{
+    gs_ctx *c = ix->ctx;
+    int rc;
+    if (!use_join(ix))
+        return hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows, nq, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16, ld);
+    if ((rc = ensure_cols(ix, n))) return rc;
+    for (uint64_t q0 = 0; q0 < nq; q0 += 4096) {
+        const uint64_t nb = std::min<uint64_t>(4096, nq - q0);
+        if ((rc = match_join_counts(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch))) return rc;
+    }
+    return GS_OK;
+}
+
+static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t mat_ld, uint64_t *ids, float *dist,
+                               uint32_t *count, uint64_t *evals)
 {
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
@@ -885,7 +925,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     do {                                                                                                                  \
         auto kern = k_hnsw_search_dense<K>;                                                                               \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, ix->visited.as<uint32_t>(), vis_words, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), vis_words, \
                            ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals);  \
     } while (0)
     if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_DSEARCH(GS_KIND_F32);
@@ -896,14 +936,14 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     return GS_OK;
 }
 
-static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t *ids,
-                         float *dist, uint32_t *count, uint64_t *evals)
+static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t mat_ld,
+                         uint64_t *ids, float *dist, uint32_t *count, uint64_t *evals)
 {
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
     if (mat && maxdeg <= (uint32_t)DT && efs <= (uint32_t)(DMAXI * DT) && dense_lds_bytes(efs, maxdeg) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
-        return search_launch_dense(ix, nq, knbn, ef, mat, ids, dist, count, evals);
+        return search_launch_dense(ix, nq, knbn, ef, mat, mat_ld, ids, dist, count, evals);
     const size_t lds = search_lds_bytes(efs, maxdeg);
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
     uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu);
@@ -914,7 +954,7 @@ static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq,
     do {                                                                                                                  \
         auto kern = k_hnsw_search<K>;                                                                                     \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST), lds, c->stream, d, q_padded_dev, nq, knbn, ef, mat,               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST), lds, c->stream, d, q_padded_dev, nq, knbn, ef, mat, mat_ld,       \
                            ix->visited.as<uint32_t>(), vis_words, ix->counter.as<unsigned long long>(), ids, dist, count, evals); \
     } while (0)
     if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_SEARCH(GS_KIND_F32);
@@ -949,7 +989,7 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
         const uint64_t np = 128;
         uint64_t *ev = evals;
         if (!ev) { if ((rc = tmp_evals.alloc(8 * np))) return rc; ev = tmp_evals.as<uint64_t>(); }
-        if ((rc = search_launch(ix, q, np, knbn, ef, nullptr, ids, dist, count, ev))) return rc;
+        if ((rc = search_launch(ix, q, np, knbn, ef, nullptr, 0, ids, dist, count, ev))) return rc;
         std::vector<uint64_t> h(np);
         GS_HIP_CHECK(hipMemcpyAsync(h.data(), ev, 8 * np, hipMemcpyDeviceToHost, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -960,19 +1000,22 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     const uint64_t rest = nq - done;
     bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || (mode == MODE_AUTO && ix->search_frac >= 0 && rest >= 128 && dense_pays(ix, ix->search_frac)));
     if (!dense) {
-        if (rest) return search_launch(ix, q + done * ix->stride, rest, knbn, ef, nullptr, ids + done * knbn, dist + done * knbn,
+        if (rest) return search_launch(ix, q + done * ix->stride, rest, knbn, ef, nullptr, 0, ids + done * knbn, dist + done * knbn,
                                        count ? count + done : nullptr, evals ? evals + done : nullptr);
         return GS_OK;
     }
-    uint64_t QB = ((uint64_t)4 << 30) / (2 * ix->n);
+    const uint64_t ld = round_up(ix->n, 8);
+    const bool join = use_join(ix);
+    uint64_t QB = ((uint64_t)4 << 30) / (2 * ld);
     QB = std::max<uint64_t>(128, QB / 128 * 128);
+    if (join) QB = std::min<uint64_t>(QB, 4096);
     QB = std::min<uint64_t>(QB, rest);
-    if ((rc = ix->mat.ensure((size_t)2 * QB * ix->n))) return rc;
+    if ((rc = ix->mat.ensure((size_t)2 * QB * ld))) return rc;
+    if (join && (rc = ensure_cols(ix, ix->n))) return rc;
     for (uint64_t q0 = done; q0 < nq; q0 += QB) {
         const uint64_t nb = std::min(QB, nq - q0);
-        if ((rc = hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, q + q0 * ix->stride, nb, ix->stride, ix->data.p, ix->n, ix->stride, nullptr,
-                                      nullptr, ix->mat.as<uint16_t>(), ix->n))) return rc;
-        if ((rc = search_launch(ix, q + q0 * ix->stride, nb, knbn, ef, ix->mat.as<uint16_t>(), ids + q0 * knbn, dist + q0 * knbn,
+        if ((rc = dense_counts(ix, q + q0 * ix->stride, nb, ix->n, ix->mat.as<uint16_t>(), ld))) return rc;
+        if ((rc = search_launch(ix, q + q0 * ix->stride, nb, knbn, ef, ix->mat.as<uint16_t>(), ld, ids + q0 * knbn, dist + q0 * knbn,
                                 count ? count + q0 : nullptr, evals ? evals + q0 : nullptr))) return rc;
     }
     return GS_OK;
@@ -1241,7 +1284,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             uint16_t *out16;
             if (slab) { out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld; mat_ld = slab_ld; }
             else { if ((rc = ix->mat.ensure((size_t)2 * B * slab_ld))) return rc; out16 = ix->mat.as<uint16_t>(); mat_ld = slab_ld; }
-            if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, ix->data.p, b0, ix->stride, nullptr, nullptr, out16, mat_ld))) return rc;
+            if ((rc = gs::dense_counts(ix, rows, nb, b0, out16, mat_ld))) return rc;
             if (slab) {
                 hipLaunchKernelGGL(gs::k_cache_rows, dim3(nb), dim3(256), 0, c->stream, out16, mat_ld, b0, nb, ix->cntmat.as<uint32_t>(), ix->rowptr.as<uint64_t>());
                 GS_HIP_CHECK(hipGetLastError());

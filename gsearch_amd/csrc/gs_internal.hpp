@@ -76,6 +76,13 @@ struct ProfScope {   // brackets one kernel launch with events when profiling is
 int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, uint64_t strideQ_bytes, const void *C, uint64_t nc,
                         uint64_t strideC_bytes, float *out, uint32_t *out_cnt, uint16_t *out_cnt16, uint64_t ld_out);
 
+struct DevBuf;
+// match-join form of the dense count matrix (gs_join.hip): counts of nq strided query rows against the first n nodes of the
+// column-major database copy `cols` ([m][colcap]); out16[q * ld + e] = mismatch count. scratch: 5 reusable buffers.
+int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch);
+int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);
+
 inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }
 inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
