@@ -276,33 +276,56 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
 constexpr int DT = 512;           // lanes per dense-mode workgroup
 constexpr int DWIN = 64;          // keys of C mirrored in LDS
 constexpr int DMAXI = 16;         // staged R keys per lane in a merge (ef <= DMAXI*DT)
-struct DenseLds { uint64_t *R, *A, *W; uint32_t *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
+constexpr int DCN = 192;          // capacity of the LDS-resident candidate buffer N (<= DT - 2M so a fold fits one key per lane)
+struct DenseLds { uint64_t *R, *A, *As, *W, *N; uint32_t *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
 __host__ __device__ inline size_t dense_lds_bytes(uint32_t ef, uint32_t maxdeg)
 {
-    return 8 * (size_t)ef + 8 * (size_t)maxdeg + 8 * DWIN + 4 * (size_t)maxdeg * 2 + 4 * ((size_t)maxdeg + 8) + 4 * (DT / 64) + 64 + 64;
+    return 8 * (size_t)ef + 16 * (size_t)maxdeg + 8 * DWIN + 8 * ((size_t)DCN + maxdeg) + 4 * (size_t)maxdeg * 2 + 4 * ((size_t)DCN + maxdeg + 8) + 4 * (DT / 64) + 64 + 64;
 }
 __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t ef, uint32_t maxdeg)
 {
     DenseLds S;
     S.R = (uint64_t *)base; base += 8 * (size_t)ef;
     S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
+    S.As = (uint64_t *)base; base += 8 * (size_t)maxdeg;
     S.W = (uint64_t *)base; base += 8 * DWIN;
+    S.N = (uint64_t *)base; base += 8 * ((size_t)DCN + maxdeg);
     S.scal = (uint64_t *)base; base += 64;
     S.Eid = (uint32_t *)base; base += 4 * (size_t)maxdeg;
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
-    S.hist = (uint32_t *)base; base += 4 * ((size_t)maxdeg + 8);
+    S.hist = (uint32_t *)base; base += 4 * ((size_t)DCN + maxdeg + 8);
     S.wsum = (uint32_t *)base;
     return S;
 }
+// #{j < na : A[j] < k}. Most merges insert a handful of keys: those are held in registers (ar[], padded with ~0) and the
+// rank is a few compares instead of a dependent chain of LDS reads.
+struct SmallA { uint64_t ar[8]; const uint64_t *A; uint32_t na; };
+__device__ __forceinline__ SmallA load_small_a(const uint64_t *A, uint32_t na)
+{
+    SmallA s; s.A = A; s.na = na;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s.ar[j] = (uint32_t)j < na ? A[j] : ~(uint64_t)0;
+    return s;
+}
+__device__ __forceinline__ uint32_t lb_a(const SmallA &s, uint64_t k)
+{
+    if (s.na <= 8) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) r += (s.ar[j] < k);
+        return r;
+    }
+    return lower_bound_keys(s.A, s.na, k);
+}
 // in-LDS merge of sorted A into sorted R[0..n) keeping `keep` keys (DT lanes)
-__device__ __forceinline__ uint32_t dense_merge_R(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep)
+__device__ __forceinline__ uint32_t dense_merge_R(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep, const SmallA &sa)
 {
     uint64_t kv[DMAXI]; uint32_t pos[DMAXI];
 #pragma unroll
     for (int it = 0; it < DMAXI; it++) {
         const uint32_t idx = threadIdx.x + it * DT;
         pos[it] = 0xFFFFFFFFu; kv[it] = 0;
-        if (idx < n) { const uint64_t k = keys[idx]; kv[it] = k; pos[it] = idx + lower_bound_keys(A, na, k); }
+        if (idx < n) { const uint64_t k = keys[idx]; kv[it] = k; pos[it] = idx + lb_a(sa, k); }
     }
     uint64_t ak = 0; uint32_t apos = 0xFFFFFFFFu;
     if (threadIdx.x < na) { ak = A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(keys, n, ak); }
@@ -319,11 +342,12 @@ template <int KIND>
 __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
                                                            uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
-                                                           uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out)
+                                                           uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out, unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t efs = ef > knbn ? ef : knbn;
+    long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     DenseLds S = carve_dense(s_raw, efs, maxdeg);
     uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
     uint64_t *Cb[2] = {cbuf + (uint64_t)blockIdx.x * 2 * capC, cbuf + (uint64_t)blockIdx.x * 2 * capC + capC};
@@ -355,28 +379,34 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 ep = nbr[KID(best)]; ep_cnt = KCNT(best);
             }
         }
-        // ---- search_layer on layer 0
+        // ---- search_layer on layer 0.  Candidates = sorted bulk array G (global, read through the LDS window W) + small sorted
+        //      array N (LDS) that receives the accepted keys; N is folded into G only when it is full. The next candidate is
+        //      min(head of G, head of N) under the same (count,id) order, so the pop sequence is unchanged.
         int cur = 0;
-        uint32_t nR = 1, nC = 1, headC = 0, wbase = 0, wn = 0;
+        uint32_t nR = 1, nG = 0, headG = 0, wbase = 0, wn = 0, nN = 1, headN = 0;
+        uint32_t tieT = 0;                                       // #keys of a full R tied at its worst count
         __syncthreads();
         if (threadIdx.x == 0) {
-            S.R[0] = KEY(ep_cnt, ep); Cb[0][0] = KEY(ep_cnt, ep);
+            S.R[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
             __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         uint64_t pre_c = ~(uint64_t)0; uint32_t pre_id = 0, pre_deg = 0;
         for (;;) {
-            if (headC >= nC) break;
-            if (headC - wbase >= wn) {                              // refill the LDS window of C
+            if (headG < nG && headG - wbase >= wn) {                 // refill the LDS window of G
                 __syncthreads();
-                wbase = headC; wn = nC - headC < (uint32_t)DWIN ? nC - headC : (uint32_t)DWIN;
-                if (threadIdx.x < wn) S.W[threadIdx.x] = Cb[cur][headC + threadIdx.x];
+                wbase = headG; wn = nG - headG < (uint32_t)DWIN ? nG - headG : (uint32_t)DWIN;
+                if (threadIdx.x < wn) S.W[threadIdx.x] = Cb[cur][headG + threadIdx.x];
                 __syncthreads();
             }
-            const uint64_t c = S.W[headC - wbase];
+            const uint64_t cg = headG < nG ? S.W[headG - wbase] : ~(uint64_t)0;
+            const uint64_t cn = headN < nN ? S.N[headN] : ~(uint64_t)0;
+            const uint64_t c = cg < cn ? cg : cn;
+            if (c == ~(uint64_t)0) break;
             const uint32_t dmax = (nR == efs) ? KCNT(S.R[efs - 1]) : INF_CNT;
             if (KCNT(c) > dmax) break;
-            headC++;
+            if (cg < cn) headG++; else headN++;
+            const long long p0 = prof ? clock64() : 0;
             uint32_t id, deg;
             if (pre_c == c) { id = pre_id; deg = pre_deg; }
             else { const uint32_t *nbr = ix.nbr0 + (uint64_t)KID(c) * maxdeg; deg = ix.deg0[KID(c)]; id = threadIdx.x < maxdeg ? nbr[threadIdx.x] : 0; }
@@ -387,74 +417,131 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 const uint32_t old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 unv = !(old & bit);
             }
-            if (headC < nC && headC - wbase < wn) {                 // prefetch the next candidate's adjacency
-                pre_c = S.W[headC - wbase];
-                pre_deg = ix.deg0[KID(pre_c)];
-                pre_id = threadIdx.x < maxdeg ? ix.nbr0[(uint64_t)KID(pre_c) * maxdeg + threadIdx.x] : 0;
-            } else pre_c = ~(uint64_t)0;
+            {   // prefetch the adjacency of the candidate that follows if this expansion accepts nothing
+                const uint64_t g2 = (headG < nG && headG - wbase < wn) ? S.W[headG - wbase] : ~(uint64_t)0;
+                const uint64_t n2 = headN < nN ? S.N[headN] : ~(uint64_t)0;
+                pre_c = g2 < n2 ? g2 : n2;
+                if (pre_c != ~(uint64_t)0 && !(headG < nG && headG - wbase >= wn)) {
+                    pre_deg = ix.deg0[KID(pre_c)];
+                    pre_id = threadIdx.x < maxdeg ? ix.nbr0[(uint64_t)KID(pre_c) * maxdeg + threadIdx.x] : 0;
+                } else pre_c = ~(uint64_t)0;
+            }
             const uint64_t bal = __ballot(unv);
+            const long long p1 = prof ? clock64() : 0;
             if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
             __syncthreads();
+            const long long p2 = prof ? clock64() : 0;
             uint32_t off = 0, ne = 0;
 #pragma unroll
             for (int w = 0; w < DT / 64; w++) { const uint32_t x = S.wsum[w]; if (w < (int)wv) off += x; ne += x; }
             if (unv) { const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1)); S.Eid[pos] = id; S.Ecnt[pos] = cntv; }
             __syncthreads();
+            const long long p3 = prof ? clock64() : 0;
+            if (prof && blockIdx.x == 0 && threadIdx.x == 0) { t_a += p1 - p0; t_b += p2 - p1; t_c += p3 - p2; n_pop++; }
             if (ne == 0) continue;
             evals += ne;
             uint64_t mykey = ~(uint64_t)0; bool acc = false;
-            if (threadIdx.x < ne) {
-                const uint32_t ci = S.Ecnt[threadIdx.x];
-                uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu));
-                if (le < efs) for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
-                acc = le < efs;
-                if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
+            uint32_t na;
+            {
+                // closed-form accept rule.  Fast path once R is full: a candidate is accepted iff c_i < dmax and
+                // #{x in R: c(x) <= c_i} + #{j<i: c_j <= c_i} < ef. With T = #{x in R: c(x) == dmax} keys tied at the tail,
+                // the first term is <= ef - T for c_i < dmax, so if the B candidates below dmax number <= T all of them pass.
+                const uint32_t ci = threadIdx.x < ne ? S.Ecnt[threadIdx.x] : INF_CNT;
+                const bool below = nR == efs && threadIdx.x < ne && ci < dmax;
+                const uint32_t B = nR == efs ? (uint32_t)__syncthreads_count(below) : 0xFFFFFFFFu;
+                if (B == 0) { na = 0; }
+                else if (B <= tieT) { acc = below; na = B; if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]); }
+                else {
+                    if (threadIdx.x < ne && !(nR == efs && ci >= dmax)) {
+                        uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu));
+                        if (le < efs) {
+#pragma unroll 8
+                            for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
+                        }
+                        acc = le < efs;
+                        if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
+                    }
+                    na = (uint32_t)__syncthreads_count(acc);
+                }
             }
-            const uint32_t na = (uint32_t)__syncthreads_count(acc);
+            const long long p4 = prof ? clock64() : 0;
+            if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_d += p4 - p3;
             if (na == 0) continue;
-            if (threadIdx.x < maxdeg) S.A[threadIdx.x] = mykey;
-            __syncthreads();
-            uint32_t rank = 0;
-            if (acc) for (uint32_t j = 0; j < ne; j++) rank += (S.A[j] < mykey);
-            __syncthreads();
-            if (acc) S.A[rank] = mykey;
-            if (threadIdx.x <= na) S.hist[threadIdx.x] = 0;
-            __syncthreads();
+            n_merge++;
+            // accepted keys: compact (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
+            {
+                const uint64_t ab = __ballot(acc);
+                if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(ab);
+                __syncthreads();
+                uint32_t aoff = 0;
+#pragma unroll
+                for (int w = 0; w < DT / 64; w++) if (w < (int)wv) aoff += S.wsum[w];
+                if (acc) S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey;
+                __syncthreads();
+                if (threadIdx.x < na) {
+                    const uint64_t k = S.As[threadIdx.x];
+                    uint32_t rank = 0;
+#pragma unroll 8
+                    for (uint32_t j = 0; j < na; j++) rank += (S.As[j] < k);
+                    S.A[rank] = k;
+                }
+                __syncthreads();
+            }
             // R <- ef smallest of R u A
-            nR = dense_merge_R(S.R, nR, S.A, na, efs);
+            const SmallA sa = load_small_a(S.A, na);
+            nR = dense_merge_R(S.R, nR, S.A, na, efs, sa);
             const uint32_t dnew = (nR == efs) ? KCNT(S.R[efs - 1]) : INF_CNT;
-            // C <- live C u A into the other buffer; hist[t] = #live C keys whose lower bound in A is t
-            const uint32_t live = nC - headC;
-            uint64_t *src = Cb[cur] + headC, *dst = Cb[cur ^ 1];
-            uint32_t alive_loc = 0;
-            for (uint32_t idx = threadIdx.x; idx < live; idx += DT) {
-                const uint64_t k = src[idx];
-                const uint32_t lb = lower_bound_keys(S.A, na, k);
-                const uint32_t pos = idx + lb;
-                if (pos < capC) dst[pos] = k;
-                atomicAdd(&S.hist[lb], 1u);
-                alive_loc += (KCNT(k) <= dnew);
-            }
-            if (threadIdx.x < na) alive_loc += (KCNT(S.A[threadIdx.x]) <= dnew);
-            __syncthreads();                                        // hist complete before the A positions are derived from it
-            // wave sums of the alive counts
-            uint32_t wsumv = alive_loc;
+            tieT = nR == efs ? efs - lower_bound_keys(S.R, nR, KEY(dnew, 0)) : 0;
+            // ---- N full? fold its live part into G first (rare): G' = live G u live N, dead tail dropped
+            if (nN - headN + na > (uint32_t)DCN) {
+                const uint32_t liveN = nN - headN, liveG = nG - headG;
+                const uint64_t *NL = S.N + headN;
+                if (threadIdx.x <= liveN) S.hist[threadIdx.x] = 0;
+                __syncthreads();
+                uint64_t *src = Cb[cur] + headG, *dst = Cb[cur ^ 1];
+                uint32_t alive_loc = 0;
+                for (uint32_t idx = threadIdx.x; idx < liveG; idx += DT) {
+                    const uint64_t k = src[idx];
+                    const uint32_t lb = lower_bound_keys(NL, liveN, k);
+                    if (idx + lb < capC) dst[idx + lb] = k;
+                    atomicAdd(&S.hist[lb], 1u);
+                    alive_loc += (KCNT(k) <= dnew);
+                }
+                if (threadIdx.x < liveN) alive_loc += (KCNT(NL[threadIdx.x]) <= dnew);
+                __syncthreads();
+                uint32_t wsumv = alive_loc;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) wsumv += __shfl_down(wsumv, o);
-            if (lane == 0) S.wsum[wv] = wsumv;
-            if (threadIdx.x < na) {
-                uint32_t below = 0;
-                for (uint32_t t = 0; t <= threadIdx.x; t++) below += S.hist[t];
-                const uint32_t pos = threadIdx.x + below;
-                if (pos < capC) dst[pos] = S.A[threadIdx.x];
-            }
-            __syncthreads();
-            uint32_t alive = 0;
+                for (int o = 32; o > 0; o >>= 1) wsumv += __shfl_down(wsumv, o);
+                if (lane == 0) S.wsum[wv] = wsumv;
+                if (threadIdx.x < liveN) {
+                    uint32_t below = 0;
+                    for (uint32_t t = 0; t <= threadIdx.x; t++) below += S.hist[t];
+                    if (threadIdx.x + below < capC) dst[threadIdx.x + below] = NL[threadIdx.x];
+                }
+                __syncthreads();
+                uint32_t alive = 0;
 #pragma unroll
-            for (int w = 0; w < DT / 64; w++) alive += S.wsum[w];
-            uint32_t tot = live + na; if (tot > capC) tot = capC;
-            nC = (nR == efs && alive < tot) ? alive : tot;
-            cur ^= 1; headC = 0; wbase = 0; wn = 0; pre_c = ~(uint64_t)0;
+                for (int w = 0; w < DT / 64; w++) alive += S.wsum[w];
+                uint32_t tot = liveG + liveN; if (tot > capC) tot = capC;
+                nG = (nR == efs && alive < tot) ? alive : tot;
+                cur ^= 1; headG = 0; wbase = 0; wn = 0; nN = 0; headN = 0;
+            }
+            // ---- N <- live N u A (both tiny, in LDS), dead tail dropped
+            {
+                const uint32_t liveN = nN - headN;
+                uint64_t nk = 0; uint32_t npos = 0xFFFFFFFFu;
+                if (threadIdx.x < liveN) { nk = S.N[headN + threadIdx.x]; npos = threadIdx.x + lb_a(sa, nk); }
+                uint64_t ak = 0; uint32_t apos = 0xFFFFFFFFu;
+                if (threadIdx.x < na) { ak = S.A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(S.N + headN, liveN, ak); }
+                __syncthreads();
+                if (npos != 0xFFFFFFFFu) S.N[npos] = nk;
+                if (apos != 0xFFFFFFFFu) S.N[apos] = ak;
+                __syncthreads();
+                nN = liveN + na; headN = 0;
+                if (nR == efs) { const uint32_t alive = lower_bound_keys(S.N, nN, KEY(dnew, 0xFFFFFFFFu)); if (alive < nN) nN = alive; }
+            }
+            pre_c = ~(uint64_t)0;
+            if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_e += clock64() - p4;
         }
         __syncthreads();
         const uint32_t nout = nR < knbn ? nR : knbn;
@@ -463,6 +550,10 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             else { ids_out[qi * knbn + i] = ~(uint64_t)0; dist_out[qi * knbn + i] = INFINITY; }
         }
         if (threadIdx.x == 0) { if (count_out) count_out[qi] = nout; if (evals_out) evals_out[qi] = evals; }
+    }
+    if (prof && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
+        atomicAdd(&prof[3], (unsigned long long)t_d); atomicAdd(&prof[4], (unsigned long long)t_e); atomicAdd(&prof[5], (unsigned long long)n_pop); atomicAdd(&prof[6], (unsigned long long)n_merge);
     }
 }
 
@@ -913,26 +1004,38 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     const size_t lds = dense_lds_bytes(efs, maxdeg);
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024 - 1024) / lds));
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
-    const uint32_t capC = 2 * efs + maxdeg + 64;
+    const uint32_t capC = 2 * efs + 2 * (uint32_t)DCN + maxdeg + 64;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu * per_cu);
     int rc;
     if ((rc = ix->visited.ensure((size_t)4 * vis_words * c->n_cu * 3))) return rc;
     if ((rc = ix->cbuf.ensure((size_t)16 * capC * c->n_cu * 3))) return rc;
     GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
     IndexDev d = index_dev(ix);
+    unsigned long long *prof = nullptr;
+    DevBuf profbuf;
+    if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(64))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 64, c->stream)); prof = profbuf.as<unsigned long long>(); }
+    {
     ProfScope ps(c, FAM_SEARCH);
 #define GS_LAUNCH_DSEARCH(K)                                                                                              \
     do {                                                                                                                  \
         auto kern = k_hnsw_search_dense<K>;                                                                               \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), vis_words, \
-                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals);  \
+                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof);  \
     } while (0)
     if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_DSEARCH(GS_KIND_F32);
     else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_DSEARCH(GS_KIND_U32);
     else GS_LAUNCH_DSEARCH(GS_KIND_U64);
 #undef GS_LAUNCH_DSEARCH
+    }
     GS_HIP_CHECK(hipGetLastError());
+    if (prof) {
+        unsigned long long h[8];
+        GS_HIP_CHECK(hipMemcpyAsync(h, prof, 64, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[GS_TRAV_PROFILE] workgroup 0: pops %llu merges %llu | cycles/pop: loads+atomics issue->ballot %.0f, sync1 %.0f, compaction+sync2 %.0f, accept rule+count %.0f | merge cycles/merge %.0f\n",
+                h[5], h[6], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], h[6] ? (double)h[4] / h[6] : 0.0);
+    }
     return GS_OK;
 }
 
