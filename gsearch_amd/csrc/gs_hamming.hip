@@ -5,6 +5,7 @@
 //                     distances of the index build). 64x64 output tile per workgroup, 4x4 per lane, K-chunks of
 //                     32 words staged through LDS; every candidate word is fetched once per 64 queries.
 //  * k_hamming_pairs: one wavefront per (a,b) pair, 16-byte coalesced row reads, v_cmp + ballot/popcount.
+#include <algorithm>
 #include "gs_internal.hpp"
 
 namespace gs {
@@ -58,7 +59,8 @@ __device__ __forceinline__ void cmp_acc8_64(uint32_t (&c)[8], uint64_t a, const 
 
 template <int KIND, bool VEC4>
 __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict__ Q, uint64_t nq, uint64_t strideQ, const uint32_t *__restrict__ C, uint64_t nc,
-                                                      uint64_t strideC, uint32_t m, float *__restrict__ out, uint32_t *__restrict__ out_cnt, uint16_t *__restrict__ out_cnt16, uint64_t ld_out)
+                                                      uint64_t strideC, uint32_t m, float *__restrict__ out, uint32_t *__restrict__ out_cnt, uint16_t *__restrict__ out_cnt16, uint64_t ld_out,
+                                                      uint32_t ksplit_words)
 {
     constexpr int EW = ElemCmp<KIND>::EW;
     __shared__ uint32_t sq[2][HT * HP];
@@ -67,7 +69,10 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
     // come from HBM once and from L2 / Infinity Cache for the other query tiles
     const uint64_t q0 = (uint64_t)blockIdx.x * HT, c0 = (uint64_t)blockIdx.y * HT;
     const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const uint64_t roww = (uint64_t)m * EW;          // words per row
+    const uint64_t roww_full = (uint64_t)m * EW;     // words per row
+    // K-split (small Q x C problems): blockIdx.z owns words [kbeg, roww); partial counts are added atomically (zeroed out_cnt)
+    const uint64_t kbeg = ksplit_words ? (uint64_t)blockIdx.z * ksplit_words : 0;
+    const uint64_t roww = ksplit_words ? (kbeg + ksplit_words < roww_full ? kbeg + ksplit_words : roww_full) : roww_full;
     uint32_t cnt[8][8];
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -100,11 +105,11 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
             dc[0] = rc[i].x; dc[1] = rc[i].y; dc[2] = rc[i].z; dc[3] = rc[i].w;
         }
     };
-    stage_load(0);
+    stage_load(kbeg);
     stage_store(0);
     __syncthreads();
     int cur = 0;
-    for (uint64_t w0 = 0; w0 < roww; w0 += HKW) {
+    for (uint64_t w0 = kbeg; w0 < roww; w0 += HKW) {
         const bool more = w0 + HKW < roww;
         if (more) stage_load(w0 + HKW);              // global loads in flight during the compare block
         const uint32_t *pa = &sq[cur][ty * HP], *pb = &sc[cur][tx * HP];
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
             const uint64_t cj = c0 + tx + 16 * j;
             if (cj < nc) {
                 if (out) out[qi * ld_out + cj] = (float)cnt[i][j] / fm;
-                else if (out_cnt) out_cnt[qi * ld_out + cj] = cnt[i][j];
+                else if (out_cnt) { if (ksplit_words) atomicAdd(&out_cnt[qi * ld_out + cj], cnt[i][j]); else out_cnt[qi * ld_out + cj] = cnt[i][j]; }
                 else out_cnt16[qi * ld_out + cj] = (uint16_t)cnt[i][j];
             }
         }
@@ -180,11 +185,22 @@ int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t
     GS_REQUIRE(!out_cnt16 || m <= 65535, GS_ERR_INVALID, "16-bit counts need m <= 65535");
     if (ld_out == 0) ld_out = nc;
     dim3 grid((uint32_t)((nq + HT - 1) / HT), (uint32_t)((nc + HT - 1) / HT)), block(256);
+    // few tiles (e.g. the batch-mates matrix of an insert): split the rows over blockIdx.z so the whole chip works on them
+    uint32_t ksplit_words = 0;
+    const uint64_t roww_all = (uint64_t)m * (kind == GS_KIND_U64 ? 2 : 1);
+    if (out_cnt && (uint64_t)grid.x * grid.y * 2 <= (uint64_t)c->n_cu && roww_all >= 8 * HKW) {
+        uint32_t nz = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 2 / ((uint64_t)grid.x * grid.y), roww_all / (4 * HKW));
+        if (nz > 1) {
+            ksplit_words = (uint32_t)(((roww_all + nz - 1) / nz + HKW - 1) / HKW * HKW);
+            grid.z = (uint32_t)((roww_all + ksplit_words - 1) / ksplit_words);
+            GS_HIP_CHECK(hipMemset2DAsync(out_cnt, ld_out * 4, 0, nc * 4, nq, c->stream));
+        }
+    }
     GS_REQUIRE(grid.y <= 65535, GS_ERR_INVALID, "too many candidate rows for one call (max %d)", 65535 * HT);
     ProfScope ps(c, FAM_HAMMING);
     const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
     const bool vec4 = (strideQ_bytes % 16 == 0) && (strideC_bytes % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)C % 16 == 0);
-#define GS_LAUNCH_QXC(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V>), grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt, out_cnt16, ld_out)
+#define GS_LAUNCH_QXC(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V>), grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt, out_cnt16, ld_out, ksplit_words)
     if (kind == GS_KIND_F32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_F32, true); else GS_LAUNCH_QXC(GS_KIND_F32, false); }
     else if (kind == GS_KIND_U32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_U32, true); else GS_LAUNCH_QXC(GS_KIND_U32, false); }
     else { if (vec4) GS_LAUNCH_QXC(GS_KIND_U64, true); else GS_LAUNCH_QXC(GS_KIND_U64, false); }

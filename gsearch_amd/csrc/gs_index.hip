@@ -42,7 +42,7 @@ struct IndexDev {
 };
 
 struct SearchLds {              // carve-up of the dynamic LDS region
-    uint64_t *R, *C, *A;        // R[ef], C[capC], A[maxdeg]
+    uint64_t *R, *C, *A, *As;   // R[ef], C[capC], A[maxdeg] sorted accepted keys, As[maxdeg] staging
     uint32_t *Eid, *Ecnt;       // [maxdeg]
     uint32_t *wsum;             // [ST/64]
     uint64_t *scal;             // small scalars
@@ -50,7 +50,7 @@ struct SearchLds {              // carve-up of the dynamic LDS region
 __host__ __device__ inline size_t search_lds_bytes(uint32_t ef, uint32_t maxdeg)
 {
     size_t capC = 2 * (size_t)ef + maxdeg + 64;
-    return 8 * (size_t)ef + 8 * capC + 8 * (size_t)maxdeg + 4 * (size_t)maxdeg * 2 + 4 * (ST / 64) + 8 * 8 + 64;
+    return 8 * (size_t)ef + 8 * capC + 16 * (size_t)maxdeg + 4 * (size_t)maxdeg * 2 + 4 * (ST / 64) + 8 * 8 + 64;
 }
 
 // number of keys in sorted a[0..n) that are < k
@@ -61,9 +61,29 @@ __device__ __forceinline__ uint32_t lower_bound_keys(const uint64_t *a, uint32_t
     return lo;
 }
 
+// #{j < na : A[j] < k}. Most merges insert a handful of keys: those are held in registers (ar[], padded with ~0) and the
+// rank is a few compares instead of a dependent chain of LDS reads.
+struct SmallA { uint64_t ar[8]; const uint64_t *A; uint32_t na; };
+__device__ __forceinline__ SmallA load_small_a(const uint64_t *A, uint32_t na)
+{
+    SmallA s; s.A = A; s.na = na;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s.ar[j] = (uint32_t)j < na ? A[j] : ~(uint64_t)0;
+    return s;
+}
+__device__ __forceinline__ uint32_t lb_a(const SmallA &s, uint64_t k)
+{
+    if (s.na <= 8) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) r += (s.ar[j] < k);
+        return r;
+    }
+    return lower_bound_keys(s.A, s.na, k);
+}
 // Merge sorted A[0..na) (na <= blockDim) into the sorted live range keys[head..n); the result starts at
 // keys[0] and is truncated to `keep`. All lanes call; returns the new length. Keys are unique.
-__device__ __forceinline__ uint32_t block_merge(uint64_t *keys, uint32_t head, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep)
+__device__ __forceinline__ uint32_t block_merge(uint64_t *keys, uint32_t head, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep, const SmallA &sa)
 {
     uint64_t kv[SMAXI]; uint32_t pos[SMAXI];
     const uint32_t live = n - head;
@@ -71,7 +91,7 @@ __device__ __forceinline__ uint32_t block_merge(uint64_t *keys, uint32_t head, u
     for (int it = 0; it < SMAXI; it++) {
         uint32_t idx = threadIdx.x + it * ST;
         pos[it] = 0xFFFFFFFFu; kv[it] = 0;
-        if (idx < live) { uint64_t k = keys[head + idx]; kv[it] = k; pos[it] = idx + lower_bound_keys(A, na, k); }
+        if (idx < live) { uint64_t k = keys[head + idx]; kv[it] = k; pos[it] = idx + lb_a(sa, k); }
     }
     uint64_t ak = 0; uint32_t apos = 0xFFFFFFFFu;
     if (threadIdx.x < na) { ak = A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(keys + head, live, ak); }
@@ -163,7 +183,7 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
 {
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t capC = 2 * ef + maxdeg + 64;
-    uint32_t nR = 1, nC = 1, headC = 0;
+    uint32_t nR = 1, nC = 1, headC = 0, tieT = 0;
     if (threadIdx.x == 0) { S.R[0] = KEY(ep_cnt, ep); S.C[0] = KEY(ep_cnt, ep); __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __syncthreads();
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -213,25 +233,52 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
         // ---- closed form of the sequential accept rule (DESIGN.md "accept rule"):
         //      e_i accepted  <=>  #{x in R : c(x) <= c_i} + #{j < i : c_j <= c_i}  <  ef
         uint64_t mykey = ~(uint64_t)0; bool acc = false;
-        if (threadIdx.x < ne) {
-            const uint32_t ci = S.Ecnt[threadIdx.x];
-            uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu));           // keys < (ci,max) ; ids never reach 2^32-1
-            if (le < ef) for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
-            acc = le < ef;
-            if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
+        uint32_t na;
+        {
+            // closed-form accept rule with the two fast paths of 3.6: a full R rejects c_i >= c(worst) outright, and when
+            // the B candidates below c(worst) number <= tieT (keys of R tied at the worst count) all of them are accepted.
+            const uint32_t ci = threadIdx.x < ne ? S.Ecnt[threadIdx.x] : INF_CNT;
+            const bool below = nR == ef && threadIdx.x < ne && ci < dmax;
+            const uint32_t B = nR == ef ? (uint32_t)__syncthreads_count(below) : 0xFFFFFFFFu;
+            if (B == 0) na = 0;
+            else if (B <= tieT) { acc = below; na = B; if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]); }
+            else {
+                if (threadIdx.x < ne && !(nR == ef && ci >= dmax)) {
+                    uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu));       // keys < (ci,max) ; ids never reach 2^32-1
+                    if (le < ef) {
+#pragma unroll 8
+                        for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
+                    }
+                    acc = le < ef;
+                    if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
+                }
+                na = (uint32_t)__syncthreads_count(acc);
+            }
         }
-        const uint32_t na = (uint32_t)__syncthreads_count(acc);       // (also orders the reads above before the next writes)
         if (na == 0) continue;
-        if (threadIdx.x < maxdeg) S.A[threadIdx.x] = mykey;          // unsorted staging (~0 = rejected)
-        __syncthreads();
-        uint32_t rank = 0;
-        if (acc) for (uint32_t j = 0; j < ne; j++) rank += (S.A[j] < mykey);
-        __syncthreads();
-        if (acc) S.A[rank] = mykey;                                  // sorted ascending, dense in [0,na)
-        __syncthreads();
+        {   // accepted keys: compact (ballot prefix) into As, rank-sort the na (usually a handful) keys into A
+            const uint64_t ab = __ballot(acc);
+            if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(ab);
+            __syncthreads();
+            uint32_t aoff = 0;
+#pragma unroll
+            for (int w = 0; w < ST / 64; w++) if (w < (int)wv) aoff += S.wsum[w];
+            if (acc) S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey;
+            __syncthreads();
+            if (threadIdx.x < na) {
+                const uint64_t k = S.As[threadIdx.x];
+                uint32_t rank = 0;
+#pragma unroll 8
+                for (uint32_t j = 0; j < na; j++) rank += (S.As[j] < k);
+                S.A[rank] = k;
+            }
+            __syncthreads();
+        }
         // ---- R <- ef smallest of R u A ; C <- live C u A ; drop dead tail of C
-        nR = block_merge(S.R, 0, nR, S.A, na, ef);
-        nC = block_merge(S.C, headC, nC, S.A, na, capC);
+        const SmallA sa = load_small_a(S.A, na);
+        nR = block_merge(S.R, 0, nR, S.A, na, ef, sa);
+        nC = block_merge(S.C, headC, nC, S.A, na, capC, sa);
+        tieT = nR == ef ? ef - lower_bound_keys(S.R, nR, KEY(KCNT(S.R[ef - 1]), 0)) : 0;
         headC = 0;
         if (nR == ef) {
             uint32_t alive = lower_bound_keys(S.C, nC, KEY(KCNT(S.R[ef - 1]), 0xFFFFFFFFu));
@@ -296,26 +343,6 @@ __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t ef, uint
     S.hist = (uint32_t *)base; base += 4 * ((size_t)DCN + maxdeg + 8);
     S.wsum = (uint32_t *)base;
     return S;
-}
-// #{j < na : A[j] < k}. Most merges insert a handful of keys: those are held in registers (ar[], padded with ~0) and the
-// rank is a few compares instead of a dependent chain of LDS reads.
-struct SmallA { uint64_t ar[8]; const uint64_t *A; uint32_t na; };
-__device__ __forceinline__ SmallA load_small_a(const uint64_t *A, uint32_t na)
-{
-    SmallA s; s.A = A; s.na = na;
-#pragma unroll
-    for (int j = 0; j < 8; j++) s.ar[j] = (uint32_t)j < na ? A[j] : ~(uint64_t)0;
-    return s;
-}
-__device__ __forceinline__ uint32_t lb_a(const SmallA &s, uint64_t k)
-{
-    if (s.na <= 8) {
-        uint32_t r = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) r += (s.ar[j] < k);
-        return r;
-    }
-    return lower_bound_keys(s.A, s.na, k);
 }
 // in-LDS merge of sorted A into sorted R[0..n) keeping `keep` keys (DT lanes)
 __device__ __forceinline__ uint32_t dense_merge_R(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep, const SmallA &sa)
@@ -564,6 +591,7 @@ __device__ __forceinline__ SearchLds carve_lds(uint8_t *base, uint32_t ef, uint3
     S.R = (uint64_t *)base; base += 8 * (size_t)ef;
     S.C = (uint64_t *)base; base += 8 * capC;
     S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
+    S.As = (uint64_t *)base; base += 8 * (size_t)maxdeg;
     S.scal = (uint64_t *)base; base += 8 * 8;
     S.Eid = (uint32_t *)base; base += 4 * (size_t)maxdeg;
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
@@ -736,7 +764,7 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
         __syncthreads();
         if (ismate) S.C[nb + rank] = mykey;
         __syncthreads();
-        if (nm) nW = block_merge(S.R, 0, nW, S.C + nb, nm, efc);
+        if (nm) { const SmallA sm = load_small_a(S.C + nb, nm); nW = block_merge(S.R, 0, nW, S.C + nb, nm, efc, sm); }
         const uint32_t deg = L == 0 ? 2 * ix.M : ix.M;
         const bool ext = (L == 0) && extend;
         uint32_t na = 0;
