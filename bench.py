@@ -321,6 +321,28 @@ def run_request(args, torch, rank, world, local):
                                     "itself is latency-bound (DESIGN.md 3.6)" if tile_n
                                     else "gather mode: one 72 kB row streamed from HBM per evaluation")}
         out["kernels"] = kernels
+        # the row-streaming (gather) form of the same search on a sub-batch: the HBM-bound DistHamming kernel the north star prices
+        # against the HBM roofline (>= 40 % target); results are identical, only the evaluation strategy differs
+        ng_q = min(256, qps)
+        prev_mode = os.environ.get("GS_DIST_MODE")
+        os.environ["GS_DIST_MODE"] = "gather"
+        try:
+            ev_g = torch.zeros((ng_q,), dtype=torch.int64, device="cuda")
+            ids_g2 = torch.empty((ng_q, knbn), dtype=torch.int64, device="cuda")
+            dist_g2 = torch.empty((ng_q, knbn), dtype=torch.float32, device="cuda")
+            ctx.profile(True); ctx.profile_read(2, reset=True)
+            chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, ng_q, knbn, ef, ids_g2.data_ptr(), dist_g2.data_ptr(), cnt_t.data_ptr(), ev_g.data_ptr()))
+            g_ms, g_n = ctx.profile_read(2, reset=True); ctx.profile(False)
+            g_bytes = float(ev_g.sum().item()) * row_bytes
+            out["roofline_gather_mode"] = {"bound": "hbm", "kernel": "k_hnsw_search (GS_DIST_MODE=gather)", "queries": ng_q, "launch_ms": g_ms / max(g_n, 1),
+                                           "algorithmic_bytes": g_bytes, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "same_answers_as_dense": bool(torch.equal(ids_g2, ids_t[:ng_q]) and torch.equal(dist_g2, dist_t[:ng_q]))}
+        finally:
+            if prev_mode is None:
+                os.environ.pop("GS_DIST_MODE", None)
+            else:
+                os.environ["GS_DIST_MODE"] = prev_mode
         # physical HBM traffic per launch from the committed rocprofv3 PMC summary of this same workload (separate --pmc passes)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom["kernel"])
