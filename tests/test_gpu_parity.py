@@ -383,3 +383,61 @@ def test_fasta_ingest_pack_and_sketch(gpu_ctx):
     goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
     ref = O.sketch_batch(O.params(21, 1500, "optdens"), oseq, ors, orl, goff)
     assert np.array_equal(sig.view(np.uint32), ref.view(np.uint32))
+
+
+def test_edge_cases_and_error_behaviour(gpu_ctx):
+    """empty / ragged inputs, extreme k, and the loud failures of the boundary (no silent fallbacks)"""
+    import gsearch_amd as G
+    sk = G.OptDensHashSketch.new(G.SeqSketcherParams(21, 128, "optdens"))
+    # empty batch, empty genome, genome of only N's, genome shorter than k
+    assert sk.sketch_genomes([]).shape == (0, 128)
+    got = sk.sketch_genomes([[], [b""], [b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNN"], [b"ACGTACGTACGTACGTACGT"]])
+    assert got.shape == (4, 128) and (got == 1.0).all()                       # no k-mer at all -> all slots 1.0 (SPEC 3.1)
+    # exactly one k-mer; k = 32 (64-bit values fully used) ; k = 1
+    one = b"ACGTTGCAACGTTGCAACGTA"
+    ref = _oracle_sketch(21, 128, "optdens", [[one]])
+    assert np.array_equal(sk.sketch_genomes([[one]]).view(np.uint32), ref.view(np.uint32))
+    rng = np.random.default_rng(2)
+    g = H.dna_ascii(H.rand_dna(rng, 5000))
+    for k, algo in ((32, "optdens"), (32, "prob"), (1, "super2"), (2, "prob"), (31, "super")):
+        s2 = G.sketcher_for(G.SeqSketcherParams(k, 96, algo))
+        assert np.array_equal(_bits(s2.sketch_genomes([[g], [g[:77]]])), _bits(_oracle_sketch(k, 96, algo, [[g], [g[:77]]]))), (k, algo)
+    # ragged: 300 records of wildly different lengths in one genome, many shorter than k
+    recs = [g[i * 13:i * 13 + (i % 40)] for i in range(300)]
+    assert np.array_equal(sk.sketch_genomes([recs]).view(np.uint32), _oracle_sketch(21, 128, "optdens", [recs]).view(np.uint32))
+    # DistHamming: zero rows / single element
+    dh = G.DistHamming()
+    assert dh.eval_qxc(np.zeros((0, 5), np.float32), np.zeros((3, 5), np.float32)).shape == (0, 3)
+    assert dh.eval(np.array([1.5], np.float32), np.array([1.5], np.float32)) == 0.0
+    with pytest.raises(G.GsError):
+        dh.eval_qxc(np.zeros((2, 5), np.float32), np.zeros((2, 6), np.float32))
+    # index: search on empty index, wrong signature length, knbn > nb_point, ef beyond the LDS budget, ids out of order
+    hn = G.Hnsw.new(8, 1000, 16, 32, dh)
+    with pytest.raises(G.GsError):
+        hn.search_arrays(np.zeros((1, 16), np.float32), 3, 10)
+    db = H.synth_sig_db(3, 4, 64, 1)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    with pytest.raises(G.GsError):
+        hn.modify_level_scale(0.5)                                              # parameters are frozen once the index holds points
+    with pytest.raises(G.GsError):
+        hn.parallel_insert(np.zeros((2, 65), np.float32))
+    with pytest.raises(G.GsError):
+        hn.parallel_insert([(db[0], 99)])
+    ids, dist, cnt, _ = hn.search_arrays(db[:2], 50, 10)                        # knbn > nb_point: short lists, padded
+    oix = O.Index(np.float32, 64, 8, 32, seed=0)
+    oix.parallel_insert(db, batch=64)
+    oids, odist, ocnt, _ = oix.parallel_search(db[:2], 50, 10)
+    assert np.array_equal(cnt, ocnt) and (cnt <= 12).all() and np.array_equal(ids, oids) and np.array_equal(dist, odist)
+    for i in range(2):
+        assert (ids[i, cnt[i]:] == np.iinfo(np.uint64).max).all() and np.isinf(dist[i, cnt[i]:]).all()
+    with pytest.raises(G.GsError) as e:
+        hn.search_arrays(db[:1], 5, 200000)
+    assert e.value.code == -3
+    h2 = G.Hnsw.new(8, 1000, 16, 8, dh)                                         # efc <= 2M with extend_candidates: refused, not approximated
+    h2.set_extend_candidates(True)
+    with pytest.raises(G.GsError) as e:
+        h2.parallel_insert(db)
+    assert e.value.code == -3
+    with pytest.raises(G.GsError):
+        G.Hnsw.new(300, 1000, 16, 32, dh).parallel_insert(db)                   # max_nb_conn > 255 (gsearch.rs:268)
