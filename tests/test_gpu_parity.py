@@ -441,3 +441,37 @@ def test_edge_cases_and_error_behaviour(gpu_ctx):
     assert e.value.code == -3
     with pytest.raises(G.GsError):
         G.Hnsw.new(300, 1000, 16, 32, dh).parallel_insert(db)                   # max_nb_conn > 255 (gsearch.rs:268)
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE sizes (k=21, s=18000, Mbp genomes, M=128, efc=1600, ef=5000, n=50) checked through size-independent properties:
+    strand / record-order invariance, slot-wise-min mergeability, d(x,x)=0, sortedness, self-retrieval, and distances that agree
+    with an independent DistHamming evaluation of the returned ids."""
+    import gsearch_amd as G
+    rng = np.random.default_rng(123)
+    k, m = 21, 18000
+    roots = [H.rand_dna(rng, 1_000_000) for _ in range(3)]
+    genomes = [[H.dna_ascii(H.mutate(rng, roots[i % 3], 0.002 * (1 + i // 3)))] for i in range(60)]
+    sk = G.OptDensHashSketch.new(G.SeqSketcherParams(k, m, "optdens"))
+    sig = sk.sketch_genomes(genomes)
+    assert ((sig >= 0) & (sig < 1)).all()
+    g0 = genomes[0][0]
+    extra = sk.sketch_genomes([[H.revcomp_ascii(g0)], [g0[:400000], g0[400000 - 20:]], [g0[400000 - 20:], g0[:400000]], [g0[:500000]], [g0[500000 - 20:]]])
+    assert np.array_equal(extra[0], sig[0])                              # reverse complement
+    assert np.array_equal(extra[1], sig[0]) and np.array_equal(extra[2], sig[0])     # record split / order
+    assert np.array_equal(np.minimum(extra[3], extra[4]), sig[0])        # mergeability of the slot-wise minimum
+    dh = G.DistHamming()
+    D = dh.eval_qxc(sig[:8], sig)
+    assert (np.diag(D[:, :8]) == 0).all() and np.array_equal(D[:8, :8], D[:8, :8].T)
+    hn = G.Hnsw.new(128, 1_500_000, 16, 1600, dh, seed=5)
+    hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+    hn.parallel_insert(sig)
+    ids, dist, cnt, ev = hn.search_arrays(sig[:16], 50, 5000)
+    assert (np.diff(dist[:, :cnt.min()], axis=1) >= 0).all()            # ascending
+    assert np.array_equal(ids[:, 0], np.arange(16, dtype=np.uint64)) and (dist[:, 0] == 0).all()   # every point retrieves itself first
+    for i in range(4):                                                   # reported distances == independent evaluation of the reported ids
+        n = int(cnt[i])
+        pairs = dh.eval_pairs(sig[:16], sig, np.full(n, i), ids[i, :n])
+        assert np.array_equal(pairs, dist[i, :n])
+    d01 = float(dist[0, 1])
+    assert abs(G.ani(d01, k) - (1 + np.log(2 * (1 - d01) / (2 - d01)) / k) * 100) < 1e-6      # ANI within 1e-6 (reformat.rs:80-86)
