@@ -427,6 +427,7 @@ def main():
         run_request(args, torch, rank, world, local)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
+        dist.barrier()                      # rank 0 may still be timing the CPU baseline: leave together
         dist.destroy_process_group()
 
 
