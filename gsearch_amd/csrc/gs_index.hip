@@ -993,6 +993,87 @@ static bool dense_pays(const gs_index *ix, double frac, uint64_t nq)
     return dense < gather;
 }
 
+// ---- how the dense count matrix is produced: equi-join over a column-major copy (gs_join.hip) or the compare tile kernel
+static bool use_join(const gs_index *ix)
+{
+    const char *e = getenv("GS_DENSE_IMPL");
+    if (e && !strcmp(e, "tile")) return false;
+    return ix->prm.m <= 65535;
+}
+// column-major copy of the signatures of nodes [0, upto): rebuilt when the capacity changed, appended otherwise
+static int ensure_cols(gs_index *ix, uint64_t upto)
+{
+    gs_ctx *c = ix->ctx;
+    int rc;
+    if (ix->cols_cap != ix->cap || !ix->cols.p) {
+        if ((rc = ix->cols.alloc((size_t)ix->prm.m * ix->cap * ix->esz))) return rc;
+        ix->cols_cap = ix->cap; ix->cols_n = 0;
+    }
+    if (ix->cols_n < upto) {
+        if ((rc = rows_to_cols(c, ix->prm.kind, ix->prm.m, ix->data.as<uint8_t>() + ix->cols_n * ix->stride, ix->stride, upto - ix->cols_n, ix->cols.p, ix->cols_cap, ix->cols_n))) return rc;
+        ix->cols_n = upto;
+    }
+    return GS_OK;
+}
+// counts of nq padded query rows against nodes [0, n): out16[q * ld + e]
+static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_t n, uint16_t *out16, uint64_t ld)
+{
+    gs_ctx *c = ix->ctx;
+    int rc;
+    if (!use_join(ix))
+        return hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows, nq, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16, ld);
+    if ((rc = ensure_cols(ix, n))) return rc;
+    for (uint64_t q0 = 0; q0 < nq; q0 += 4096) {
+        const uint64_t nb = std::min<uint64_t>(4096, nq - q0);
+        if ((rc = match_join_counts(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch))) return rc;
+    }
+    return GS_OK;
+}
+
+static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t mat_ld, uint64_t *ids, float *dist,
+                               uint32_t *count, uint64_t *evals)
+{
+    gs_ctx *c = ix->ctx;
+    const uint32_t efs = std::max(ef, knbn);
+    const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
+    const size_t lds = dense_lds_bytes(efs, maxdeg);
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024 - 1024) / lds));
+    const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
+    const uint32_t capC = 2 * efs + 2 * (uint32_t)DCN + maxdeg + 64;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu * per_cu);
+    int rc;
+    if ((rc = ix->visited.ensure((size_t)4 * vis_words * c->n_cu * 3))) return rc;
+    if ((rc = ix->cbuf.ensure((size_t)16 * capC * c->n_cu * 3))) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
+    IndexDev d = index_dev(ix);
+    unsigned long long *prof = nullptr;
+    DevBuf profbuf;
+    if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(64))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 64, c->stream)); prof = profbuf.as<unsigned long long>(); }
+    {
+    ProfScope ps(c, FAM_SEARCH);
+#define GS_LAUNCH_DSEARCH(K)                                                                                              \
+    do {                                                                                                                  \
+        auto kern = k_hnsw_search_dense<K>;                                                                               \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), vis_words, \
+                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof);  \
+    } while (0)
+    if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_DSEARCH(GS_KIND_F32);
+    else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_DSEARCH(GS_KIND_U32);
+    else GS_LAUNCH_DSEARCH(GS_KIND_U64);
+#undef GS_LAUNCH_DSEARCH
+    }
+    GS_HIP_CHECK(hipGetLastError());
+    if (prof) {
+        unsigned long long h[8];
+        GS_HIP_CHECK(hipMemcpyAsync(h, prof, 64, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[GS_TRAV_PROFILE] workgroup 0: pops %llu merges %llu | cycles/pop: loads+atomics issue->ballot %.0f, sync1 %.0f, compaction+sync2 %.0f, accept rule+count %.0f | merge cycles/merge %.0f\n",
+                h[5], h[6], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], h[6] ? (double)h[4] / h[6] : 0.0);
+    }
+    return GS_OK;
+}
+
 static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t mat_ld,
                          uint64_t *ids, float *dist, uint32_t *count, uint64_t *evals)
 {
