@@ -475,3 +475,27 @@ def test_full_size_properties(gpu_ctx):
         assert np.array_equal(pairs, dist[i, :n])
     d01 = float(dist[0, 1])
     assert abs(G.ani(d01, k) - (1 + np.log(2 * (1 - d01) / (2 - d01)) / k) * 100) < 1e-6      # ANI within 1e-6 (reformat.rs:80-86)
+
+
+@pytest.mark.parametrize("dtype,m,impl", [(np.uint64, 97, "join"), (np.uint32, 130, "join"), (np.uint64, 97, "tile"), (np.float32, 75, "tile")])
+def test_dense_strategies_for_every_signature_kind(gpu_ctx, monkeypatch, dtype, m, impl):
+    """match-join and compare-tile producers of the dense count matrix, for u64 / u32 / f32 signatures and odd sizes (n=1201)"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_DENSE_IMPL", impl)
+    db = H.synth_sig_db(30, 40, m, 55, dtype=dtype, jlo=0.02, jhi=0.9)[:1201]
+    if dtype == np.float32:                                   # float `==` corner cases inside the index: -0.0 == +0.0, NaN != NaN
+        db[5, :10] = -0.0; db[6, :10] = 0.0; db[7, 3] = np.nan; db[8, 3] = np.nan
+    oix = O.Index(dtype, m, 12, 48, seed=4)
+    oix.parallel_insert(db, batch=100)
+    hn = G.Hnsw.new(12, 100000, 16, 48, G.DistHamming(), dtype=dtype, seed=4, insert_batch=100)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    g, og = hn.export_graph(), oix.export()
+    assert np.array_equal(g["deg0"], og["deg0"])
+    for i in range(len(db)):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]) and np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d])
+    q = np.concatenate([H.queries_from(db, 150, 3, frac=0.2), db[5:9]])
+    got, want = hn.search_arrays(q, 15, 300), oix.parallel_search(q, 15, 300)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
