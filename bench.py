@@ -304,7 +304,9 @@ def run_request(args, torch, rank, world, local):
                 kd.update({"pair_elements_per_sec": pairs_total * m / (tile_ms * 1e-3), "valu_peak_pair_elements_per_sec": valu_peak,
                            "valu_frac": pairs_total * m / (tile_ms * 1e-3) / valu_peak})
             kernels.append(kd)
-        kernels.append({"kernel": "k_hnsw_search", "role": "HNSW traversal (gather mode streams rows, dense mode looks counts up)", "total_ms": srch_ms,
+        kernels.append({"kernel": "k_hnsw_search_dense" if tile_n else "k_hnsw_search",
+                        "role": "HNSW traversal (dense mode: looks the counts up in the query x node matrix)" if tile_n else "HNSW traversal (gather mode: streams one row per evaluation)",
+                        "total_ms": srch_ms,
                         "launches": srch_n, "avg_launch_ms": srch_ms / max(srch_n, 1),
                         "algorithmic_bytes_per_launch": evals_total / max(srch_n, 1) * row_bytes,
                         "achieved_GBps": evals_total * row_bytes / (srch_ms * 1e-3) / 1e9 if srch_ms > 0 else 0.0})
@@ -345,7 +347,12 @@ def run_request(args, torch, rank, world, local):
                 os.environ["GS_DIST_MODE"] = prev_mode
         # physical HBM traffic per launch from the committed rocprofv3 PMC summary of this same workload (separate --pmc passes)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom["kernel"])
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            pmc = pmc_all.get(dom["kernel"])
+            if N == 300000 and qps == 2500 and m == 18000:
+                for kk in kernels:
+                    if kk["kernel"] in pmc_all:
+                        kk["pmc_hbm_bytes_per_launch"] = pmc_all[kk["kernel"]]["hbm_bytes_per_launch"]
             if pmc and N == 300000 and qps == 2500 and m == 18000:
                 out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"

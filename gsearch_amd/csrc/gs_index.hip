@@ -314,42 +314,82 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
 }
 
 // ======================================================================================================
-// Dense-mode traversal (DESIGN.md 3.5): all counts of the query against every node are in `matrow`, so an iteration is pure
-// latency (adjacency load, visited test, lookup). To overlap that latency the kernel runs THREE 512-lane workgroups per CU:
-// R stays in LDS (8 ef bytes), the candidate array C lives in global memory (ping-pong buffers, read through a 64-key LDS
-// window; it is only rewritten when an expansion accepts something — rare once R is saturated by ties).
-// Semantics identical to search_layer_block (same closed-form accept rule, same merges, same pruning of dead candidates).
+// Dense-mode traversal (DESIGN.md 3.6): all counts of the query against every node are in `matrow`, so an iteration is pure
+// latency (adjacency load, visited test, lookup). To overlap that latency the kernel runs THREE 512-lane workgroups per CU.
+//
+// The result set R is NOT kept as a sorted key array here. The accept rule of search_layer_block only needs, of R, the
+// multiset of its counts (rank queries, worst count, number of keys tied at the worst count), and the answer only needs the
+// knbn smallest keys ever accepted (R is always "the ef smallest accepted keys", so its head is exactly that). So R becomes
+//   H  : u16 histogram of the counts in R (m+1 bins, LDS), H1 : per-64-bin block sums, registers dmax / tieT / nR
+//   T  : sorted array of the min(knbn, nR) smallest keys (LDS)
+// which turns the O(ef) merge per accepting expansion into O(#accepted) histogram updates. Dropping the largest keys of a
+// full R = decrementing the top bins. Candidates: sorted bulk array G (global ping-pong, read through a 64-key LDS window) plus
+// the small sorted LDS array N that receives the accepted keys. Semantics identical to search_layer_block (same closed-form
+// accept rule, same pruning of dead candidates) - ids, distances and evaluation counts are bit-identical.
 // ======================================================================================================
 constexpr int DT = 512;           // lanes per dense-mode workgroup
 constexpr int DWIN = 64;          // keys of C mirrored in LDS
-constexpr int DMAXI = 16;         // staged R keys per lane in a merge (ef <= DMAXI*DT)
 constexpr int DCN = 192;          // capacity of the LDS-resident candidate buffer N (<= DT - 2M so a fold fits one key per lane)
-struct DenseLds { uint64_t *R, *A, *As, *W, *N; uint32_t *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
-__host__ __device__ inline size_t dense_lds_bytes(uint32_t ef, uint32_t maxdeg)
+constexpr int TMAXI = 2;          // staged T keys per lane in a merge (knbn <= TMAXI*DT)
+constexpr int HB = 64;            // histogram bins per H1 block
+struct DenseLds { uint64_t *T, *A, *As, *W, *N; uint32_t *H, *H1, *P1, *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
+__host__ __device__ inline uint32_t dense_nblocks(uint32_t m) { return m / HB + 1; }
+__host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uint32_t maxdeg)
 {
-    return 8 * (size_t)ef + 16 * (size_t)maxdeg + 8 * DWIN + 8 * ((size_t)DCN + maxdeg) + 4 * (size_t)maxdeg * 2 + 4 * ((size_t)DCN + maxdeg + 8) + 4 * (DT / 64) + 64 + 64;
+    const size_t nb = dense_nblocks(m);
+    return 8 * (size_t)((knbn + 1) & ~1u) + 16 * (size_t)maxdeg + 8 * DWIN + 8 * ((size_t)DCN + maxdeg) + 64 + 4 * nb * (HB / 2) + 8 * nb + 4 * (size_t)maxdeg * 2 +
+           4 * ((size_t)DCN + maxdeg + 8) + 4 * (DT / 64) + 64;
 }
-__device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t ef, uint32_t maxdeg)
+__device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg)
 {
     DenseLds S;
-    S.R = (uint64_t *)base; base += 8 * (size_t)ef;
+    const size_t nb = dense_nblocks(m);
+    S.T = (uint64_t *)base; base += 8 * (size_t)((knbn + 1) & ~1u);
     S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
     S.As = (uint64_t *)base; base += 8 * (size_t)maxdeg;
     S.W = (uint64_t *)base; base += 8 * DWIN;
     S.N = (uint64_t *)base; base += 8 * ((size_t)DCN + maxdeg);
     S.scal = (uint64_t *)base; base += 64;
+    S.H = (uint32_t *)base; base += 4 * nb * (HB / 2);
+    S.H1 = (uint32_t *)base; base += 4 * nb;
+    S.P1 = (uint32_t *)base; base += 4 * nb;
     S.Eid = (uint32_t *)base; base += 4 * (size_t)maxdeg;
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
     S.hist = (uint32_t *)base; base += 4 * ((size_t)DCN + maxdeg + 8);
     S.wsum = (uint32_t *)base;
     return S;
 }
-// in-LDS merge of sorted A into sorted R[0..n) keeping `keep` keys (DT lanes)
-__device__ __forceinline__ uint32_t dense_merge_R(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep, const SmallA &sa)
+__device__ __forceinline__ uint32_t hget(const uint32_t *H, uint32_t b) { return (H[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu; }
+__device__ __forceinline__ void hadd(uint32_t *H, uint32_t b, uint32_t v) { atomicAdd(&H[b >> 1], v << ((b & 1) * 16)); }
+__device__ __forceinline__ void hsub(uint32_t *H, uint32_t b, uint32_t v) { atomicSub(&H[b >> 1], v << ((b & 1) * 16)); }
+// one wave: highest non-empty bin <= d (d wave-uniform); 0 when the histogram is empty below d
+__device__ __forceinline__ uint32_t hist_find_down(const uint32_t *H, const uint32_t *H1, uint32_t d, uint32_t lane)
 {
-    uint64_t kv[DMAXI]; uint32_t pos[DMAXI];
+    uint32_t blk = d / HB;
+    {
+        const uint32_t b = blk * HB + lane;
+        const uint32_t v = b <= d ? hget(H, b) : 0;
+        const uint64_t bal = __ballot(v != 0);
+        if (bal) return blk * HB + (63 - (uint32_t)__clzll((long long)bal));
+    }
+    for (int base = (int)blk - 1; base >= 0; base -= 64) {
+        const int bi = base - (int)lane;
+        const uint32_t v = bi >= 0 ? H1[bi] : 0;
+        const uint64_t bal = __ballot(v != 0);
+        if (bal) {
+            blk = (uint32_t)base - (uint32_t)(__ffsll((long long)bal) - 1);
+            const uint64_t b2 = __ballot(hget(H, blk * HB + lane) != 0);
+            return b2 ? blk * HB + (63 - (uint32_t)__clzll((long long)b2)) : 0;
+        }
+    }
+    return 0;
+}
+// merge sorted A (na <= DT keys) into the sorted T[0..n) keeping `keep` keys (DT lanes)
+__device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep, const SmallA &sa)
+{
+    uint64_t kv[TMAXI]; uint32_t pos[TMAXI];
 #pragma unroll
-    for (int it = 0; it < DMAXI; it++) {
+    for (int it = 0; it < TMAXI; it++) {
         const uint32_t idx = threadIdx.x + it * DT;
         pos[it] = 0xFFFFFFFFu; kv[it] = 0;
         if (idx < n) { const uint64_t k = keys[idx]; kv[it] = k; pos[it] = idx + lb_a(sa, k); }
@@ -358,7 +398,7 @@ __device__ __forceinline__ uint32_t dense_merge_R(uint64_t *keys, uint32_t n, co
     if (threadIdx.x < na) { ak = A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(keys, n, ak); }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < DMAXI; it++) if (pos[it] < keep) keys[pos[it]] = kv[it];
+    for (int it = 0; it < TMAXI; it++) if (pos[it] < keep) keys[pos[it]] = kv[it];
     if (apos < keep) keys[apos] = ak;
     __syncthreads();
     const uint32_t tot = n + na;
@@ -374,8 +414,9 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t efs = ef > knbn ? ef : knbn;
+    const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2);
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
-    DenseLds S = carve_dense(s_raw, efs, maxdeg);
+    DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg);
     uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
     uint64_t *Cb[2] = {cbuf + (uint64_t)blockIdx.x * 2 * capC, cbuf + (uint64_t)blockIdx.x * 2 * capC + capC};
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -387,6 +428,8 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         if (qi >= nq) break;
         const uint16_t *matrow = mat + qi * mat_ld;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
+        for (uint32_t w = threadIdx.x; w < hwords; w += DT) S.H[w] = 0;
+        for (uint32_t w = threadIdx.x; w < nb; w += DT) S.H1[w] = 0;
         uint64_t evals = 1;
         uint32_t ep = (uint32_t)ix.entry, ep_cnt = matrow[ep];
         // greedy descent on the upper layers (hnsw_rs::search outer loop)
@@ -406,17 +449,20 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 ep = nbr[KID(best)]; ep_cnt = KCNT(best);
             }
         }
-        // ---- search_layer on layer 0.  Candidates = sorted bulk array G (global, read through the LDS window W) + small sorted
-        //      array N (LDS) that receives the accepted keys; N is folded into G only when it is full. The next candidate is
-        //      min(head of G, head of N) under the same (count,id) order, so the pop sequence is unchanged.
+        // ---- search_layer on layer 0. The next candidate is min(head of G, head of N) under the same (count,id) order, so the
+        //      pop sequence is that of search_layer_block.
         int cur = 0;
-        uint32_t nR = 1, nG = 0, headG = 0, wbase = 0, wn = 0, nN = 1, headN = 0;
-        uint32_t tieT = 0;                                       // #keys of a full R tied at its worst count
+        uint32_t nR = 1, nT = 1, nG = 0, headG = 0, wbase = 0, wn = 0, nN = 1, headN = 0;
+        uint32_t dmax = INF_CNT, tieT = 0;                       // worst count of a full R / #keys of R tied at it
+        uint64_t Tmax = 0;                                       // T[knbn-1] once T is full
         __syncthreads();
         if (threadIdx.x == 0) {
-            S.R[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
+            S.T[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
+            hadd(S.H, ep_cnt, 1); S.H1[ep_cnt / HB] = 1;
             __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        if (efs == 1) { dmax = ep_cnt; tieT = 1; }
+        if (knbn == 1) Tmax = KEY(ep_cnt, ep);
         __syncthreads();
         uint64_t pre_c = ~(uint64_t)0; uint32_t pre_id = 0, pre_deg = 0;
         for (;;) {
@@ -430,8 +476,8 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             const uint64_t cn = headN < nN ? S.N[headN] : ~(uint64_t)0;
             const uint64_t c = cg < cn ? cg : cn;
             if (c == ~(uint64_t)0) break;
-            const uint32_t dmax = (nR == efs) ? KCNT(S.R[efs - 1]) : INF_CNT;
-            if (KCNT(c) > dmax) break;
+            const bool full = nR == efs;
+            if (KCNT(c) > dmax) break;                               // dmax is INF_CNT until R is full
             if (cg < cn) headG++; else headN++;
             const long long p0 = prof ? clock64() : 0;
             uint32_t id, deg;
@@ -440,9 +486,9 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             bool unv = false; uint32_t cntv = 0;
             if (threadIdx.x < deg) {
                 const uint32_t bit = 1u << (id & 31);
-                cntv = matrow[id];
                 const uint32_t old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 unv = !(old & bit);
+                if (unv) cntv = matrow[id];        // lookup only for the unvisited: every 2-byte lookup costs a full HBM sector
             }
             {   // prefetch the adjacency of the candidate that follows if this expansion accepts nothing
                 const uint64_t g2 = (headG < nG && headG - wbase < wn) ? S.W[headG - wbase] : ~(uint64_t)0;
@@ -469,34 +515,63 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             evals += ne;
             uint64_t mykey = ~(uint64_t)0; bool acc = false;
             uint32_t na;
+            const uint32_t ci = threadIdx.x < ne ? S.Ecnt[threadIdx.x] : INF_CNT;
             {
-                // closed-form accept rule.  Fast path once R is full: a candidate is accepted iff c_i < dmax and
-                // #{x in R: c(x) <= c_i} + #{j<i: c_j <= c_i} < ef. With T = #{x in R: c(x) == dmax} keys tied at the tail,
-                // the first term is <= ef - T for c_i < dmax, so if the B candidates below dmax number <= T all of them pass.
-                const uint32_t ci = threadIdx.x < ne ? S.Ecnt[threadIdx.x] : INF_CNT;
-                const bool below = nR == efs && threadIdx.x < ne && ci < dmax;
-                const uint32_t B = nR == efs ? (uint32_t)__syncthreads_count(below) : 0xFFFFFFFFu;
-                if (B == 0) { na = 0; }
-                else if (B <= tieT) { acc = below; na = B; if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]); }
-                else {
-                    if (threadIdx.x < ne && !(nR == efs && ci >= dmax)) {
-                        uint32_t le = lower_bound_keys(S.R, nR, KEY(ci, 0xFFFFFFFFu));
+                // closed-form accept rule: e_i is accepted iff #{x in R: c(x) <= c_i} + #{j<i: c_j <= c_i} < ef (and c_i < dmax once
+                // R is full). Shortcuts: R not full and nR + ne <= ef -> everything passes; R full with T keys tied at dmax and
+                // B <= T candidates below dmax -> the first term is <= ef - T, all B pass.
+                bool slow = false;
+                if (!full) {
+                    if (nR + ne <= efs) { acc = threadIdx.x < ne; na = ne; }
+                    else slow = true;
+                } else {
+                    const bool below = threadIdx.x < ne && ci < dmax;
+                    const uint32_t B = (uint32_t)__syncthreads_count(below);
+                    if (B == 0) na = 0;
+                    else if (B <= tieT) { acc = below; na = B; }
+                    else slow = true;
+                }
+                if (slow) {
+                    // exclusive prefix of the block sums, then rank = P1[block] + bins of the block up to c_i
+                    const uint32_t CH = (nb + DT - 1) / DT;
+                    uint32_t loc = 0;
+                    for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) loc += S.H1[idx]; }
+                    uint32_t inc = loc;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+                    if (lane == 63) S.wsum[wv] = inc;
+                    __syncthreads();
+                    uint32_t woff = 0;
+#pragma unroll
+                    for (int w = 0; w < DT / 64; w++) if (w < (int)wv) woff += S.wsum[w];
+                    uint32_t run = woff + inc - loc;
+                    for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) { S.P1[idx] = run; run += S.H1[idx]; } }
+                    __syncthreads();
+                    if (threadIdx.x < ne && ci < dmax) {
+                        uint32_t le = S.P1[ci / HB];
+                        const uint32_t w1 = ci >> 1;
+                        for (uint32_t w = (ci / HB) * (HB / 2); w <= w1; w++) {
+                            const uint32_t x = S.H[w];
+                            le += x & 0xFFFFu;
+                            if (w < w1 || (ci & 1)) le += x >> 16;
+                        }
                         if (le < efs) {
 #pragma unroll 8
                             for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
                         }
                         acc = le < efs;
-                        if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
                     }
                     na = (uint32_t)__syncthreads_count(acc);
                 }
+                if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
             }
             const long long p4 = prof ? clock64() : 0;
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_d += p4 - p3;
             if (na == 0) continue;
             n_merge++;
-            // accepted keys: compact (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
+            // accepted keys: histogram update, compaction (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
             {
+                if (acc) { hadd(S.H, ci, 1); atomicAdd(&S.H1[ci / HB], 1u); }
                 const uint64_t ab = __ballot(acc);
                 if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(ab);
                 __syncthreads();
@@ -514,11 +589,41 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 }
                 __syncthreads();
             }
-            // R <- ef smallest of R u A
+            // R <- ef smallest of R u A: drop the (nR + na - ef) largest counts from the top bins
+            if (nR + na >= efs) {
+                const uint32_t excess = nR + na - efs;
+                if (full && excess < tieT) {
+                    if (threadIdx.x == 0 && excess) { hsub(S.H, dmax, excess); atomicSub(&S.H1[dmax / HB], excess); }
+                    tieT -= excess;
+                } else {
+                    if (threadIdx.x < 64) {
+                        uint32_t d = full ? dmax : ix.m, ex = excess, tt;
+                        for (;;) {
+                            d = hist_find_down(S.H, S.H1, d, lane);
+                            tt = hget(S.H, d);
+                            if (ex == 0) break;
+                            const uint32_t r = ex < tt ? ex : tt;
+                            if (lane == 0) { hsub(S.H, d, r); atomicSub(&S.H1[d / HB], r); }
+                            __threadfence_block();
+                            ex -= r;
+                            if (r < tt) { tt -= r; break; }
+                            if (d == 0) { tt = 0; break; }
+                            d -= 1;
+                        }
+                        if (lane == 0) { S.scal[2] = d; S.scal[3] = tt; }
+                    }
+                    __syncthreads();
+                    dmax = (uint32_t)S.scal[2]; tieT = (uint32_t)S.scal[3];
+                }
+                nR = efs;
+            } else nR += na;
+            const uint32_t dnew = dmax;                              // INF_CNT while R is not full
             const SmallA sa = load_small_a(S.A, na);
-            nR = dense_merge_R(S.R, nR, S.A, na, efs, sa);
-            const uint32_t dnew = (nR == efs) ? KCNT(S.R[efs - 1]) : INF_CNT;
-            tieT = nR == efs ? efs - lower_bound_keys(S.R, nR, KEY(dnew, 0)) : 0;
+            // T <- knbn smallest of T u A (only when A reaches into it)
+            if (nT < knbn || S.A[0] < Tmax) {
+                nT = dense_merge_T(S.T, nT, S.A, na, knbn, sa);
+                if (nT == knbn) Tmax = S.T[knbn - 1];
+            }
             // ---- N full? fold its live part into G first (rare): G' = live G u live N, dead tail dropped
             if (nN - headN + na > (uint32_t)DCN) {
                 const uint32_t liveN = nN - headN, liveG = nG - headG;
@@ -571,12 +676,11 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_e += clock64() - p4;
         }
         __syncthreads();
-        const uint32_t nout = nR < knbn ? nR : knbn;
         for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
-            if (i < nout) { ids_out[qi * knbn + i] = KID(S.R[i]); dist_out[qi * knbn + i] = (float)KCNT(S.R[i]) / (float)ix.m; }
+            if (i < nT) { ids_out[qi * knbn + i] = KID(S.T[i]); dist_out[qi * knbn + i] = (float)KCNT(S.T[i]) / (float)ix.m; }
             else { ids_out[qi * knbn + i] = ~(uint64_t)0; dist_out[qi * knbn + i] = INFINITY; }
         }
-        if (threadIdx.x == 0) { if (count_out) count_out[qi] = nout; if (evals_out) evals_out[qi] = evals; }
+        if (threadIdx.x == 0) { if (count_out) count_out[qi] = nT; if (evals_out) evals_out[qi] = evals; }
     }
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
@@ -1036,7 +1140,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
-    const size_t lds = dense_lds_bytes(efs, maxdeg);
+    const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg);
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024 - 1024) / lds));
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
     const uint32_t capC = 2 * efs + 2 * (uint32_t)DCN + maxdeg + 64;
@@ -1080,7 +1184,8 @@ static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq,
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
-    if (mat && maxdeg <= (uint32_t)DT && efs <= (uint32_t)(DMAXI * DT) && dense_lds_bytes(efs, maxdeg) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
+    if (mat && maxdeg <= (uint32_t)DT && efs <= 65535u && knbn <= (uint32_t)(TMAXI * DT) && ix->prm.m <= 65535u &&
+        dense_lds_bytes(ix->prm.m, knbn, maxdeg) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
         return search_launch_dense(ix, nq, knbn, ef, mat, mat_ld, ids, dist, count, evals);
     const size_t lds = search_lds_bytes(efs, maxdeg);
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
