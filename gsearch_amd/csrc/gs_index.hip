@@ -315,74 +315,124 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
 
 // ======================================================================================================
 // Dense-mode traversal: all counts of the query against every node are in `matrow`, so an iteration is pure
-// latency (adjacency load, visited test, lookup). To overlap that latency the kernel runs THREE 512-lane workgroups per CU.
+// latency (adjacency load, visited test, lookup) and the kernel runs up to THREE 512-lane workgroups per CU to overlap it.
 //
 // The result set R is NOT kept as a sorted key array here. The accept rule of search_layer_block only needs, of R, the
 // multiset of its counts (rank queries, worst count, number of keys tied at the worst count), and the answer only needs the
 // knbn smallest keys ever accepted (R is always "the ef smallest accepted keys", so its head is exactly that). So R becomes
-//   H  : u16 histogram of the counts in R (m+1 bins, LDS), H1 : per-64-bin block sums, registers dmax / tieT / nR
-//   T  : sorted array of the min(knbn, nR) smallest keys (LDS)
-// which turns the O(ef) merge per accepting expansion into O(#accepted) histogram updates. Dropping the largest keys of a
+//   Hf : u16 histogram of the counts in R (one bin per count), H2 : sums per 8 bins, H1 : sums per 64 bins,
+//        registers dmax / tieT / nR;   T : sorted array of the min(knbn, nR) smallest keys (LDS)
+// which turns the O(ef) merge per accepting expansion into O(#accepted) histogram updates; dropping the largest keys of a
 // full R = decrementing the top bins. Candidates: sorted bulk array G (global ping-pong, read through a 64-key LDS window) plus
-// the small sorted LDS array N that receives the accepted keys. Semantics identical to search_layer_block (same closed-form
-// accept rule, same pruning of dead candidates) - ids, distances and evaluation counts are bit-identical.
+// the small sorted LDS array N that receives the accepted keys.
+//
+// Two placements (template VLDS), chosen on the host by what fits in LDS:
+//   VLDS = true : visited bitmap in LDS (n/8 bytes), Hf in global (the hot path only sends fire-and-forget atomics to it; H1/H2
+//                 stay in LDS). A visited bitmap in global memory costs one L2 atomic per neighbour and, with ~100 bitmaps per
+//                 XCD, thrashes the L2 (rocprofv3: 101 GB of write-backs per 2500-query launch) - in LDS it is free, and cheap
+//                 enough to read ahead, so the lookups of the NEXT candidate are prefetched while the current one is expanded.
+//   VLDS = false: visited bitmap in global, Hf in LDS (large n).
+// Semantics identical to search_layer_block (same closed-form accept rule, same pruning of dead candidates): ids, distances
+// and evaluation counts are bit-identical.
 // ======================================================================================================
-constexpr int DT = 512;           // lanes per dense-mode workgroup
+constexpr int DT = 512;           // lanes per dense-mode workgroup (two halves of 256: maxdeg <= 256)
 constexpr int DWIN = 64;          // keys of C mirrored in LDS
-constexpr int DCN = 192;          // capacity of the LDS-resident candidate buffer N (<= DT - 2M so a fold fits one key per lane)
+constexpr int DCN = 192;          // capacity of the LDS-resident candidate buffer N
 constexpr int TMAXI = 2;          // staged T keys per lane in a merge (knbn <= TMAXI*DT)
-constexpr int HB = 64;            // histogram bins per H1 block
-struct DenseLds { uint64_t *T, *A, *As, *W, *N; uint32_t *H, *H1, *P1, *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
+constexpr int HB = 64;            // histogram bins per H1 block (8 groups of 8 bins)
+struct DenseLds { uint64_t *T, *A, *As, *W, *N; uint32_t *Hf, *H2, *H1, *P1, *vis, *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
 __host__ __device__ inline uint32_t dense_nblocks(uint32_t m) { return m / HB + 1; }
-__host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uint32_t maxdeg)
+__host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
 {
     const size_t nb = dense_nblocks(m);
-    return 8 * (size_t)((knbn + 1) & ~1u) + 16 * (size_t)maxdeg + 8 * DWIN + 8 * ((size_t)DCN + maxdeg) + 64 + 4 * nb * (HB / 2) + 8 * nb + 4 * (size_t)maxdeg * 2 +
-           4 * ((size_t)DCN + maxdeg + 8) + 4 * (DT / 64) + 64;
+    size_t histb = 4 * ((size_t)DCN + maxdeg + 8); if (histb < 4 * nb) histb = 4 * nb;          // fold histogram, aliased by P1
+    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * DWIN + 8 * ((size_t)DCN + maxdeg) + 64 + 4 * nb * 4 /*H2*/ + 4 * nb /*H1*/ +
+           8 * (size_t)maxdeg /*Eid,Ecnt (aliased by As)*/ + histb + 4 * (DT / 64) + 64 + (vlds ? 4 * (size_t)((n + 31) / 32 + 1) : 4 * nb * (HB / 2));
 }
-__device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg)
+__device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
 {
     DenseLds S;
     const size_t nb = dense_nblocks(m);
+    size_t histb = 4 * ((size_t)DCN + maxdeg + 8); if (histb < 4 * nb) histb = 4 * nb;
     S.T = (uint64_t *)base; base += 8 * (size_t)((knbn + 1) & ~1u);
     S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
-    S.As = (uint64_t *)base; base += 8 * (size_t)maxdeg;
     S.W = (uint64_t *)base; base += 8 * DWIN;
     S.N = (uint64_t *)base; base += 8 * ((size_t)DCN + maxdeg);
     S.scal = (uint64_t *)base; base += 64;
-    S.H = (uint32_t *)base; base += 4 * nb * (HB / 2);
-    S.H1 = (uint32_t *)base; base += 4 * nb;
-    S.P1 = (uint32_t *)base; base += 4 * nb;
-    S.Eid = (uint32_t *)base; base += 4 * (size_t)maxdeg;
+    S.Eid = (uint32_t *)base; S.As = (uint64_t *)base; base += 4 * (size_t)maxdeg;     // As (compaction of accepted keys) reuses Eid/Ecnt, dead by then
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
-    S.hist = (uint32_t *)base; base += 4 * ((size_t)DCN + maxdeg + 8);
-    S.wsum = (uint32_t *)base;
+    S.H2 = (uint32_t *)base; base += 4 * nb * 4;
+    S.H1 = (uint32_t *)base; base += 4 * nb;
+    S.hist = (uint32_t *)base; S.P1 = (uint32_t *)base; base += histb;                  // P1 (slow accept path) and hist (fold) are never live together
+    S.wsum = (uint32_t *)base; base += 4 * (DT / 64) + 64;
+    S.Hf = nullptr; S.vis = nullptr;
+    if (vlds) S.vis = (uint32_t *)base; else S.Hf = (uint32_t *)base;
     return S;
 }
-__device__ __forceinline__ uint32_t hget(const uint32_t *H, uint32_t b) { return (H[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu; }
-__device__ __forceinline__ void hadd(uint32_t *H, uint32_t b, uint32_t v) { atomicAdd(&H[b >> 1], v << ((b & 1) * 16)); }
-__device__ __forceinline__ void hsub(uint32_t *H, uint32_t b, uint32_t v) { atomicSub(&H[b >> 1], v << ((b & 1) * 16)); }
-// one wave: highest non-empty bin <= d (d wave-uniform); 0 when the histogram is empty below d
-__device__ __forceinline__ uint32_t hist_find_down(const uint32_t *H, const uint32_t *H1, uint32_t d, uint32_t lane)
+// 16-bit counters packed two per word
+__device__ __forceinline__ uint32_t h16(const uint32_t *H, uint32_t b) { return (H[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu; }
+__device__ __forceinline__ void h16add(uint32_t *H, uint32_t b, uint32_t v) { atomicAdd(&H[b >> 1], v << ((b & 1) * 16)); }
+__device__ __forceinline__ void h16sub(uint32_t *H, uint32_t b, uint32_t v) { atomicSub(&H[b >> 1], v << ((b & 1) * 16)); }
+// fine bins: in LDS, or in global memory where they are only ever touched by workgroup-scope atomics (performed in the L2), so a
+// read goes through an atomic as well rather than through the (non-coherent) vector L1
+template <bool VLDS> __device__ __forceinline__ uint32_t hf_word(uint32_t *Hf, uint32_t w)
 {
-    uint32_t blk = d / HB;
-    {
-        const uint32_t b = blk * HB + lane;
-        const uint32_t v = b <= d ? hget(H, b) : 0;
+    if (VLDS) return __hip_atomic_fetch_add(&Hf[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return Hf[w];
+}
+template <bool VLDS> __device__ __forceinline__ uint32_t hf_get(uint32_t *Hf, uint32_t b) { return (hf_word<VLDS>(Hf, b >> 1) >> ((b & 1) * 16)) & 0xFFFFu; }
+struct Hist3 { uint32_t *Hf, *H2, *H1; };
+template <bool VLDS> __device__ __forceinline__ void hist_add(const Hist3 &h, uint32_t c, uint32_t v)
+{
+    if (VLDS) __hip_atomic_fetch_add(&h.Hf[c >> 1], v << ((c & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd(&h.Hf[c >> 1], v << ((c & 1) * 16));
+    h16add(h.H2, c >> 3, v); atomicAdd(&h.H1[c / HB], v);
+}
+template <bool VLDS> __device__ __forceinline__ void hist_sub(const Hist3 &h, uint32_t c, uint32_t v)
+{
+    if (VLDS) __hip_atomic_fetch_sub(&h.Hf[c >> 1], v << ((c & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicSub(&h.Hf[c >> 1], v << ((c & 1) * 16));
+    h16sub(h.H2, c >> 3, v); atomicSub(&h.H1[c / HB], v);
+}
+// one wave: highest non-empty bin <= d (d wave-uniform) and its multiplicity; bin 0 / 0 when there is none
+template <bool VLDS> __device__ __forceinline__ uint32_t hist_find_down(const Hist3 &h, uint32_t d, uint32_t lane, uint32_t &mult)
+{
+    const uint32_t l8 = lane & 7;
+    uint32_t grp = d >> 3;
+    {   // bins of d's own group
+        const uint32_t b = grp * 8 + l8;
+        const uint32_t v = (lane < 8 && b <= d) ? hf_get<VLDS>(h.Hf, b) : 0;
         const uint64_t bal = __ballot(v != 0);
-        if (bal) return blk * HB + (63 - (uint32_t)__clzll((long long)bal));
+        if (bal) { const uint32_t top = 63 - (uint32_t)__clzll((long long)bal); mult = __shfl(v, top); return grp * 8 + top; }
     }
-    for (int base = (int)blk - 1; base >= 0; base -= 64) {
-        const int bi = base - (int)lane;
-        const uint32_t v = bi >= 0 ? H1[bi] : 0;
+    bool found = false;
+    {   // lower groups of d's block
+        const uint32_t blk = d / HB, g = blk * 8 + l8;
+        const uint32_t v = (lane < 8 && g < grp) ? h16(h.H2, g) : 0;
         const uint64_t bal = __ballot(v != 0);
-        if (bal) {
-            blk = (uint32_t)base - (uint32_t)(__ffsll((long long)bal) - 1);
-            const uint64_t b2 = __ballot(hget(H, blk * HB + lane) != 0);
-            return b2 ? blk * HB + (63 - (uint32_t)__clzll((long long)b2)) : 0;
+        if (bal) { grp = blk * 8 + (63 - (uint32_t)__clzll((long long)bal)); found = true; }
+        else {
+            for (int base = (int)blk - 1; base >= 0 && !found; base -= 64) {
+                const int bi = base - (int)lane;
+                const uint32_t v1 = bi >= 0 ? h.H1[bi] : 0;
+                const uint64_t b1 = __ballot(v1 != 0);
+                if (b1) {
+                    const uint32_t blk2 = (uint32_t)base - (uint32_t)(__ffsll((long long)b1) - 1);
+                    const uint32_t v2 = lane < 8 ? h16(h.H2, blk2 * 8 + l8) : 0;
+                    const uint64_t b2 = __ballot(v2 != 0);
+                    if (b2) { grp = blk2 * 8 + (63 - (uint32_t)__clzll((long long)b2)); found = true; }
+                    else base = -1;                       // inconsistent summaries cannot happen; stop
+                }
+            }
         }
     }
-    return 0;
+    if (!found) { mult = 0; return 0; }
+    const uint32_t v = lane < 8 ? hf_get<VLDS>(h.Hf, grp * 8 + l8) : 0;
+    const uint64_t bal = __ballot(v != 0);
+    if (!bal) { mult = 0; return 0; }
+    const uint32_t top = 63 - (uint32_t)__clzll((long long)bal);
+    mult = __shfl(v, top);
+    return grp * 8 + top;
 }
 // merge sorted A (na <= DT keys) into the sorted T[0..n) keeping `keep` keys (DT lanes)
 __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep, const SmallA &sa)
@@ -405,21 +455,24 @@ __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, co
     return tot < keep ? tot : keep;
 }
 
-template <int KIND>
+template <bool VLDS>
 __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
-                                                           uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ cbuf, uint32_t capC,
+                                                           uint32_t *__restrict__ scratch, uint32_t scratch_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
                                                            uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out, unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t efs = ef > knbn ? ef : knbn;
-    const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2);
+    const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
-    DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg);
-    uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
+    DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, ix.n, VLDS);
+    // per-workgroup global scratch: the visited bitmap (VLDS = false) or the fine histogram bins (VLDS = true)
+    uint32_t *vis = VLDS ? S.vis : scratch + (uint64_t)blockIdx.x * scratch_words;
+    Hist3 hs; hs.Hf = VLDS ? scratch + (uint64_t)blockIdx.x * scratch_words : S.Hf; hs.H2 = S.H2; hs.H1 = S.H1;
     uint64_t *Cb[2] = {cbuf + (uint64_t)blockIdx.x * 2 * capC, cbuf + (uint64_t)blockIdx.x * 2 * capC + capC};
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t half = threadIdx.x >> 8, hl = threadIdx.x & 255;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) S.scal[1] = atomicAdd(counter, 1ull);
@@ -428,7 +481,8 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         if (qi >= nq) break;
         const uint16_t *matrow = mat + qi * mat_ld;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
-        for (uint32_t w = threadIdx.x; w < hwords; w += DT) S.H[w] = 0;
+        for (uint32_t w = threadIdx.x; w < hwords; w += DT) hs.Hf[w] = 0;
+        for (uint32_t w = threadIdx.x; w < nb * 4; w += DT) S.H2[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb; w += DT) S.H1[w] = 0;
         uint64_t evals = 1;
         uint32_t ep = (uint32_t)ix.entry, ep_cnt = matrow[ep];
@@ -458,13 +512,22 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         __syncthreads();
         if (threadIdx.x == 0) {
             S.T[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
-            hadd(S.H, ep_cnt, 1); S.H1[ep_cnt / HB] = 1;
-            __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            hist_add<VLDS>(hs, ep_cnt, 1);
+            if (VLDS) vis[ep >> 5] = 1u << (ep & 31);
+            else __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (efs == 1) { dmax = ep_cnt; tieT = 1; }
         if (knbn == 1) Tmax = KEY(ep_cnt, ep);
         __syncthreads();
-        uint64_t pre_c = ~(uint64_t)0; uint32_t pre_id = 0, pre_deg = 0;
+        // Two-stage software pipeline over the pops. The two 256-lane halves of the workgroup alternate roles: on pop i half
+        // (i & 1) expands the candidate while the other half prefetches for pop i+1 - its adjacency and (VLDS) a plain read of
+        // the visited words as a hint plus, where the hint says "unvisited", the count lookup; the expanding half then loads the
+        // adjacency of the candidate after next. Prefetched data is keyed by the candidate it belongs to and is only a hint
+        // (adjacency and counts are constant during a search, visited bits only ever get set), so a wrong prediction costs a
+        // direct load, never a wrong answer.
+        uint64_t pk = ~(uint64_t)0;                              // candidate this half holds data for
+        uint32_t pid = 0, pdeg = 0, pcnt = 0, pst = 0, it = 0;   // pst: 1 = adjacency, 2 = + visited hint and lookups
+        bool pclr = false;
         for (;;) {
             if (headG < nG && headG - wbase >= wn) {                 // refill the LDS window of G
                 __syncthreads();
@@ -480,25 +543,56 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             if (KCNT(c) > dmax) break;                               // dmax is INF_CNT until R is full
             if (cg < cn) headG++; else headN++;
             const long long p0 = prof ? clock64() : 0;
-            uint32_t id, deg;
-            if (pre_c == c) { id = pre_id; deg = pre_deg; }
-            else { const uint32_t *nbr = ix.nbr0 + (uint64_t)KID(c) * maxdeg; deg = ix.deg0[KID(c)]; id = threadIdx.x < maxdeg ? nbr[threadIdx.x] : 0; }
-            bool unv = false; uint32_t cntv = 0;
-            if (threadIdx.x < deg) {
-                const uint32_t bit = 1u << (id & 31);
-                const uint32_t old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                unv = !(old & bit);
-                if (unv) cntv = matrow[id];        // lookup only for the unvisited: every 2-byte lookup costs a full HBM sector
+            // the two candidates that follow in the current order (G beyond its LDS window counts as unknown)
+            uint64_t c1, c2;
+            {
+                uint32_t vg = headG, vn = headN;
+                uint64_t g = (vg < nG && vg - wbase < wn) ? S.W[vg - wbase] : ~(uint64_t)0;
+                uint64_t n2 = vn < nN ? S.N[vn] : ~(uint64_t)0;
+                c1 = g < n2 ? g : n2;
+                if (g < n2) vg++; else vn++;
+                g = (vg < nG && vg - wbase < wn) ? S.W[vg - wbase] : ~(uint64_t)0;
+                n2 = vn < nN ? S.N[vn] : ~(uint64_t)0;
+                c2 = g < n2 ? g : n2;
+                if (c1 == ~(uint64_t)0) c2 = ~(uint64_t)0;
             }
-            {   // prefetch the adjacency of the candidate that follows if this expansion accepts nothing
-                const uint64_t g2 = (headG < nG && headG - wbase < wn) ? S.W[headG - wbase] : ~(uint64_t)0;
-                const uint64_t n2 = headN < nN ? S.N[headN] : ~(uint64_t)0;
-                pre_c = g2 < n2 ? g2 : n2;
-                if (pre_c != ~(uint64_t)0 && !(headG < nG && headG - wbase >= wn)) {
-                    pre_deg = ix.deg0[KID(pre_c)];
-                    pre_id = threadIdx.x < maxdeg ? ix.nbr0[(uint64_t)KID(pre_c) * maxdeg + threadIdx.x] : 0;
-                } else pre_c = ~(uint64_t)0;
-            }
+            uint32_t id = 0, cntv = 0; bool unv = false;
+            if (half == (it & 1)) {
+                if (pk != c) {
+                    pdeg = ix.deg0[KID(c)];
+                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(c) * maxdeg + hl] : 0;
+                    pst = 1;
+                }
+                id = pid;
+                if (hl < pdeg) {
+                    const uint32_t bit = 1u << (id & 31);
+                    uint32_t old;
+                    if (VLDS) old = atomicOr(&vis[id >> 5], bit);
+                    else old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    unv = !(old & bit);
+                    if (unv) cntv = (pst == 2 && pclr) ? pcnt : (uint32_t)matrow[id];   // every 2-byte lookup costs a full HBM sector: only for the unvisited
+                }
+                pk = c2; pst = 1;
+                if (c2 != ~(uint64_t)0) {
+                    pdeg = ix.deg0[KID(c2)];
+                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(c2) * maxdeg + hl] : 0;
+                }
+            } else if (c1 != ~(uint64_t)0) {
+                if (pk != c1) {
+                    pk = c1; pst = 1;
+                    pdeg = ix.deg0[KID(c1)];
+                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(c1) * maxdeg + hl] : 0;
+                }
+                if (VLDS) {
+                    pclr = false;
+                    if (hl < pdeg) {
+                        pclr = !((vis[pid >> 5] >> (pid & 31)) & 1u);
+                        if (pclr) pcnt = matrow[pid];
+                    }
+                    pst = 2;
+                }
+            } else pk = ~(uint64_t)0;
+            it++;
             const uint64_t bal = __ballot(unv);
             const long long p1 = prof ? clock64() : 0;
             if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
@@ -532,7 +626,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                     else slow = true;
                 }
                 if (slow) {
-                    // exclusive prefix of the block sums, then rank = P1[block] + bins of the block up to c_i
+                    // exclusive prefix of the block sums, then rank = P1[block] + groups of the block + bins of the group up to c_i
                     const uint32_t CH = (nb + DT - 1) / DT;
                     uint32_t loc = 0;
                     for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) loc += S.H1[idx]; }
@@ -549,9 +643,10 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                     __syncthreads();
                     if (threadIdx.x < ne && ci < dmax) {
                         uint32_t le = S.P1[ci / HB];
-                        const uint32_t w1 = ci >> 1;
-                        for (uint32_t w = (ci / HB) * (HB / 2); w <= w1; w++) {
-                            const uint32_t x = S.H[w];
+                        for (uint32_t g = (ci / HB) * 8; g < (ci >> 3); g++) le += h16(S.H2, g);
+                        const uint32_t w0 = (ci >> 3) * 4, w1 = ci >> 1;
+                        for (uint32_t w = w0; w <= w1; w++) {
+                            const uint32_t x = hf_word<VLDS>(hs.Hf, w);
                             le += x & 0xFFFFu;
                             if (w < w1 || (ci & 1)) le += x >> 16;
                         }
@@ -571,10 +666,10 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             n_merge++;
             // accepted keys: histogram update, compaction (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
             {
-                if (acc) { hadd(S.H, ci, 1); atomicAdd(&S.H1[ci / HB], 1u); }
+                if (acc) hist_add<VLDS>(hs, ci, 1);
                 const uint64_t ab = __ballot(acc);
                 if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(ab);
-                __syncthreads();
+                __syncthreads();                                  // also: every read of Eid/Ecnt is done, As may overwrite them
                 uint32_t aoff = 0;
 #pragma unroll
                 for (int w = 0; w < DT / 64; w++) if (w < (int)wv) aoff += S.wsum[w];
@@ -593,17 +688,16 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             if (nR + na >= efs) {
                 const uint32_t excess = nR + na - efs;
                 if (full && excess < tieT) {
-                    if (threadIdx.x == 0 && excess) { hsub(S.H, dmax, excess); atomicSub(&S.H1[dmax / HB], excess); }
+                    if (threadIdx.x == 0 && excess) hist_sub<VLDS>(hs, dmax, excess);
                     tieT -= excess;
                 } else {
                     if (threadIdx.x < 64) {
-                        uint32_t d = full ? dmax : ix.m, ex = excess, tt;
+                        uint32_t d = full ? dmax : ix.m, ex = excess, tt = 0;
                         for (;;) {
-                            d = hist_find_down(S.H, S.H1, d, lane);
-                            tt = hget(S.H, d);
-                            if (ex == 0) break;
+                            d = hist_find_down<VLDS>(hs, d, lane, tt);
+                            if (ex == 0 || tt == 0) break;
                             const uint32_t r = ex < tt ? ex : tt;
-                            if (lane == 0) { hsub(S.H, d, r); atomicSub(&S.H1[d / HB], r); }
+                            if (lane == 0) hist_sub<VLDS>(hs, d, r);
                             __threadfence_block();
                             ex -= r;
                             if (r < tt) { tt -= r; break; }
@@ -672,7 +766,6 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 nN = liveN + na; headN = 0;
                 if (nR == efs) { const uint32_t alive = lower_bound_keys(S.N, nN, KEY(dnew, 0xFFFFFFFFu)); if (alive < nN) nN = alive; }
             }
-            pre_c = ~(uint64_t)0;
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_e += clock64() - p4;
         }
         __syncthreads();
@@ -1134,19 +1227,31 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
     return GS_OK;
 }
 
+// placement for the dense traversal: visited bitmap in LDS when that still leaves >= 2 workgroups per CU (GS_DENSE_VIS=lds|global overrides)
+static bool dense_vis_in_lds(const gs_index *ix, uint32_t knbn, uint32_t maxdeg)
+{
+    const size_t cap = 160 * 1024 - 1024;
+    const size_t l = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true);
+    const char *e = getenv("GS_DENSE_VIS");
+    if (e && !strcmp(e, "global")) return false;
+    if (e && !strcmp(e, "lds")) return l <= cap;
+    return l <= cap / 2;
+}
 static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t mat_ld, uint64_t *ids, float *dist,
                                uint32_t *count, uint64_t *evals)
 {
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
-    const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg);
+    const bool vlds = dense_vis_in_lds(ix, knbn, maxdeg);
+    const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, vlds);
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024 - 1024) / lds));
-    const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
+    // per-workgroup global scratch: visited bitmap (vlds = false) or the fine histogram bins (vlds = true)
+    const uint32_t scratch_words = vlds ? dense_nblocks(ix->prm.m) * (HB / 2) : (uint32_t)((ix->n + 31) / 32);
     const uint32_t capC = 2 * efs + 2 * (uint32_t)DCN + maxdeg + 64;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu * per_cu);
     int rc;
-    if ((rc = ix->visited.ensure((size_t)4 * vis_words * c->n_cu * 3))) return rc;
+    if ((rc = ix->visited.ensure((size_t)4 * scratch_words * c->n_cu * 3))) return rc;
     if ((rc = ix->cbuf.ensure((size_t)16 * capC * c->n_cu * 3))) return rc;
     GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
     IndexDev d = index_dev(ix);
@@ -1155,16 +1260,15 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(64))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 64, c->stream)); prof = profbuf.as<unsigned long long>(); }
     {
     ProfScope ps(c, FAM_SEARCH);
-#define GS_LAUNCH_DSEARCH(K)                                                                                              \
+#define GS_LAUNCH_DSEARCH(V)                                                                                              \
     do {                                                                                                                  \
-        auto kern = k_hnsw_search_dense<K>;                                                                               \
+        auto kern = k_hnsw_search_dense<V>;                                                                               \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), vis_words, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
                            ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof);  \
     } while (0)
-    if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_DSEARCH(GS_KIND_F32);
-    else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_DSEARCH(GS_KIND_U32);
-    else GS_LAUNCH_DSEARCH(GS_KIND_U64);
+    if (vlds) GS_LAUNCH_DSEARCH(true);
+    else GS_LAUNCH_DSEARCH(false);
 #undef GS_LAUNCH_DSEARCH
     }
     GS_HIP_CHECK(hipGetLastError());
@@ -1184,8 +1288,8 @@ static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq,
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
-    if (mat && maxdeg <= (uint32_t)DT && efs <= 65535u && knbn <= (uint32_t)(TMAXI * DT) && ix->prm.m <= 65535u &&
-        dense_lds_bytes(ix->prm.m, knbn, maxdeg) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
+    if (mat && maxdeg <= (uint32_t)DT / 2 && efs <= 65535u && knbn <= (uint32_t)(TMAXI * DT) && ix->prm.m <= 65535u &&
+        dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, false) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
         return search_launch_dense(ix, nq, knbn, ef, mat, mat_ld, ids, dist, count, evals);
     const size_t lds = search_lds_bytes(efs, maxdeg);
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);

@@ -499,3 +499,34 @@ def test_dense_strategies_for_every_signature_kind(gpu_ctx, monkeypatch, dtype, 
     q = np.concatenate([H.queries_from(db, 150, 3, frac=0.2), db[5:9]])
     got, want = hn.search_arrays(q, 15, 300), oix.parallel_search(q, 15, 300)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
+
+
+@pytest.mark.parametrize("vis", ["lds", "global"])
+@pytest.mark.parametrize("regime", ["spread", "ties", "tiny_ef"])
+def test_dense_traversal_placements_and_regimes(gpu_ctx, monkeypatch, vis, regime):
+    """dense traversal (histogram result set): visited bitmap in LDS / in global memory, on data with spread-out distances (the rank
+    path), with almost everything tied at distance 1 (the flood regime of the request workload) and with ef = knbn = small"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_DENSE_VIS", vis)
+    m = 200
+    if regime == "ties":
+        db = H.synth_sig_db(150, 8, m, 77, jlo=0.0, jhi=0.6)      # many small unrelated families: most pairs share no slot
+        knbn, ef = 10, 400
+    elif regime == "spread":
+        db = H.synth_sig_db(3, 400, m, 78, jlo=0.02, jhi=0.98)
+        knbn, ef = 25, 300
+    else:
+        db = H.synth_sig_db(12, 100, m, 79, jlo=0.1, jhi=0.9)
+        knbn, ef = 7, 7
+    oix = O.Index(np.float32, m, 8, 64, seed=9)
+    oix.parallel_insert(db, batch=64)
+    hn = G.Hnsw.new(8, 100000, 16, 64, G.DistHamming(), seed=9, insert_batch=64)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    q = np.concatenate([H.queries_from(db, 300, 5, frac=0.25), db[:40]])
+    got, want = hn.search_arrays(q, knbn, ef), oix.parallel_search(q, knbn, ef)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    if regime == "ties":
+        assert (want[1] == 1.0).mean() > 0.3                      # the data really is tie-heavy
