@@ -347,7 +347,7 @@ __host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uin
     const size_t nb = dense_nblocks(m);
     size_t histb = 4 * ((size_t)DCN + maxdeg + 8); if (histb < 4 * nb) histb = 4 * nb;          // fold histogram, aliased by P1
     return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * DWIN + 8 * ((size_t)DCN + maxdeg) + 64 + 4 * nb * 4 /*H2*/ + 4 * nb /*H1*/ +
-           8 * (size_t)maxdeg /*Eid,Ecnt (aliased by As)*/ + histb + 4 * (DT / 64) + 64 + (vlds ? 4 * (size_t)((n + 31) / 32 + 1) : 4 * nb * (HB / 2));
+           8 * (size_t)maxdeg /*Eid,Ecnt (aliased by As)*/ + histb + 4 * 48 + (vlds ? 4 * (size_t)((n + 31) / 32 + 1) : 4 * nb * (HB / 2));
 }
 __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
 {
@@ -364,7 +364,7 @@ __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint3
     S.H2 = (uint32_t *)base; base += 4 * nb * 4;
     S.H1 = (uint32_t *)base; base += 4 * nb;
     S.hist = (uint32_t *)base; S.P1 = (uint32_t *)base; base += histb;                  // P1 (slow accept path) and hist (fold) are never live together
-    S.wsum = (uint32_t *)base; base += 4 * (DT / 64) + 64;
+    S.wsum = (uint32_t *)base; base += 4 * 48;                                          // 5 call-site private slots of 8 words
     S.Hf = nullptr; S.vis = nullptr;
     if (vlds) S.vis = (uint32_t *)base; else S.Hf = (uint32_t *)base;
     return S;
@@ -434,6 +434,26 @@ template <bool VLDS> __device__ __forceinline__ uint32_t hist_find_down(const Hi
     mult = __shfl(v, top);
     return grp * 8 + top;
 }
+// Barrier that only orders LDS traffic: global loads issued before it (prefetches) stay in flight across it. Everything the
+// dense traversal exchanges between lanes inside a pop goes through LDS; the few places that hand global data between lanes
+// (G window refill, fold, histogram bins read back in the slow paths) keep the full __syncthreads().
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// number of lanes of the workgroup with pred set (slot: 8 words of LDS private to the call site)
+__device__ __forceinline__ uint32_t lds_count(bool pred, uint32_t *slot)
+{
+    const uint64_t b = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    lds_barrier();
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < DT / 64; w++) t += slot[w];
+    return t;
+}
 // merge sorted A (na <= DT keys) into the sorted T[0..n) keeping `keep` keys (DT lanes)
 __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, const uint64_t *A, uint32_t na, uint32_t keep, const SmallA &sa)
 {
@@ -446,11 +466,11 @@ __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, co
     }
     uint64_t ak = 0; uint32_t apos = 0xFFFFFFFFu;
     if (threadIdx.x < na) { ak = A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(keys, n, ak); }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int it = 0; it < TMAXI; it++) if (pos[it] < keep) keys[pos[it]] = kv[it];
     if (apos < keep) keys[apos] = ak;
-    __syncthreads();
+    lds_barrier();
     const uint32_t tot = n + na;
     return tot < keep ? tot : keep;
 }
@@ -596,13 +616,13 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             const uint64_t bal = __ballot(unv);
             const long long p1 = prof ? clock64() : 0;
             if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
-            __syncthreads();
+            lds_barrier();
             const long long p2 = prof ? clock64() : 0;
             uint32_t off = 0, ne = 0;
 #pragma unroll
             for (int w = 0; w < DT / 64; w++) { const uint32_t x = S.wsum[w]; if (w < (int)wv) off += x; ne += x; }
             if (unv) { const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1)); S.Eid[pos] = id; S.Ecnt[pos] = cntv; }
-            __syncthreads();
+            lds_barrier();
             const long long p3 = prof ? clock64() : 0;
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) { t_a += p1 - p0; t_b += p2 - p1; t_c += p3 - p2; n_pop++; }
             if (ne == 0) continue;
@@ -620,7 +640,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                     else slow = true;
                 } else {
                     const bool below = threadIdx.x < ne && ci < dmax;
-                    const uint32_t B = (uint32_t)__syncthreads_count(below);
+                    const uint32_t B = lds_count(below, S.wsum + 8);
                     if (B == 0) na = 0;
                     else if (B <= tieT) { acc = below; na = B; }
                     else slow = true;
@@ -633,14 +653,14 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                     uint32_t inc = loc;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
-                    if (lane == 63) S.wsum[wv] = inc;
-                    __syncthreads();
+                    if (lane == 63) S.wsum[16 + wv] = inc;
+                    __syncthreads();                              // full: the histogram atomics sent to global memory have landed
                     uint32_t woff = 0;
 #pragma unroll
-                    for (int w = 0; w < DT / 64; w++) if (w < (int)wv) woff += S.wsum[w];
+                    for (int w = 0; w < DT / 64; w++) if (w < (int)wv) woff += S.wsum[16 + w];
                     uint32_t run = woff + inc - loc;
                     for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) { S.P1[idx] = run; run += S.H1[idx]; } }
-                    __syncthreads();
+                    lds_barrier();
                     if (threadIdx.x < ne && ci < dmax) {
                         uint32_t le = S.P1[ci / HB];
                         for (uint32_t g = (ci / HB) * 8; g < (ci >> 3); g++) le += h16(S.H2, g);
@@ -656,7 +676,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                         }
                         acc = le < efs;
                     }
-                    na = (uint32_t)__syncthreads_count(acc);
+                    na = lds_count(acc, S.wsum + 24);
                 }
                 if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
             }
@@ -668,13 +688,13 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             {
                 if (acc) hist_add<VLDS>(hs, ci, 1);
                 const uint64_t ab = __ballot(acc);
-                if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(ab);
-                __syncthreads();                                  // also: every read of Eid/Ecnt is done, As may overwrite them
+                if (lane == 0) S.wsum[32 + wv] = (uint32_t)__popcll(ab);
+                lds_barrier();                                    // also: every read of Eid/Ecnt is done, As may overwrite them
                 uint32_t aoff = 0;
 #pragma unroll
-                for (int w = 0; w < DT / 64; w++) if (w < (int)wv) aoff += S.wsum[w];
+                for (int w = 0; w < DT / 64; w++) if (w < (int)wv) aoff += S.wsum[32 + w];
                 if (acc) S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey;
-                __syncthreads();
+                lds_barrier();
                 if (threadIdx.x < na) {
                     const uint64_t k = S.As[threadIdx.x];
                     uint32_t rank = 0;
@@ -682,8 +702,21 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                     for (uint32_t j = 0; j < na; j++) rank += (S.As[j] < k);
                     S.A[rank] = k;
                 }
-                __syncthreads();
+                lds_barrier();
             }
+            {   // the candidate order has changed: start loading the adjacency of the two candidates that now come first
+                // (first two of merge(A, {c1, c2})) so that the loads overlap with the rest of the merge
+                const uint64_t a0 = S.A[0], a1 = na > 1 ? S.A[1] : ~(uint64_t)0;
+                const uint64_t n1 = a0 < c1 ? a0 : c1;
+                const uint64_t n2 = a0 < c1 ? (a1 < c1 ? a1 : c1) : (a0 < c2 ? a0 : c2);
+                const uint64_t want = half == (it & 1) ? n1 : n2;
+                if (want != ~(uint64_t)0 && pk != want) {
+                    pk = want; pst = 1;
+                    pdeg = ix.deg0[KID(want)];
+                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(want) * maxdeg + hl] : 0;
+                }
+            }
+            const uint32_t dold = dmax;
             // R <- ef smallest of R u A: drop the (nR + na - ef) largest counts from the top bins
             if (nR + na >= efs) {
                 const uint32_t excess = nR + na - efs;
@@ -691,6 +724,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                     if (threadIdx.x == 0 && excess) hist_sub<VLDS>(hs, dmax, excess);
                     tieT -= excess;
                 } else {
+                    __syncthreads();                              // full: wave 0 reads bins other waves have just incremented
                     if (threadIdx.x < 64) {
                         uint32_t d = full ? dmax : ix.m, ex = excess, tt = 0;
                         for (;;) {
@@ -706,7 +740,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                         }
                         if (lane == 0) { S.scal[2] = d; S.scal[3] = tt; }
                     }
-                    __syncthreads();
+                    lds_barrier();
                     dmax = (uint32_t)S.scal[2]; tieT = (uint32_t)S.scal[3];
                 }
                 nR = efs;
@@ -759,12 +793,12 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 if (threadIdx.x < liveN) { nk = S.N[headN + threadIdx.x]; npos = threadIdx.x + lb_a(sa, nk); }
                 uint64_t ak = 0; uint32_t apos = 0xFFFFFFFFu;
                 if (threadIdx.x < na) { ak = S.A[threadIdx.x]; apos = threadIdx.x + lower_bound_keys(S.N + headN, liveN, ak); }
-                __syncthreads();
+                lds_barrier();
                 if (npos != 0xFFFFFFFFu) S.N[npos] = nk;
                 if (apos != 0xFFFFFFFFu) S.N[apos] = ak;
-                __syncthreads();
+                lds_barrier();
                 nN = liveN + na; headN = 0;
-                if (nR == efs) { const uint32_t alive = lower_bound_keys(S.N, nN, KEY(dnew, 0xFFFFFFFFu)); if (alive < nN) nN = alive; }
+                if (nR == efs && dnew != dold) { const uint32_t alive = lower_bound_keys(S.N, nN, KEY(dnew, 0xFFFFFFFFu)); if (alive < nN) nN = alive; }
             }
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_e += clock64() - p4;
         }
