@@ -555,27 +555,23 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 if (threadIdx.x < wn) S.W[threadIdx.x] = Cb[cur][headG + threadIdx.x];
                 __syncthreads();
             }
-            const uint64_t cg = headG < nG ? S.W[headG - wbase] : ~(uint64_t)0;
-            const uint64_t cn = headN < nN ? S.N[headN] : ~(uint64_t)0;
-            const uint64_t c = cg < cn ? cg : cn;
+            // heads of G (through its LDS window; beyond the window counts as unknown) and of N, read in one round: the candidate to
+            // pop and the two that follow in the current order
+            const uint32_t wo = headG - wbase;
+            const uint64_t g0 = headG < nG ? S.W[wo] : ~(uint64_t)0;
+            const uint64_t g1 = (headG + 1 < nG && wo + 1 < wn) ? S.W[wo + 1] : ~(uint64_t)0;
+            const uint64_t g2 = (headG + 2 < nG && wo + 2 < wn) ? S.W[wo + 2] : ~(uint64_t)0;
+            const uint64_t n0 = headN < nN ? S.N[headN] : ~(uint64_t)0;
+            const uint64_t n1 = headN + 1 < nN ? S.N[headN + 1] : ~(uint64_t)0;
+            const uint64_t n2 = headN + 2 < nN ? S.N[headN + 2] : ~(uint64_t)0;
+            const uint64_t c = g0 < n0 ? g0 : n0;
             if (c == ~(uint64_t)0) break;
             const bool full = nR == efs;
             if (KCNT(c) > dmax) break;                               // dmax is INF_CNT until R is full
-            if (cg < cn) headG++; else headN++;
-            const long long p0 = prof ? clock64() : 0;
-            // the two candidates that follow in the current order (G beyond its LDS window counts as unknown)
             uint64_t c1, c2;
-            {
-                uint32_t vg = headG, vn = headN;
-                uint64_t g = (vg < nG && vg - wbase < wn) ? S.W[vg - wbase] : ~(uint64_t)0;
-                uint64_t n2 = vn < nN ? S.N[vn] : ~(uint64_t)0;
-                c1 = g < n2 ? g : n2;
-                if (g < n2) vg++; else vn++;
-                g = (vg < nG && vg - wbase < wn) ? S.W[vg - wbase] : ~(uint64_t)0;
-                n2 = vn < nN ? S.N[vn] : ~(uint64_t)0;
-                c2 = g < n2 ? g : n2;
-                if (c1 == ~(uint64_t)0) c2 = ~(uint64_t)0;
-            }
+            if (g0 < n0) { headG++; c1 = g1 < n0 ? g1 : n0; c2 = g1 < n0 ? (g2 < n0 ? g2 : n0) : (g1 < n1 ? g1 : n1); }
+            else { headN++; c1 = g0 < n1 ? g0 : n1; c2 = g0 < n1 ? (g1 < n1 ? g1 : n1) : (g0 < n2 ? g0 : n2); }
+            const long long p0 = prof ? clock64() : 0;
             uint32_t id = 0, cntv = 0; bool unv = false;
             if (half == (it & 1)) {
                 if (pk != c) {
@@ -613,72 +609,72 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 }
             } else pk = ~(uint64_t)0;
             it++;
-            const uint64_t bal = __ballot(unv);
+            // one barrier per pop: every wave publishes how many of its lanes hit an unvisited node and how many of those are
+            // below the worst count of a full R (dmax is INF_CNT until R is full, so "below" = "unvisited" then)
+            const bool below = unv && cntv < dmax;
+            const uint64_t bal = __ballot(unv), balb = __ballot(below);
             const long long p1 = prof ? clock64() : 0;
-            if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
+            uint32_t *ws = S.wsum + ((it & 1) ? 8 : 0);              // double-buffered: the next pop may start before every wave has read
+            if (lane == 0) ws[wv] = (uint32_t)__popcll(bal) | ((uint32_t)__popcll(balb) << 16);
             lds_barrier();
             const long long p2 = prof ? clock64() : 0;
-            uint32_t off = 0, ne = 0;
+            uint32_t off = 0, ne = 0, boff = 0, B = 0;
 #pragma unroll
-            for (int w = 0; w < DT / 64; w++) { const uint32_t x = S.wsum[w]; if (w < (int)wv) off += x; ne += x; }
-            if (unv) { const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1)); S.Eid[pos] = id; S.Ecnt[pos] = cntv; }
-            lds_barrier();
+            for (int w = 0; w < DT / 64; w++) { const uint32_t x = ws[w]; if (w < (int)wv) { off += x & 0xFFFFu; boff += x >> 16; } ne += x & 0xFFFFu; B += x >> 16; }
             const long long p3 = prof ? clock64() : 0;
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) { t_a += p1 - p0; t_b += p2 - p1; t_c += p3 - p2; n_pop++; }
             if (ne == 0) continue;
             evals += ne;
-            uint64_t mykey = ~(uint64_t)0; bool acc = false;
-            uint32_t na;
-            const uint32_t ci = threadIdx.x < ne ? S.Ecnt[threadIdx.x] : INF_CNT;
-            {
-                // closed-form accept rule: e_i is accepted iff #{x in R: c(x) <= c_i} + #{j<i: c_j <= c_i} < ef (and c_i < dmax once
-                // R is full). Shortcuts: R not full and nR + ne <= ef -> everything passes; R full with T keys tied at dmax and
-                // B <= T candidates below dmax -> the first term is <= ef - T, all B pass.
-                bool slow = false;
-                if (!full) {
-                    if (nR + ne <= efs) { acc = threadIdx.x < ne; na = ne; }
-                    else slow = true;
-                } else {
-                    const bool below = threadIdx.x < ne && ci < dmax;
-                    const uint32_t B = lds_count(below, S.wsum + 8);
-                    if (B == 0) na = 0;
-                    else if (B <= tieT) { acc = below; na = B; }
-                    else slow = true;
-                }
-                if (slow) {
-                    // exclusive prefix of the block sums, then rank = P1[block] + groups of the block + bins of the group up to c_i
-                    const uint32_t CH = (nb + DT - 1) / DT;
-                    uint32_t loc = 0;
-                    for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) loc += S.H1[idx]; }
-                    uint32_t inc = loc;
+            // closed-form accept rule: e_i is accepted iff #{x in R: c(x) <= c_i} + #{j<i: c_j <= c_i} < ef (and c_i < dmax once R is
+            // full). Shortcuts that need no ranks (and no compaction of the expansion): R not full and nR + ne <= ef -> everything
+            // passes; R full with T keys tied at dmax and B <= T candidates below dmax -> the first term is <= ef - T, all B pass.
+            bool slow;
+            if (!full) slow = nR + ne > efs;
+            else { if (B == 0) continue; slow = B > tieT; }
+            uint64_t mykey = ~(uint64_t)0, ab; bool acc = false;
+            uint32_t na, ci, aoff;
+            if (!slow) { acc = below; na = B; ci = cntv; mykey = KEY(cntv, id); ab = balb; aoff = boff; }
+            else {
+                // the expansion E in adjacency order
+                if (unv) { const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1)); S.Eid[pos] = id; S.Ecnt[pos] = cntv; }
+                // exclusive prefix of the block sums, then rank = P1[block] + groups of the block + bins of the group up to c_i
+                const uint32_t CH = (nb + DT - 1) / DT;
+                uint32_t loc = 0;
+                for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) loc += S.H1[idx]; }
+                uint32_t inc = loc;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
-                    if (lane == 63) S.wsum[16 + wv] = inc;
-                    __syncthreads();                              // full: the histogram atomics sent to global memory have landed
-                    uint32_t woff = 0;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+                if (lane == 63) S.wsum[16 + wv] = inc;
+                __syncthreads();                              // full: the histogram atomics sent to global memory have landed
+                ci = threadIdx.x < ne ? S.Ecnt[threadIdx.x] : INF_CNT;
+                uint32_t woff = 0;
 #pragma unroll
-                    for (int w = 0; w < DT / 64; w++) if (w < (int)wv) woff += S.wsum[16 + w];
-                    uint32_t run = woff + inc - loc;
-                    for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) { S.P1[idx] = run; run += S.H1[idx]; } }
-                    lds_barrier();
-                    if (threadIdx.x < ne && ci < dmax) {
-                        uint32_t le = S.P1[ci / HB];
-                        for (uint32_t g = (ci / HB) * 8; g < (ci >> 3); g++) le += h16(S.H2, g);
-                        const uint32_t w0 = (ci >> 3) * 4, w1 = ci >> 1;
-                        for (uint32_t w = w0; w <= w1; w++) {
-                            const uint32_t x = hf_word<VLDS>(hs.Hf, w);
-                            le += x & 0xFFFFu;
-                            if (w < w1 || (ci & 1)) le += x >> 16;
-                        }
-                        if (le < efs) {
-#pragma unroll 8
-                            for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
-                        }
-                        acc = le < efs;
+                for (int w = 0; w < DT / 64; w++) if (w < (int)wv) woff += S.wsum[16 + w];
+                uint32_t run = woff + inc - loc;
+                for (uint32_t k2 = 0; k2 < CH; k2++) { const uint32_t idx = threadIdx.x * CH + k2; if (idx < nb) { S.P1[idx] = run; run += S.H1[idx]; } }
+                lds_barrier();
+                if (threadIdx.x < ne && ci < dmax) {
+                    uint32_t le = S.P1[ci / HB];
+                    for (uint32_t g = (ci / HB) * 8; g < (ci >> 3); g++) le += h16(S.H2, g);
+                    const uint32_t w0 = (ci >> 3) * 4, w1 = ci >> 1;
+                    for (uint32_t w = w0; w <= w1; w++) {
+                        const uint32_t x = hf_word<VLDS>(hs.Hf, w);
+                        le += x & 0xFFFFu;
+                        if (w < w1 || (ci & 1)) le += x >> 16;
                     }
-                    na = lds_count(acc, S.wsum + 24);
+                    if (le < efs) {
+#pragma unroll 8
+                        for (uint32_t j = 0; j < threadIdx.x; j++) le += (S.Ecnt[j] <= ci);
+                    }
+                    acc = le < efs;
                 }
                 if (acc) mykey = KEY(ci, S.Eid[threadIdx.x]);
+                ab = __ballot(acc);
+                if (lane == 0) S.wsum[24 + wv] = (uint32_t)__popcll(ab);
+                lds_barrier();                                    // also: every read of Eid/Ecnt is done, As may overwrite them
+                aoff = 0; na = 0;
+#pragma unroll
+                for (int w = 0; w < DT / 64; w++) { const uint32_t x = S.wsum[24 + w]; if (w < (int)wv) aoff += x; na += x; }
             }
             const long long p4 = prof ? clock64() : 0;
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_d += p4 - p3;
@@ -686,14 +682,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             n_merge++;
             // accepted keys: histogram update, compaction (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
             {
-                if (acc) hist_add<VLDS>(hs, ci, 1);
-                const uint64_t ab = __ballot(acc);
-                if (lane == 0) S.wsum[32 + wv] = (uint32_t)__popcll(ab);
-                lds_barrier();                                    // also: every read of Eid/Ecnt is done, As may overwrite them
-                uint32_t aoff = 0;
-#pragma unroll
-                for (int w = 0; w < DT / 64; w++) if (w < (int)wv) aoff += S.wsum[32 + w];
-                if (acc) S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey;
+                if (acc) { hist_add<VLDS>(hs, ci, 1); S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey; }
                 lds_barrier();
                 if (threadIdx.x < na) {
                     const uint64_t k = S.As[threadIdx.x];
