@@ -1243,8 +1243,9 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
     if (!use_join(ix))
         return hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows, nq, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16, ld);
     if ((rc = ensure_cols(ix, n))) return rc;
-    for (uint64_t q0 = 0; q0 < nq; q0 += 4096) {
-        const uint64_t nb = std::min<uint64_t>(4096, nq - q0);
+    const uint64_t jq = match_join_max_queries();
+    for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
+        const uint64_t nb = std::min<uint64_t>(jq, nq - q0);
         if ((rc = match_join_counts(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch))) return rc;
     }
     return GS_OK;
@@ -1378,7 +1379,7 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     const bool join = use_join(ix);
     uint64_t QB = ((uint64_t)4 << 30) / (2 * ld);
     QB = std::max<uint64_t>(128, QB / 128 * 128);
-    if (join) QB = std::min<uint64_t>(QB, 4096);
+    if (join) QB = std::min<uint64_t>(QB, match_join_max_queries());
     QB = std::min<uint64_t>(QB, rest);
     if ((rc = ix->mat.ensure((size_t)2 * QB * ld))) return rc;
     if (join && (rc = ensure_cols(ix, ix->n))) return rc;

@@ -79,6 +79,7 @@ int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t
 struct DevBuf;
 // match-join form of the dense count matrix (gs_join.hip): counts of nq strided query rows against the first n nodes of the
 // column-major database copy `cols` ([m][colcap]); out16[q * ld + e] = mismatch count. scratch: 5 reusable buffers.
+uint64_t match_join_max_queries();
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
                       uint16_t *out16, uint64_t ld, DevBuf *scratch);
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);

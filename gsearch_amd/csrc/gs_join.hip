@@ -4,11 +4,11 @@
 //   c(q,e) = m - #{s : q[s] == e[s]}.
 // Sketches of unrelated genomes agree in ~0.5 of 18000 slots, so the matches are ~10^4 times rarer than the mismatches the
 // tile kernel has to touch. With a column-major copy of the database (cols[s][e]) the matches of a whole query batch are the
-// equi-join, slot by slot, of the batch's column (sorted once per batch) with the database column (streamed once per batch):
-//   per slot s:  for every node e:  binary-search cols[s][e] in the sorted query values; every hit (q,e) -> matches[q][e] += 1
-// HBM traffic: the database once per BATCH (21.6 GB for 300 k x 18000 f32) instead of once per 128 queries; arithmetic: one
-// 12-step LDS binary search per (slot, node) instead of nq compares. Output is bit-identical to the tile kernel.
-#include <hipcub/hipcub.hpp>
+// equi-join, slot by slot, of the batch's column (hashed once per workgroup) with the database column (streamed once per batch):
+//   per slot s:  for every node e:  probe cols[s][e] in an LDS hash table of the query values; every hit (q,e) -> matches[q][e] += 1
+// HBM traffic: the database once per BATCH (21.6 GB for 300 k x 18000 f32) instead of once per 128 queries; arithmetic: ~1.5 LDS
+// probes per (slot, node) instead of nq compares. Output is bit-identical to the tile kernel.
+#include <algorithm>
 #include "gs_internal.hpp"
 
 namespace gs {
@@ -49,56 +49,135 @@ __global__ __launch_bounds__(256) void k_rows_to_cols(const uint8_t *__restrict_
     }
 }
 
-// query batch -> per-slot (key, query index) lists: qkey[s * nq + q], qidx[s * nq + q]
+// query batch -> per-slot key lists: qkey[s * nq + q] (canonical keys)
 template <int KIND, typename T>
-__global__ __launch_bounds__(256) void k_query_cols(const uint8_t *__restrict__ rows, uint64_t stride, uint32_t nq, uint32_t m, T *__restrict__ qkey, uint32_t *__restrict__ qidx)
+__global__ __launch_bounds__(256) void k_query_cols(const uint8_t *__restrict__ rows, uint64_t stride, uint32_t nq, uint32_t m, T *__restrict__ qkey)
 {
     __shared__ T tile[32][33];
     const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const uint64_t r0 = (uint64_t)blockIdx.x * 32, s0 = (uint64_t)blockIdx.y * 32;
     for (uint32_t j = ty; j < 32; j += 8) {
         const uint64_t r = r0 + j, s = s0 + tx;
-        tile[j][tx] = (r < nq && s < m) ? canon<KIND, T>(((const T *)(rows + r * stride))[s]) : (T)0;
+        tile[j][tx] = (r < nq && s < m) ? ((const T *)(rows + r * stride))[s] : (T)0;
     }
     __syncthreads();
     for (uint32_t j = ty; j < 32; j += 8) {
         const uint64_t s = s0 + j, r = r0 + tx;
-        if (s < m && r < nq) { qkey[s * nq + r] = tile[tx][j]; qidx[s * nq + r] = (uint32_t)r; }
+        if (s < m && r < nq) qkey[s * nq + r] = tile[tx][j];
     }
 }
-__global__ void k_seg_offsets(uint64_t *off, uint32_t m, uint32_t nq)
+
+constexpr int JT = 1024;          // lanes per join workgroup (they share one hash table)
+constexpr int JU = 4;             // database values in flight per lane
+constexpr int JP_MAX_LOG2 = 13;   // largest table: 8192 entries (64 KB for 4-byte keys, 96 KB for 8-byte keys)
+constexpr int JQ_MAX = 3276;      // queries per join call: load factor <= 0.4
+constexpr int JB_LOG2 = 16;       // bits of the pre-filter bitmap (8 KB)
+
+__device__ __forceinline__ uint32_t join_hash(uint32_t k) { return k * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t join_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }
+#define GS_SEL4(a, i) (((i) & 2) ? (((i) & 1) ? a[3] : a[2]) : (((i) & 1) ? a[1] : a[0]))
+
+constexpr int JN = 8;             // nodes per lane: a workgroup owns JT * JN nodes for a whole block of slots
+
+// one match of (tag = query + 1) with the lane's node `slot`: run-length accumulate in the lane's "sticky" register for that node
+// (tag in bits 0-11, run length above) and only send an atomic when the run is evicted. A node related to a query matches it in
+// thousands of slots, so its counter would otherwise take thousands of atomics; unrelated matches (run length 1) evict nothing
+// that has proved itself (length >= 2) and go straight to memory.
+#define GS_JOIN_HIT(st, tagv, e)                                                                              \
+    do {                                                                                                      \
+        if (((st) & 0xFFFu) == (tagv)) (st) += 0x1000u;                                                       \
+        else if ((st) < 0x2000u) { if (st) join_flush(mm32, ld, (st), (e)); (st) = (tagv) | 0x1000u; }        \
+        else join_flush(mm32, ld, (tagv) | 0x1000u, (e));                                                     \
+    } while (0)
+__device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t st, uint64_t e)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= m) off[i] = (uint64_t)i * nq;
+    const uint64_t idx = (uint64_t)((st & 0xFFFu) - 1) * ld + e;
+    atomicAdd(&mm32[idx >> 1], (st >> 12) << ((idx & 1) * 16));
 }
 
-constexpr int JQ_MAX = 4096;      // queries per join call (LDS: sorted keys + indices)
-constexpr int JT = 256;
-
-// grid: (node chunks, slots). matches[q * ld + e] (16-bit counters, incremented through their 32-bit container)
+// grid: (node chunks of JT*JN, slot blocks). matches[q * ld + e] (16-bit counters, incremented through their 32-bit container).
+// For every slot of its block the workgroup builds, in LDS, an open-addressing hash table (linear probing, load <= 0.4) of the slot's
+// query values - tag = query index + 1, 0 = empty; equal values of different queries occupy several entries of one probe run -
+// plus a 64-kbit bitmap of their hashes, and streams its nodes' values of that slot through them. ~96 % of the values stop at the
+// bitmap (one LDS read); the survivors (true matches plus false positives) are probed by a flattened per-lane state machine: every
+// trip of the loop advances each lane by one table entry of whichever of its JU values is pending, so the wave pays for the
+// longest per-lane total, not for JU times the longest probe. Keys are canonical under the element type's `==` (f32: -0 -> +0,
+// NaN never inserted / never probed), so bitwise equality is the reference's equality.
 template <int KIND, typename T>
-__global__ __launch_bounds__(JT) void k_match_join(const T *__restrict__ qkey, const uint32_t *__restrict__ qidx, uint32_t nq, const T *__restrict__ cols,
-                                                    uint64_t colcap, uint64_t n, uint64_t chunk, uint32_t *__restrict__ mm32, uint64_t ld)
+__global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
+                                                    uint32_t m, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld)
 {
+    static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
-    T *skey = (T *)s_raw;
-    uint16_t *sq = (uint16_t *)(s_raw + sizeof(T) * (size_t)nq);
-    const uint64_t s = blockIdx.y;
-    for (uint32_t i = threadIdx.x; i < nq; i += JT) { skey[i] = qkey[s * nq + i]; sq[i] = (uint16_t)qidx[s * nq + i]; }
-    __syncthreads();
-    const uint64_t e0 = (uint64_t)blockIdx.x * chunk, e1 = e0 + chunk < n ? e0 + chunk : n;
-    const T *col = cols + s * colcap;
-    for (uint64_t e = e0 + threadIdx.x; e < e1; e += JT) {
-        T v = col[e];
-        if (never_equal<KIND, T>(v)) continue;
-        v = canon<KIND, T>(v);
-        uint32_t lo = 0, hi = nq;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (skey[mid] < v) lo = mid + 1; else hi = mid; }
-        for (; lo < nq && skey[lo] == v; lo++) {
-            const uint64_t idx = (uint64_t)sq[lo] * ld + e;
-            atomicAdd(&mm32[idx >> 1], (idx & 1) ? 0x10000u : 1u);
+    const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
+    uint32_t *tag = (uint32_t *)s_raw;
+    uint32_t *bm = (uint32_t *)(s_raw + 4 * (size_t)P);
+    T *key = (T *)(s_raw + 4 * (size_t)P + ((size_t)1 << JB_LOG2) / 8);
+    const uint64_t e0 = (uint64_t)blockIdx.x * (JT * JN) + threadIdx.x;      // the lane's nodes: e0 + i * JT, i < JN
+    const uint32_t s0 = blockIdx.y * slots_per_wg, s1 = s0 + slots_per_wg < m ? s0 + slots_per_wg : m;
+    uint32_t sticky[JN];
+#pragma unroll
+    for (int i = 0; i < JN; i++) sticky[i] = 0;
+    T vn[JU];
+#pragma unroll
+    for (int u = 0; u < JU; u++) { const uint64_t e = e0 + (uint64_t)u * JT; vn[u] = (e < n && s0 < s1) ? cols[(uint64_t)s0 * colcap + e] : (T)0; }
+    for (uint32_t s = s0; s < s1; s++) {
+        __syncthreads();                                          // the previous slot's probes are done
+        for (uint32_t i = threadIdx.x; i < P; i += JT) tag[i] = 0;
+        for (uint32_t i = threadIdx.x; i < (1u << JB_LOG2) / 32; i += JT) bm[i] = 0;
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < nq; q += JT) {
+            T k = qkey[(uint64_t)s * nq + q];
+            if (never_equal<KIND, T>(k)) continue;
+            k = canon<KIND, T>(k);
+            const uint32_t hq = join_hash(k);
+            atomicOr(&bm[hq >> (32 - JB_LOG2 + 5)], 1u << ((hq >> (32 - JB_LOG2)) & 31));
+            uint32_t h = hq >> sh;
+            while (atomicCAS(&tag[h], 0u, q + 1) != 0u) h = (h + 1) & mask;
+            key[h] = k;
+        }
+        __syncthreads();
+        const T *col = cols + (uint64_t)s * colcap;
+#pragma unroll
+        for (int it = 0; it < JN / JU; it++) {
+            T v[JU]; uint32_t hs[JU]; uint32_t pend = 0;
+#pragma unroll
+            for (int u = 0; u < JU; u++) {
+                const uint64_t e = e0 + (uint64_t)(it * JU + u) * JT;
+                v[u] = canon<KIND, T>(vn[u]);
+                hs[u] = join_hash(v[u]);
+                const uint32_t bit = hs[u] >> (32 - JB_LOG2);
+                const bool pass = e < n && !never_equal<KIND, T>(vn[u]) && ((bm[bit >> 5] >> (bit & 31)) & 1u);
+                pend |= (uint32_t)pass << u;
+            }
+            // next values: the following nodes of this slot, or the first nodes of the next slot
+#pragma unroll
+            for (int u = 0; u < JU; u++) {
+                const bool wrap = it + 1 == JN / JU;
+                const uint64_t e = e0 + (uint64_t)((wrap ? 0 : (it + 1) * JU) + u) * JT;
+                const T *src = wrap ? col + colcap : col;
+                vn[u] = (e < n && (!wrap || s + 1 < s1)) ? src[e] : (T)0;
+            }
+            uint32_t hh = 0, uu = 0; T vv = 0; bool have = false;
+            for (;;) {
+                if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
+                if (!have) break;
+                const uint32_t t = tag[hh];
+                const T k = key[hh];
+                if (t == 0u) { have = false; continue; }
+                if (k == vv) {
+                    const uint64_t e = e0 + (uint64_t)(it * JU + uu) * JT;
+                    uint32_t st = GS_SEL4((sticky + it * JU), uu);
+                    GS_JOIN_HIT(st, t, e);
+#pragma unroll
+                    for (int u = 0; u < JU; u++) if (uu == (uint32_t)u) sticky[it * JU + u] = st;
+                }
+                hh = (hh + 1) & mask;
+            }
         }
     }
+#pragma unroll
+    for (int i = 0; i < JN; i++) if (sticky[i]) join_flush(mm32, ld, sticky[i], e0 + (uint64_t)i * JT);
 }
 // matches -> mismatch counts, in place:  c = m - matches
 __global__ void k_match_to_count(uint16_t *mm, uint64_t nq, uint64_t n, uint64_t ld, uint32_t m)
@@ -116,40 +195,36 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
 {
     int rc;
     const size_t items = (size_t)m * nq;
-    DevBuf &k0 = scratch[0], &k1 = scratch[1], &i0 = scratch[2], &i1 = scratch[3], &tmp = scratch[4];
+    DevBuf &k0 = scratch[0];
     if ((rc = k0.ensure(sizeof(T) * items))) return rc;
-    if ((rc = k1.ensure(sizeof(T) * items))) return rc;
-    if ((rc = i0.ensure(4 * items))) return rc;
-    if ((rc = i1.ensure(4 * items))) return rc;
-    DevBuf off;
-    if ((rc = off.alloc(8 * ((size_t)m + 1)))) return rc;
     // zero the 16-bit match counters of the used rows (ld may exceed n: only [0,n) of each row is used)
     GS_HIP_CHECK(hipMemset2DAsync(out16, ld * 2, 0, n * 2, nq, c->stream));
     dim3 tg((nq + 31) / 32, (m + 31) / 32);
-    hipLaunchKernelGGL((k_query_cols<KIND, T>), tg, dim3(256), 0, c->stream, qrows, qstride, nq, m, k0.as<T>(), i0.as<uint32_t>());
-    hipLaunchKernelGGL(k_seg_offsets, dim3((m + 256) / 256), dim3(256), 0, c->stream, off.as<uint64_t>(), m, nq);
+    hipLaunchKernelGGL((k_query_cols<KIND, T>), tg, dim3(256), 0, c->stream, qrows, qstride, nq, m, k0.as<T>());
     GS_HIP_CHECK(hipGetLastError());
-    size_t tb = 0;
-    GS_HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, k0.as<T>(), k1.as<T>(), i0.as<uint32_t>(), i1.as<uint32_t>(), (int)items, (int)m,
-                                                             off.as<uint64_t>(), off.as<uint64_t>() + 1, 0, (int)(8 * sizeof(T)), c->stream));
-    if ((rc = tmp.ensure(tb))) return rc;
-    GS_HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp.p, tb, k0.as<T>(), k1.as<T>(), i0.as<uint32_t>(), i1.as<uint32_t>(), (int)items, (int)m,
-                                                             off.as<uint64_t>(), off.as<uint64_t>() + 1, 0, (int)(8 * sizeof(T)), c->stream));
-    const uint64_t chunk = 32768;
-    dim3 jg((uint32_t)((n + chunk - 1) / chunk), m);
-    const size_t lds = (sizeof(T) + 2) * (size_t)nq + 16;
+    uint32_t log2p = 6;
+    while (log2p < (uint32_t)JP_MAX_LOG2 && (double)(1u << log2p) * 0.4 < (double)nq) log2p++;
+    // one workgroup = JT * JN nodes x a block of slots; blocks sized so that the grid is about one round of 2 workgroups per CU
+    const uint32_t chunks = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
+    uint32_t blocks = std::max<uint32_t>(1, (2 * c->n_cu) / chunks);
+    if (getenv("GS_JOIN_BLOCKS")) blocks = (uint32_t)atoi(getenv("GS_JOIN_BLOCKS"));
+    blocks = std::min<uint32_t>(std::max<uint32_t>(blocks, 1), m);
+    const uint32_t slots_per_wg = (m + blocks - 1) / blocks;
+    dim3 jg(chunks, (m + slots_per_wg - 1) / slots_per_wg);
+    const size_t lds = (sizeof(T) + 4) * ((size_t)1 << log2p) + ((size_t)1 << JB_LOG2) / 8;
     {
         ProfScope ps(c, FAM_HAMMING);
         auto kern = k_match_join<KIND, T>;
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k1.as<T>(), i1.as<uint32_t>(), nq, (const T *)cols, colcap, n, chunk, (uint32_t *)out16, ld);
+        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld);
         GS_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_match_to_count, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, (uint64_t)nq, n, ld, m);
     GS_HIP_CHECK(hipGetLastError());
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));       // `off` is freed on return
     return GS_OK;
 }
+
+uint64_t match_join_max_queries() { return JQ_MAX; }
 
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
                       uint16_t *out16, uint64_t ld, DevBuf *scratch)
