@@ -10,7 +10,7 @@ def short(name):
     return n.split("(")[0].split("<")[0].replace("gs::", "")
 
 stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
-rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, "*kernel_stats.csv"))[0])))
+rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0])))
 agg = collections.OrderedDict()
 for r in rows:
     k = short(r["Name"]); a = agg.setdefault(k, [0, 0.0])
@@ -22,7 +22,7 @@ with open(out + "_kernel_stats.csv", "w") as f:
         f.write('"%s",%d,%.0f,%.1f,%.3f\n' % (k, c, t, t / c, 100.0 * t / tot))
 def pmc(d, cn):
     res = collections.defaultdict(list)
-    fn = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    fn = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not fn: return res
     for r in csv.DictReader(open(fn[0])):
         if r.get("Counter_Name") == cn: res[short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
