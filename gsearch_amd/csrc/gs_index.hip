@@ -206,11 +206,11 @@ __device__ __forceinline__ uint32_t search_layer_block(const IndexDev &ix, const
         bool unv = false; uint32_t cntv = 0;
         if (threadIdx.x < deg) {
             const uint32_t bit = 1u << (id & 31);
-            if (matrow) cntv = matrow[id];                           // dense mode: the lookup overlaps the visited test
-            // the bitmap is private to this workgroup: workgroup scope keeps the RMW in the XCD's L2 (device scope went to memory:
-            // rocprof WRITE_SIZE showed ~146 B of HBM writes per evaluation)
+            // the bitmap is private to this workgroup (LDS, or global where workgroup scope keeps the RMW in the XCD's L2 - device
+            // scope went to memory: rocprof WRITE_SIZE showed ~146 B of HBM writes per evaluation)
             const uint32_t old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             unv = !(old & bit);
+            if (matrow && unv) cntv = matrow[id];                    // dense mode: every 2-byte lookup costs an HBM sector, only for the unvisited
         }
         if (headC < nC) {                                            // issue the next candidate's adjacency loads now
             pre_c = S.C[headC];
@@ -935,7 +935,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
 template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint32_t nb, const uint8_t *__restrict__ blevels,
                                                    const uint32_t *__restrict__ cntmat, const uint16_t *__restrict__ mat, uint64_t mat_ld, uint32_t efc, uint32_t ef_lds, int extend,
-                                                   uint32_t *__restrict__ visited, uint32_t vis_words, uint64_t *__restrict__ plan_keys,
+                                                   uint32_t *__restrict__ visited, uint32_t vis_words, int vis_in_lds, uint64_t *__restrict__ plan_keys,
                                                    uint32_t *__restrict__ plan_n, unsigned long long *__restrict__ evals_total)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
@@ -945,7 +945,9 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
     const uint64_t id = b0 + i;
     const int lv = blevels[i];
     const uint4 *q = (const uint4 *)(ix.data + id * ix.stride);
-    uint32_t *vis = visited + (uint64_t)blockIdx.x * vis_words;
+    // visited bitmap: in LDS behind the search arrays when it fits (a bitmap in global memory costs an L2 atomic per neighbour and
+    // thrashes the L2), else this workgroup's slice of the global scratch
+    uint32_t *vis = vis_in_lds ? (uint32_t *)(s_raw + ((search_lds_bytes(ef_lds, maxdeg) + 15) & ~(size_t)15)) : visited + (uint64_t)blockIdx.x * vis_words;
     uint64_t evals = 0;
     const bool have_graph = ix.n > 0;
     const uint16_t *matrow = mat ? mat + (uint64_t)i * mat_ld : nullptr;
@@ -1663,14 +1665,17 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             matp = out16;
         }
         if (b0 >= 4096) { seg_den += (double)nb * (double)b0; seg_batches++; }
+        const size_t lds_vis = ((lds + 15) & ~(size_t)15) + (size_t)4 * vw;
+        const int vis_in_lds = lds_vis <= 160 * 1024 - 1024 && !getenv("GS_PLAN_VIS_GLOBAL");
+        const size_t lds_plan = vis_in_lds ? lds_vis : lds;
         {
             gs::ProfScope ps(c, gs::FAM_INSERT);
 #define GS_LAUNCH_PLAN(K)                                                                                                  \
     do {                                                                                                                   \
         auto kern = gs::k_hnsw_plan<K>;                                                                                    \
-        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), matp, mat_ld, efc, ef_lds, \
-                           ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan));  \
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds_plan, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), matp, mat_ld, efc, ef_lds, \
+                           ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, vis_in_lds, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
                            ix->evals_dev.as<unsigned long long>());                                                        \
     } while (0)
             if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_PLAN(GS_KIND_F32);

@@ -530,3 +530,20 @@ def test_dense_traversal_placements_and_regimes(gpu_ctx, monkeypatch, vis, regim
     assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
     if regime == "ties":
         assert (want[1] == 1.0).mean() > 0.3                      # the data really is tie-heavy
+
+
+def test_insert_with_global_visited_bitmap(gpu_ctx, monkeypatch):
+    """k_hnsw_plan keeps its visited bitmap in LDS when it fits; the global-memory fallback (large n) must build the same graph"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_PLAN_VIS_GLOBAL", "1")
+    db = H.synth_sig_db(10, 60, 128, 91, jlo=0.05, jhi=0.9)
+    oix = O.Index(np.float32, 128, 8, 48, seed=2)
+    oix.parallel_insert(db, batch=50)
+    hn = G.Hnsw.new(8, 10000, 16, 48, G.DistHamming(), seed=2, insert_batch=50)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    g, og = hn.export_graph(), oix.export()
+    assert np.array_equal(g["deg0"], og["deg0"]) and np.array_equal(g["levels"], og["levels"])
+    for i in range(len(db)):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d])
