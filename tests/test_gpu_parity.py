@@ -547,3 +547,21 @@ def test_insert_with_global_visited_bitmap(gpu_ctx, monkeypatch):
     for i in range(len(db)):
         d = int(og["deg0"][i])
         assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d])
+
+
+@pytest.mark.parametrize("dtype,nq,knbn,ef", [(np.float32, 4000, 5, 40), (np.uint64, 2000, 600, 700), (np.uint32, 3500, 1024, 1024)])
+def test_dense_search_large_batches_and_wide_answers(gpu_ctx, monkeypatch, dtype, nq, knbn, ef):
+    """join batches beyond one hash table (3276 queries), the 8-byte-key table (104 kB of LDS) and answers wider than one key per lane"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    m = 48
+    db = H.synth_sig_db(25, 80, m, 123, dtype=dtype, jlo=0.05, jhi=0.9)
+    oix = O.Index(dtype, m, 8, 40, seed=6)
+    oix.parallel_insert(db, batch=128)
+    hn = G.Hnsw.new(8, 100000, 16, 40, G.DistHamming(), dtype=dtype, seed=6, insert_batch=128)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    q = H.queries_from(db, nq, 11, frac=0.3)
+    got, want = hn.search_arrays(q, knbn, ef), oix.parallel_search(q, knbn, ef)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
