@@ -565,3 +565,23 @@ def test_dense_search_large_batches_and_wide_answers(gpu_ctx, monkeypatch, dtype
     got, want = hn.search_arrays(q, knbn, ef), oix.parallel_search(q, knbn, ef)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["dense", "gather"])
+def test_wide_graph_falls_back_to_sorted_array_traversal(gpu_ctx, monkeypatch, mode):
+    """max_nb_conn > 128 (2M > 256 lanes per half): the dense traversal kernel does not apply, the sorted-array kernel answers"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", mode)
+    m, M = 64, 160
+    db = H.synth_sig_db(6, 150, m, 321, jlo=0.05, jhi=0.9)
+    oix = O.Index(np.float32, m, M, 400, seed=8)
+    oix.parallel_insert(db, batch=200)
+    hn = G.Hnsw.new(M, 100000, 16, 400, G.DistHamming(), seed=8, insert_batch=200)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    g, og = hn.export_graph(), oix.export()
+    assert np.array_equal(g["deg0"], og["deg0"])
+    q = H.queries_from(db, 200, 4, frac=0.2)
+    got, want = hn.search_arrays(q, 20, 350), oix.parallel_search(q, 20, 350)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
