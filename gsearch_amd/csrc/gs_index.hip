@@ -1210,7 +1210,9 @@ static bool dense_pays(const gs_index *ix, double frac, uint64_t nq)
     const double n = (double)ix->n;
     const double gather = frac * n * (double)ix->rowbytes / 5.5e12;
     double dense;
-    if (use_join(ix)) dense = (n * (double)ix->rowbytes / 5.0e12 + 3e-3) / (double)std::max<uint64_t>(nq, 1) + frac * n * 2e-9;
+    // measured (profiles/r01_v8, tools/join_probe.py): the join streams the column store at ~3.5 TB/s for an insert batch (256
+    // queries) and ~1 TB/s effective for thousands of queries (probe work per value grows); a dense-mode evaluation costs ~0.1 ns
+    if (use_join(ix)) dense = (n * (double)ix->rowbytes / (nq <= 512 ? 3.5e12 : 1.0e12) + 3e-3) / (double)std::max<uint64_t>(nq, 1) + frac * n * 0.3e-9;
     else dense = n * (double)ix->prm.m / (ix->prm.kind == GS_KIND_U64 ? 1.4e13 : 1.6e13) + frac * n * 2e-9;
     return dense < gather;
 }
@@ -1357,7 +1359,11 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     const DistMode mode = env_mode();
     uint64_t done = 0;
     DevBuf tmp_evals;
-    if (mode == MODE_AUTO && ix->search_frac < 0 && nq >= 256 && ix->n >= 4096) {
+    // a traversal evaluates at least min(n, ef) nodes (R must fill before the stop rule can fire): when that lower bound already
+    // makes the dense strategy cheaper there is nothing to probe
+    const bool lb_dense = mode == MODE_AUTO && ix->prm.m <= 65535 && nq >= 128 && ix->n >= 4096 &&
+                          dense_pays(ix, (double)std::min<uint64_t>(ix->n, efs) / (double)ix->n, nq);
+    if (mode == MODE_AUTO && !lb_dense && ix->search_frac < 0 && nq >= 256 && ix->n >= 4096) {
         // probe: the first queries go the gather way and tell which fraction of the graph a traversal evaluates
         const uint64_t np = 128;
         uint64_t *ev = evals;
@@ -1371,7 +1377,7 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
         done = np;
     }
     const uint64_t rest = nq - done;
-    bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || (mode == MODE_AUTO && ix->search_frac >= 0 && rest >= 128 && dense_pays(ix, ix->search_frac, rest)));
+    bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || lb_dense || (mode == MODE_AUTO && ix->search_frac >= 0 && rest >= 128 && dense_pays(ix, ix->search_frac, rest)));
     if (!dense) {
         if (rest) return search_launch(ix, q + done * ix->stride, rest, knbn, ef, nullptr, 0, ids + done * knbn, dist + done * knbn,
                                        count ? count + done : nullptr, evals ? evals + done : nullptr);
