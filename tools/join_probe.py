@@ -12,10 +12,23 @@ nq = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 18000
 rng = np.random.default_rng(1)
 U = 2 * m                                   # value universe: unrelated rows agree in ~0.5 slots, as OptDens sketches of unrelated genomes do
-db = rng.integers(0, U, (n, m), dtype=np.int32).astype(np.float32)
-q = db[rng.integers(0, n, nq)].copy()
-mask = rng.random(q.shape) < 0.5
-q[mask] = rng.integers(0, U, int(mask.sum())).astype(np.float32)
+fam = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # members per root (0: unrelated rows; 100: the family structure of the bench DB)
+if fam:
+    roots = rng.integers(0, U, (n // fam, m), dtype=np.int32).astype(np.float32)
+    db = np.repeat(roots, fam, axis=0)
+    for r0 in range(0, n, 4096):                           # members keep a root slot with probability J ~ U[0.3, 0.9]
+        blk = db[r0:r0 + 4096]
+        J = rng.uniform(0.3, 0.9, (len(blk), 1)).astype(np.float32)
+        mk = rng.random(blk.shape, dtype=np.float32) > J
+        blk[mk] = rng.integers(0, U, int(mk.sum())).astype(np.float32)
+    q = db[rng.integers(0, n, nq)].copy()
+    mask = rng.random(q.shape, dtype=np.float32) < 0.3
+    q[mask] = rng.integers(0, U, int(mask.sum())).astype(np.float32)
+else:
+    db = rng.integers(0, U, (n, m), dtype=np.int32).astype(np.float32)
+    q = db[rng.integers(0, n, nq)].copy()
+    mask = rng.random(q.shape) < 0.5
+    q[mask] = rng.integers(0, U, int(mask.sum())).astype(np.float32)
 M = 8
 hn = G.Hnsw.new(M, n, 16, 16, G.DistHamming(), seed=1)
 g = dict(levels=np.zeros(n, np.uint8), entry=0, deg0=np.zeros(n, np.uint32), nbr0=np.zeros((n, 2 * M), np.uint32), cnt0=np.zeros((n, 2 * M), np.uint32),
