@@ -261,8 +261,11 @@ def run_request(args, torch, rank, world, local):
     ctx.profile_read(2, reset=True); ctx.profile_read(0, reset=True)
     barrier_sync(torch, world)
     t0 = time.perf_counter()
+    step_ms = []
     for i in range(args.steps):
+        t_s = time.perf_counter()
         step(i)
+        step_ms.append((time.perf_counter() - t_s) * 1e3)      # the library calls return when their results are ready
         evals_steps.append(ev_t.clone())
     barrier_sync(torch, world)
     dt = max_over_ranks(torch, world, time.perf_counter() - t0)
@@ -280,7 +283,7 @@ def run_request(args, torch, rank, world, local):
                                % (qps, L / 1e6, k, m, knbn, ef, N, args.max_nb_conn, args.ef_construction, args.scale_modify),
                    "db_genomes": N, "queries_per_gpu_per_step": qps, "genome_len": L, "kmer_size": k, "sketch_size": m, "knbn": knbn, "ef_search": ef,
                    "max_nb_conn": args.max_nb_conn, "ef_construction": args.ef_construction},
-        "build_seconds": build_s, "build_genomes_per_sec": N / build_s, "dist_evals_per_query": evals_total / (qps * args.steps),
+        "step_ms": [round(x, 2) for x in step_ms], "build_seconds": build_s, "build_genomes_per_sec": N / build_s, "dist_evals_per_query": evals_total / (qps * args.steps),
         "sketch_kmers_per_sec": (L - k + 1) * qps * sk_n / (sk_ms * 1e-3) if sk_ms > 0 else None,
     }
     if rank == 0:

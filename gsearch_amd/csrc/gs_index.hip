@@ -337,7 +337,7 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
 // ======================================================================================================
 constexpr int DT = 512;           // lanes per dense-mode workgroup (two halves of 256: maxdeg <= 256)
 constexpr int DWIN = 64;          // keys of C mirrored in LDS
-constexpr int DCN = 192;          // capacity of the LDS-resident candidate buffer N
+constexpr int DCN = 448;          // capacity of the LDS-resident candidate buffer N (>= 2M: an empty N takes a whole expansion; <= DT: one key per lane)
 constexpr int TMAXI = 2;          // staged T keys per lane in a merge (knbn <= TMAXI*DT)
 constexpr int HB = 64;            // histogram bins per H1 block (8 groups of 8 bins)
 struct DenseLds { uint64_t *T, *A, *As, *W, *N; uint32_t *Hf, *H2, *H1, *P1, *vis, *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
@@ -345,19 +345,19 @@ __host__ __device__ inline uint32_t dense_nblocks(uint32_t m) { return m / HB + 
 __host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
 {
     const size_t nb = dense_nblocks(m);
-    size_t histb = 4 * ((size_t)DCN + maxdeg + 8); if (histb < 4 * nb) histb = 4 * nb;          // fold histogram, aliased by P1
-    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * DWIN + 8 * ((size_t)DCN + maxdeg) + 64 + 4 * nb * 4 /*H2*/ + 4 * nb /*H1*/ +
+    size_t histb = 4 * ((size_t)DCN + 8); if (histb < 4 * nb) histb = 4 * nb;                   // fold histogram, aliased by P1
+    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * DWIN + 8 * (size_t)DCN + 64 + 4 * nb * 4 /*H2*/ + 4 * nb /*H1*/ +
            8 * (size_t)maxdeg /*Eid,Ecnt (aliased by As)*/ + histb + 4 * 48 + (vlds ? 4 * (size_t)((n + 31) / 32 + 1) : 4 * nb * (HB / 2));
 }
 __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
 {
     DenseLds S;
     const size_t nb = dense_nblocks(m);
-    size_t histb = 4 * ((size_t)DCN + maxdeg + 8); if (histb < 4 * nb) histb = 4 * nb;
+    size_t histb = 4 * ((size_t)DCN + 8); if (histb < 4 * nb) histb = 4 * nb;
     S.T = (uint64_t *)base; base += 8 * (size_t)((knbn + 1) & ~1u);
     S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
     S.W = (uint64_t *)base; base += 8 * DWIN;
-    S.N = (uint64_t *)base; base += 8 * ((size_t)DCN + maxdeg);
+    S.N = (uint64_t *)base; base += 8 * (size_t)DCN;
     S.scal = (uint64_t *)base; base += 64;
     S.Eid = (uint32_t *)base; S.As = (uint64_t *)base; base += 4 * (size_t)maxdeg;     // As (compaction of accepted keys) reuses Eid/Ecnt, dead by then
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
@@ -486,6 +486,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
     const uint32_t efs = ef > knbn ? ef : knbn;
     const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
+    long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, ix.n, VLDS);
     // per-workgroup global scratch: the visited bitmap (VLDS = false) or the fine histogram bins (VLDS = true)
     uint32_t *vis = VLDS ? S.vis : scratch + (uint64_t)blockIdx.x * scratch_words;
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                     pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(want) * maxdeg + hl] : 0;
                 }
             }
+            const long long q1 = prof ? clock64() : 0;
             const uint32_t dold = dmax;
             // R <- ef smallest of R u A: drop the (nR + na - ef) largest counts from the top bins
             if (nR + na >= efs) {
@@ -735,6 +737,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 nR = efs;
             } else nR += na;
             const uint32_t dnew = dmax;                              // INF_CNT while R is not full
+            const long long q2 = prof ? clock64() : 0;
             const SmallA sa = load_small_a(S.A, na);
             // T <- knbn smallest of T u A (only when A reaches into it)
             if (nT < knbn || S.A[0] < Tmax) {
@@ -762,9 +765,16 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) wsumv += __shfl_down(wsumv, o);
                 if (lane == 0) S.wsum[wv] = wsumv;
+                // N key t lands behind the G keys that sort before it: inclusive prefix of hist[0..t] (block scan)
+                uint32_t inc = threadIdx.x <= liveN ? S.hist[threadIdx.x] : 0;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+                if (lane == 63) S.wsum[40 + wv] = inc;
+                __syncthreads();
                 if (threadIdx.x < liveN) {
-                    uint32_t below = 0;
-                    for (uint32_t t = 0; t <= threadIdx.x; t++) below += S.hist[t];
+                    uint32_t below = inc;
+#pragma unroll
+                    for (int w = 0; w < DT / 64; w++) if (w < (int)wv) below += S.wsum[40 + w];
                     if (threadIdx.x + below < capC) dst[threadIdx.x + below] = NL[threadIdx.x];
                 }
                 __syncthreads();
@@ -775,6 +785,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 nG = (nR == efs && alive < tot) ? alive : tot;
                 cur ^= 1; headG = 0; wbase = 0; wn = 0; nN = 0; headN = 0;
             }
+            const long long q3 = prof ? clock64() : 0;
             // ---- N <- live N u A (both tiny, in LDS), dead tail dropped
             {
                 const uint32_t liveN = nN - headN;
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 nN = liveN + na; headN = 0;
                 if (nR == efs && dnew != dold) { const uint32_t alive = lower_bound_keys(S.N, nN, KEY(dnew, 0xFFFFFFFFu)); if (alive < nN) nN = alive; }
             }
-            if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_e += clock64() - p4;
+            if (prof && blockIdx.x == 0 && threadIdx.x == 0) { const long long q4 = clock64(); t_e += q4 - p4; tq1 += q1 - p4; tq2 += q2 - q1; tq3 += q3 - q2; tq4 += q4 - q3; tna += na; }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
@@ -801,6 +812,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
         atomicAdd(&prof[3], (unsigned long long)t_d); atomicAdd(&prof[4], (unsigned long long)t_e); atomicAdd(&prof[5], (unsigned long long)n_pop); atomicAdd(&prof[6], (unsigned long long)n_merge);
+        atomicAdd(&prof[8], (unsigned long long)tq1); atomicAdd(&prof[9], (unsigned long long)tq2); atomicAdd(&prof[10], (unsigned long long)tq3); atomicAdd(&prof[11], (unsigned long long)tq4); atomicAdd(&prof[12], (unsigned long long)tna);
     }
 }
 
@@ -1285,7 +1297,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     IndexDev d = index_dev(ix);
     unsigned long long *prof = nullptr;
     DevBuf profbuf;
-    if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(64))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 64, c->stream)); prof = profbuf.as<unsigned long long>(); }
+    if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); prof = profbuf.as<unsigned long long>(); }
     {
     ProfScope ps(c, FAM_SEARCH);
 #define GS_LAUNCH_DSEARCH(V)                                                                                              \
@@ -1301,11 +1313,13 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     }
     GS_HIP_CHECK(hipGetLastError());
     if (prof) {
-        unsigned long long h[8];
-        GS_HIP_CHECK(hipMemcpyAsync(h, prof, 64, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long h[16];
+        GS_HIP_CHECK(hipMemcpyAsync(h, prof, 128, hipMemcpyDeviceToHost, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         fprintf(stderr, "[GS_TRAV_PROFILE] workgroup 0: pops %llu merges %llu | cycles/pop: loads+atomics issue->ballot %.0f, sync1 %.0f, compaction+sync2 %.0f, accept rule+count %.0f | merge cycles/merge %.0f\n",
                 h[5], h[6], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], h[6] ? (double)h[4] / h[6] : 0.0);
+        if (h[6]) fprintf(stderr, "[GS_TRAV_PROFILE] per accepting pop: compaction+sort %.0f, prefetch+trim %.0f, T %.0f, fold+N merge %.0f cycles; accepted keys %.2f\n",
+                          (double)h[8] / h[6], (double)h[9] / h[6], (double)h[10] / h[6], (double)h[11] / h[6], (double)h[12] / h[6]);
     }
     return GS_OK;
 }
