@@ -358,6 +358,7 @@ def run_request(args, torch, rank, world, local):
                         kk["pmc_hbm_bytes_per_launch"] = pmc_all[kk["kernel"]]["hbm_bytes_per_launch"]
             if pmc and N == 300000 and qps == 2500 and m == 18000:
                 out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_GBps"] = pmc["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9     # physical HBM rate of the launch
                 out["roofline"]["traffic_source"] = "profiles/r01_v8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
         except Exception:
             pass
