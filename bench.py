@@ -6,7 +6,7 @@
 One rank per GPU (launched by torch.distributed.run for N > 1). A *step* is one pass of the hot path over one
 batch of synthetic input that is already resident in HBM:
 
-  request (default; BASELINE.json configs[2]/[3]): sketch 2500 query genomes (5 Mbp) + HNSW parallel_search (n=50, ef=5000)
+  request (default; BASELINE.json configs[2]/[3]): sketch 10 000 query genomes (5 Mbp) + HNSW parallel_search (n=50, ef=5000)
           against a 300k-genome OptDens HNSW built on the GPU from synthetic genomes during (untimed) setup.
   sketch  (BASELINE.json configs[1]): 10k synthetic 5 Mbp genomes, k=21, s=18000, --algo optdens, per rank.
 
@@ -215,9 +215,10 @@ def run_request(args, torch, rank, world, local):
     chunk = min(args.build_chunk, N)
     d_seq = ctx.alloc(chunk * gbytes + 64)
     d_sig = ctx.alloc(chunk * m * 4)
-    rs = np.arange(chunk, dtype=np.uint64) * np.uint64(words * 32)
-    d_rs, d_rl, d_goff = ctx.alloc(rs.nbytes), ctx.alloc(rs.nbytes), ctx.alloc(8 * (chunk + 1))
-    ctx.upload(d_rs, rs); ctx.upload(d_rl, np.full(chunk, L, np.uint64)); ctx.upload(d_goff, np.arange(chunk + 1, dtype=np.uint64))
+    nrec = max(chunk, qps)                                  # record tables serve the build chunks and the query batches
+    rs = np.arange(nrec, dtype=np.uint64) * np.uint64(words * 32)
+    d_rs, d_rl, d_goff = ctx.alloc(rs.nbytes), ctx.alloc(rs.nbytes), ctx.alloc(8 * (nrec + 1))
+    ctx.upload(d_rs, rs); ctx.upload(d_rl, np.full(nrec, L, np.uint64)); ctx.upload(d_goff, np.arange(nrec + 1, dtype=np.uint64))
     t_b = time.perf_counter()
     for g0 in range(0, N, chunk):
         n = min(chunk, N - g0)
@@ -352,11 +353,11 @@ def run_request(args, torch, rank, world, local):
         try:
             pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")))["kernels"]
             pmc = pmc_all.get(dom["kernel"])
-            if N == 300000 and qps == 2500 and m == 18000:
+            if N == 300000 and qps in (2500, 10000) and m == 18000:      # 10000 = launches of 3276+3276+3276+172 queries: 2500 on average
                 for kk in kernels:
                     if kk["kernel"] in pmc_all and kk["kernel"] != "k_match_join":   # the join's largest-grid launches are insert-time ones
                         kk["pmc_hbm_bytes_per_launch"] = pmc_all[kk["kernel"]]["hbm_bytes_per_launch"]
-            if pmc and N == 300000 and qps == 2500 and m == 18000:
+            if pmc and N == 300000 and qps in (2500, 10000) and m == 18000:
                 out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_GBps"] = pmc["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9     # physical HBM rate of the launch
                 out["roofline"]["traffic_source"] = "profiles/r01_v8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
@@ -420,7 +421,7 @@ def main():
     # request workload (BASELINE configs[2])
     ap.add_argument("--db-genomes", type=int, default=300000)
     ap.add_argument("--queries", type=int, default=10000, help="query genomes per GPU (resident in HBM)")
-    ap.add_argument("--queries-per-step", type=int, default=2500)
+    ap.add_argument("--queries-per-step", type=int, default=10000, help="query genomes per GPU per step (configs[2]: one request of 10k queries)")
     ap.add_argument("--knbn", type=int, default=50)
     ap.add_argument("--ef-search", type=int, default=5000, help="gsearch hard-codes 5000 (src/bin/gsearch.rs:893)")
     ap.add_argument("--max-nb-conn", type=int, default=128)
