@@ -363,6 +363,10 @@ def run_request(args, torch, rank, world, local):
                 out["roofline"]["traffic_source"] = "profiles/r01_v8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
         except Exception:
             pass
+        if world > 1:                                        # parity sample and CPU baseline: rank 0 at N=1 only
+            out["cpu_baseline"] = None
+            print(json.dumps(out))
+            return
         # ---- parity / recall / CPU baseline on a bounded sample of the last step's queries
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
