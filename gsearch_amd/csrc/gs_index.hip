@@ -1402,6 +1402,7 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     uint64_t QB = ((uint64_t)4 << 30) / (2 * ld);
     QB = std::max<uint64_t>(128, QB / 128 * 128);
     if (join) QB = std::min<uint64_t>(QB, match_join_max_queries());
+    if (getenv("GS_SEARCH_QB")) QB = std::min<uint64_t>(QB, (uint64_t)std::max(1, atoi(getenv("GS_SEARCH_QB"))));
     QB = std::min<uint64_t>(QB, rest);
     if ((rc = ix->mat.ensure((size_t)2 * QB * ld))) return rc;
     if (join && (rc = ensure_cols(ix, ix->n))) return rc;
