@@ -1262,7 +1262,11 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
     const uint64_t jq = match_join_max_queries();
     for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
         const uint64_t nb = std::min<uint64_t>(jq, nq - q0);
-        if ((rc = match_join_counts(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch))) return rc;
+        int declined = 0;
+        if ((rc = match_join_counts(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch,
+                                    &declined))) return rc;
+        if (declined &&      // too many matches to record one by one (redundant queries against a redundant database): fixed-cost compare kernel
+            (rc = hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, nb, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16 + q0 * ld, ld))) return rc;
     }
     return GS_OK;
 }

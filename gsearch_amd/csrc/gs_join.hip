@@ -179,6 +179,62 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
 #pragma unroll
     for (int i = 0; i < JN; i++) if (sticky[i]) join_flush(mm32, ld, sticky[i], e0 + (uint64_t)i * JT);
 }
+// Match-density probe: what would the join cost on THIS batch? Its work is proportional to the number of matches it has to
+// record, and a redundant query set against a redundant database (hundreds of near-identical genomes on both sides) has orders of
+// magnitude more of them than unrelated data - there the compare tile kernel, whose cost is fixed, is the better producer.
+// Each workgroup takes one node chunk and one sampled PAIR of consecutive slots (s, s+1): it counts the matches of slot s+1 and
+// how many of them repeat the (query, node) pair that node matched first in slot s - the matches the run-length accumulator
+// of k_match_join absorbs. out[0] += matches, out[1] += repeats.
+template <int KIND, typename T>
+__global__ __launch_bounds__(JT) void k_match_sample(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
+                                                      uint32_t m, uint32_t nsamp, unsigned long long *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
+    uint32_t *tag = (uint32_t *)s_raw;
+    T *key = (T *)(s_raw + 4 * (size_t)P);
+    const uint64_t e0 = (uint64_t)blockIdx.x * (JT * JN) + threadIdx.x;
+    const uint32_t sbase = (uint32_t)(((uint64_t)blockIdx.y * (m - 1)) / nsamp);      // sbase + 1 <= m - 1
+    uint32_t first[JN];
+#pragma unroll
+    for (int i = 0; i < JN; i++) first[i] = 0;
+    uint32_t hits = 0, reps = 0;
+    for (uint32_t pass = 0; pass < 2; pass++) {
+        const uint32_t s = sbase + pass;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < P; i += JT) tag[i] = 0;
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < nq; q += JT) {
+            T k = qkey[(uint64_t)s * nq + q];
+            if (never_equal<KIND, T>(k)) continue;
+            k = canon<KIND, T>(k);
+            uint32_t h = join_hash(k) >> sh;
+            while (atomicCAS(&tag[h], 0u, q + 1) != 0u) h = (h + 1) & mask;
+            key[h] = k;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < JN; i++) {
+            const uint64_t e = e0 + (uint64_t)i * JT;
+            if (e >= n) continue;
+            T v = cols[(uint64_t)s * colcap + e];
+            if (never_equal<KIND, T>(v)) continue;
+            v = canon<KIND, T>(v);
+            uint32_t h = join_hash(v) >> sh, t;
+            while ((t = tag[h]) != 0u) {
+                if (key[h] == v) {
+                    if (pass == 0) { if (!first[i]) first[i] = t; }
+                    else { hits++; reps += (t == first[i]); }
+                }
+                h = (h + 1) & mask;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o); reps += __shfl_down(reps, o); }
+    if ((threadIdx.x & 63) == 0 && hits) { atomicAdd(&out[0], (unsigned long long)hits); atomicAdd(&out[1], (unsigned long long)reps); }
+}
+
 // matches -> mismatch counts, in place:  c = m - matches
 __global__ void k_match_to_count(uint16_t *mm, uint64_t nq, uint64_t n, uint64_t ld, uint32_t m)
 {
@@ -191,9 +247,10 @@ __global__ void k_match_to_count(uint16_t *mm, uint64_t nq, uint64_t n, uint64_t
 
 template <int KIND, typename T>
 static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstride, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint16_t *out16,
-                     uint64_t ld, DevBuf *scratch /* [5] reusable */)
+                     uint64_t ld, DevBuf *scratch /* [5] reusable */, int *declined)
 {
     int rc;
+    if (declined) *declined = 0;
     const size_t items = (size_t)m * nq;
     DevBuf &k0 = scratch[0];
     if ((rc = k0.ensure(sizeof(T) * items))) return rc;
@@ -204,6 +261,33 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     GS_HIP_CHECK(hipGetLastError());
     uint32_t log2p = 6;
     while (log2p < (uint32_t)JP_MAX_LOG2 && (double)(1u << log2p) * 0.4 < (double)nq) log2p++;
+    if (declined && m >= 64 && n >= 4096) {
+        // sampled match density -> estimated join time (column stream + one memory-side atomic per match the accumulator does not
+        // absorb, 1.6e10/s: profiles/r01_match_join_pmc.txt) against the fixed cost of the compare tile kernel
+        const uint32_t nsamp = 24;
+        DevBuf &cnt = scratch[1];
+        if ((rc = cnt.ensure(16))) return rc;
+        GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 16, c->stream));
+        const uint32_t chunks_s = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
+        const size_t lds_s = (sizeof(T) + 4) * ((size_t)1 << log2p);
+        auto ks = k_match_sample<KIND, T>;
+        if (lds_s > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+        hipLaunchKernelGGL(ks, dim3(chunks_s, nsamp), dim3(JT), lds_s, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, nsamp, cnt.as<unsigned long long>());
+        GS_HIP_CHECK(hipGetLastError());
+        unsigned long long hr[2] = {0, 0};
+        GS_HIP_CHECK(hipMemcpyAsync(hr, cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        const double scale = (double)m / (double)nsamp;
+        const double atomics = (double)(hr[0] - hr[1]) * scale + (double)hr[1] * scale / 64.0;       // absorbed runs still flush now and then
+        const double t_join = (double)n * m * sizeof(T) / 3.5e12 + atomics / 1.6e10 + (double)hr[0] * scale / 2.0e11;
+        const double t_tile = (double)nq * (double)n * (double)m / (KIND == GS_KIND_U64 ? 1.4e13 : 1.6e13);
+        const char *force = getenv("GS_JOIN_DECLINE");
+        const bool decline = force ? atoi(force) != 0 : t_join > t_tile;
+        if (getenv("GS_JOIN_VERBOSE"))
+            fprintf(stderr, "[GS_JOIN] nq=%u n=%llu sampled matches %llu repeats %llu -> est. join %.2f ms, tile %.2f ms: %s\n", nq, (unsigned long long)n, hr[0], hr[1],
+                    t_join * 1e3, t_tile * 1e3, decline ? "tile" : "join");
+        if (decline) { *declined = 1; return GS_OK; }
+    }
     // one workgroup = JT * JN nodes x a block of slots; blocks sized so that the grid is about one round of 2 workgroups per CU
     const uint32_t chunks = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
     uint32_t blocks = std::max<uint32_t>(1, (2 * c->n_cu) / chunks);
@@ -226,14 +310,16 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
 
 uint64_t match_join_max_queries() { return JQ_MAX; }
 
+// `declined` (optional): set to 1 - and out16 is left zeroed - when the sampled match density says the compare tile kernel is the
+// cheaper producer for this batch (the caller then runs it)
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
-                      uint16_t *out16, uint64_t ld, DevBuf *scratch)
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined)
 {
     GS_REQUIRE(nq >= 1 && nq <= (uint64_t)JQ_MAX && m <= 65535 && (ld % 2) == 0 && ((uintptr_t)out16 % 4) == 0, GS_ERR_INVALID, "match_join_counts: bad shape");
     GS_REQUIRE((uint64_t)m * nq < ((uint64_t)1 << 31), GS_ERR_INVALID, "match_join_counts: batch too large");
-    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch);
-    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch);
-    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch);
+    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined);
+    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined);
+    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined);
 }
 
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first)

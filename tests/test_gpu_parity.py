@@ -585,3 +585,30 @@ def test_wide_graph_falls_back_to_sorted_array_traversal(gpu_ctx, monkeypatch, m
     got, want = hn.search_arrays(q, 20, 350), oix.parallel_search(q, 20, 350)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("force", ["0", "1", None])
+def test_join_declines_to_tile_kernel_on_redundant_batches(gpu_ctx, monkeypatch, force, capfd):
+    """the join samples the match density of the batch; a redundant query set against a redundant database (everything matches
+    everything) is handed to the fixed-cost compare kernel. Either producer gives the same counts (forced both ways + natural)."""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_JOIN_VERBOSE", "1")
+    if force is not None:
+        monkeypatch.setenv("GS_JOIN_DECLINE", force)
+    m = 96
+    db = H.synth_sig_db(2, 2600, m, 7, jlo=0.85, jhi=0.99)          # two big families of near-identical signatures (5200 nodes)
+    oix = O.Index(np.float32, m, 8, 40, seed=12)
+    oix.parallel_insert(db, batch=200)
+    hn = G.Hnsw.new(8, 100000, 16, 40, G.DistHamming(), seed=12, insert_batch=200)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    g, og = hn.export_graph(), oix.export()
+    assert np.array_equal(g["deg0"], og["deg0"])
+    q = np.repeat(db[:3], 400, axis=0)                              # 1200 queries, three distinct signatures
+    got, want = hn.search_arrays(q, 10, 60), oix.parallel_search(q, 10, 60)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    err = capfd.readouterr().err
+    if force is None:
+        assert "-> est." in err and ": tile" in err                 # the natural decision on this data is the tile kernel
