@@ -48,6 +48,7 @@ __global__ void k_unit_prefix(const uint64_t *rec_start, const uint64_t *rec_len
 template <int ALGO, int VBITS, typename T, bool LDS_TABLE>
 struct MinEmit {
     T *table; uint32_t m; uint64_t zone;
+    uint16_t *bound;              // !LDS_TABLE: per-slot upper bound (top 16 bits) of this workgroup's minima, in LDS
     __device__ __forceinline__ void operator()(uint64_t v, uint64_t /*rec*/, uint64_t /*pos*/) const
     {
         uint64_t o1; uint32_t b;
@@ -56,7 +57,14 @@ struct MinEmit {
         if (ALGO == ALGO_SUPER2) key = sizeof(T) == 8 ? (T)o1 : (T)(o1 >> 32);
         else key = (T)(o1 >> 41);
         if (LDS_TABLE) atomicMin(&table[b], key);
-        else if (key < table[b]) atomicMin(&table[b], key);      // stale (larger) reads only cost a redundant atomic
+        else {
+            // The slot table does not fit in LDS (e.g. 24000 x u64 = 192 kB): it lives in global memory, but a 2-byte LDS filter
+            // keeps all but the ~ln(n)/n fraction of k-mers that can still lower a minimum away from it. bound[b] only ever holds
+            // the top bits of a key this workgroup has applied, so it is >= the top bits of the true minimum: skipping keys whose
+            // top bits exceed it is exact; plain (racy) 16-bit stores can only leave it staler, i.e. more conservative.
+            const uint16_t hi = (uint16_t)(key >> (8 * sizeof(T) - 16));
+            if (hi <= bound[b]) { atomicMin(&table[b], key); bound[b] = hi; }
+        }
     }
 };
 
@@ -138,11 +146,15 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__rest
     const uint32_t part = blockIdx.x, parts = gridDim.x;
     T *gtab = table_out + g * (uint64_t)m;
     T *table = LDS_TABLE ? s_table : gtab;
+    uint16_t *s_bound = (uint16_t *)s_raw_table;
     if (LDS_TABLE) {
         for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s_table[i] = EMPTY;
         __syncthreads();
+    } else {
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s_bound[i] = 0xFFFFu;
+        __syncthreads();
     }
-    MinEmit<ALGO, VBITS, T, LDS_TABLE> emit{table, m, zone};
+    MinEmit<ALGO, VBITS, T, LDS_TABLE> emit{table, m, zone, s_bound};
     walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
     if (LDS_TABLE) {
         __syncthreads();
@@ -340,8 +352,9 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
 #define GS_LAUNCH_MIN(AAV, LDSV)                                                                                        \
     do {                                                                                                                \
         auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T>;                                                            \
-        if (LDSV) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, block, LDSV ? lds : 0, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, p->k, m, zone, tab); \
+        const size_t l = LDSV ? lds : ((size_t)2 * m + 15) & ~(size_t)15;      /* slot table, or its 2-byte filter */            \
+        if (l > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
+        hipLaunchKernelGGL(kern, grid, block, l, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, p->k, m, zone, tab); \
     } while (0)
         if (aa) { if (ge.use_lds) GS_LAUNCH_MIN(true, true); else GS_LAUNCH_MIN(true, false); }
         else    { if (ge.use_lds) GS_LAUNCH_MIN(false, true); else GS_LAUNCH_MIN(false, false); }
