@@ -26,6 +26,15 @@ __constant__ uint8_t c_aa_code[32] = {
     // index = ASCII & 31 : @ A B C D E F G H I J K L M N O P Q R S T U V W X Y Z ...
     0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 0, 8, 9, 10, 11, 0, 12, 13, 14, 15, 16, 0, 17, 18, 0, 19, 0, 0, 0, 0, 0, 0};
 
+// the same table as c_aa_code, packed 8 codes x 5 bits per word and kept in registers: a per-lane (divergent) index into
+// __constant__ memory is a vector memory load per residue, this is four VALU operations
+__device__ __forceinline__ uint32_t aa_code_reg(uint32_t ch)
+{
+    const uint32_t idx = ch & 31, sh = (idx & 7) * 5;
+    const uint64_t lo = (idx & 8) ? 0x2d49400e6ull : 0x2906208000ull, hi = (idx & 8) ? 0x260ull : 0x944107b9acull;
+    return (uint32_t)(((idx & 16) ? hi : lo) >> sh) & 31u;
+}
+
 // per-record unit counts -> exclusive prefix inside each genome (one thread per genome; record lists are short)
 __global__ void k_unit_prefix(const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *genome_rec_off,
                               uint64_t n_genomes, uint32_t k, uint64_t *rec_upre, uint64_t *gen_units)
@@ -114,7 +123,7 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
                 for (uint32_t j = 0; j + 1 < k; j++) {
                     uint64_t a = a0 - (k - 1) + j;
                     uint8_t ch = seq[a];
-                    val = ((val << 5) | c_aa_code[ch & 31]) & mask;
+                    val = ((val << 5) | aa_code_reg(ch)) & mask;
                 }
             }
 #pragma unroll
@@ -123,7 +132,7 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
 #pragma unroll 2
                 for (uint32_t j = 0; j < 8; j++) {
                     uint32_t ch = (uint32_t)(x & 0xFF); x >>= 8;
-                    val = ((val << 5) | c_aa_code[ch & 31]) & mask;
+                    val = ((val << 5) | aa_code_reg(ch)) & mask;
                     uint64_t a = a0 + q * 8 + j;
                     if (a >= first_valid && a < re) emit(val, lo, a);
                 }
