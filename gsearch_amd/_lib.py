@@ -41,6 +41,7 @@ SYMBOLS = {
     "gs_ctx_create": (_i, [C.POINTER(_vp), _i, _vp]),
     "gs_ctx_destroy": (None, [_vp]),
     "gs_ctx_sync": (_i, [_vp]),
+    "gs_ctx_release_scratch": (_i, [_vp]),
     "gs_ctx_stream": (_vp, [_vp]),
     "gs_ctx_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_u64), C.c_char_p, C.c_size_t]),
     "gs_ctx_timer_start": (_i, [_vp]),

@@ -52,8 +52,18 @@ void gs_ctx_destroy(gs_ctx *c)
     for (auto &s : c->prof) for (auto &p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
+    delete (gs::ScratchPool *)c->scratch_pool;
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+int gs_ctx_release_scratch(gs_ctx *c)
+{
+    GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    delete (gs::ScratchPool *)c->scratch_pool;
+    c->scratch_pool = nullptr;
+    return GS_OK;
 }
 int gs_ctx_sync(gs_ctx *c)
 {

@@ -48,6 +48,7 @@ struct gs_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profile = false;
     gs::ProfSlot prof[gs::FAM_COUNT];
+    void *scratch_pool = nullptr;      // gs::ScratchPool: grow-only device buffers reused by the calls of this context
 };
 
 namespace gs {
@@ -103,6 +104,28 @@ struct DevBuf {   // owning device allocation
         return GS_OK;
     }
     int ensure(size_t n) { return (n <= bytes && p) ? GS_OK : alloc(n); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// Per-context scratch: a call's temporaries come from numbered grow-only slots instead of hipMalloc/hipFree (allocating and freeing
+// multi-GB buffers costs more than the kernels that use them). A context serves one call at a time (one stream), so slots are never
+// shared; gs_ctx_release_scratch / gs_ctx_destroy give the memory back.
+enum { SCRATCH_SLOTS = 40 };
+struct ScratchPool { DevBuf b[SCRATCH_SLOTS]; };
+struct PoolBuf {    // same surface as DevBuf for the code that uses it
+    gs_ctx *c; int slot; void *p = nullptr; size_t bytes = 0;
+    PoolBuf(gs_ctx *ctx, int s) : c(ctx), slot(s) {}
+    int alloc(size_t n)
+    {
+        if (!c->scratch_pool) c->scratch_pool = new ScratchPool();
+        DevBuf &d = ((ScratchPool *)c->scratch_pool)->b[slot];
+        if (n == 0) n = 16;
+        int rc = d.ensure(n);
+        if (rc) return rc;
+        p = d.p; bytes = n;
+        return GS_OK;
+    }
+    void release() { p = nullptr; bytes = 0; }          // the slot keeps its memory for the next call
     template <class T> T *as() const { return (T *)p; }
 };
 

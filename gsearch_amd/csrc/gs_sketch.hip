@@ -492,8 +492,13 @@ __global__ void k_prob_init(uint64_t *q, uint64_t *qprev, uint64_t *sig, uint64_
 }
 __global__ void k_prob_wmax(const uint64_t *ukey, const uint32_t *ucnt, uint64_t ne, uint32_t vbits, uint32_t *wmax)
 {
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x)
-        atomicMax(&wmax[vbits >= 64 ? 0 : (ukey[e] >> vbits)], ucnt[e]);
+    // hundreds of millions of elements, a few hundred destination words: read first (a stale, smaller value only costs a
+    // redundant atomic) - unconditional atomics serialise on the same addresses (2 s per 128 genomes)
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t *w = &wmax[vbits >= 64 ? 0 : (ukey[e] >> vbits)];
+        const uint32_t cnt = ucnt[e];
+        if (cnt > *(volatile uint32_t *)w) atomicMax(w, cnt);
+    }
 }
 // pass `it`, phase A: i-th point of every live element -> q[b] = min
 __global__ void k_prob_point(const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ ucnt, uint64_t ne, uint32_t vbits, uint32_t m, uint64_t zone,
@@ -642,7 +647,7 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
         std::vector<uint64_t> base;
         while (g0 + ng < n_genomes && ng < max_g && (ng == 0 || T + hk[g0 + ng] <= max_items)) { base.push_back(T); T += hk[g0 + ng]; ng++; }
         GS_REQUIRE(T < ((uint64_t)1 << 31), GS_ERR_UNSUPPORTED, "a single genome with more than 2^31 k-mers is not supported by the prob sketcher");
-        DevBuf dbase, q, qprev, sig, sigpass, wmax, qmax, nact;
+        PoolBuf dbase(c, 0), q(c, 1), qprev(c, 2), sig(c, 3), sigpass(c, 4), wmax(c, 5), qmax(c, 6), nact(c, 7);
         if ((rc = dbase.alloc(8 * ng))) return rc;
         if ((rc = q.alloc(8 * ng * m))) return rc;
         if ((rc = qprev.alloc(8 * ng * m))) return rc;
@@ -660,7 +665,7 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
             GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         }
         if (T > 0) {
-            DevBuf vals, sorted, ukey, ucnt, nruns, tmp, candh, candb;
+            PoolBuf vals(c, 8), sorted(c, 9), ukey(c, 10), ucnt(c, 11), nruns(c, 12), tmp(c, 13), candh(c, 14), candb(c, 15);
             if ((rc = vals.alloc(8 * T))) return rc;
             if ((rc = sorted.alloc(8 * T))) return rc;
             const uint64_t avg_units = (aa ? seq_bytes / 32 : seq_bytes / 8) / n_genomes + 1;
@@ -695,7 +700,7 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
             const uint32_t eg = (uint32_t)std::min<uint64_t>((ne + 255) / 256, (uint64_t)c->n_cu * 16);
             hipLaunchKernelGGL(k_prob_wmax, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ucnt.as<uint32_t>(), ne, vbits, wmax.as<uint32_t>());
             const uint32_t ACT_CAP = 1u << 24;                       // 16 M live elements keep their generator state (0.5 GB)
-            DevBuf akey, acnt, astate, nlist;
+            PoolBuf akey(c, 16), acnt(c, 17), astate(c, 18), nlist(c, 19);
             uint32_t n_list = 0; bool use_list = false;
             for (uint32_t it = 1;; it++) {
                 GS_HIP_CHECK(hipMemsetAsync(nact.p, 0, 4, c->stream));

@@ -44,6 +44,7 @@ typedef struct gs_ctx gs_ctx;
 int   gs_ctx_create(gs_ctx **out, int device_id, void *stream);
 void  gs_ctx_destroy(gs_ctx *);
 int   gs_ctx_sync(gs_ctx *);
+int   gs_ctx_release_scratch(gs_ctx *);   /* free the device scratch the context keeps between calls (it grows on demand) */
 void *gs_ctx_stream(gs_ctx *);                         /* the hipStream_t kernels are launched on */
 int   gs_ctx_device_info(gs_ctx *, int *n_cu, uint64_t *hbm_bytes, char *name, size_t name_cap);
 /* HIP-event stopwatch on the context's stream (bench.py measures kernels with it) */
