@@ -1541,7 +1541,7 @@ static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_
     GS_REQUIRE(ix->n > 0, GS_ERR_STATE, "search on an empty index");
     gs_ctx *c = ix->ctx;
     GS_HIP_CHECK(hipSetDevice(c->device));
-    gs::DevBuf dq, dids, ddist, dcount, devals;
+    gs::PoolBuf dq(c, 32), dids(c, 33), ddist(c, 34), dcount(c, 35), devals(c, 36);
     int rc;
     if ((rc = dq.alloc(ix->stride * nq))) return rc;
     if ((rc = gs::upload_rows(c, dq.p, ix->stride, queries, ix->rowbytes, nq, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;

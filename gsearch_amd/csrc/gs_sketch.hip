@@ -380,7 +380,7 @@ static int run_smh(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
                    void *sig_out)
 {
     const uint32_t m = p->sketch_size;
-    DevBuf table, cold;
+    PoolBuf table(c, 24), cold(c, 25);
     int rc;
     if ((rc = table.alloc((size_t)n_genomes * m * sizeof(T)))) return rc;
     if ((rc = cold.alloc(n_genomes))) return rc;
@@ -626,7 +626,7 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
     pc.c2 = log(2.0 / (1.0 + exp(-pc.lambda))) / pc.lambda;
     pc.c3 = (1.0 - exp(-pc.lambda)) / pc.lambda;
     int rc;
-    DevBuf upre, gunits, kpre, gkm;
+    PoolBuf upre(c, 28), gunits(c, 29), kpre(c, 30), gkm(c, 31);
     if ((rc = upre.alloc(8 * (n_rec + 1)))) return rc;
     if ((rc = gunits.alloc(8 * n_genomes))) return rc;
     if ((rc = kpre.alloc(8 * (n_rec + 1)))) return rc;
@@ -758,7 +758,7 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
     GS_HIP_CHECK(hipSetDevice(c->device));
     const uint32_t m = p->sketch_size;
     if (p->algo == GS_ALGO_OPTDENS || p->algo == GS_ALGO_REVOPTDENS) {
-        DevBuf upre, gunits, table, win;
+        PoolBuf upre(c, 20), gunits(c, 21), table(c, 22), win(c, 23);
         rc = upre.alloc(8 * (n_rec + 1)); if (rc) return rc;
         rc = gunits.alloc(8 * n_genomes); if (rc) return rc;
         rc = table.alloc((size_t)n_genomes * m * 4); if (rc) return rc;
@@ -774,7 +774,7 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
         return GS_OK;
     }
     if (p->algo == GS_ALGO_SUPER || p->algo == GS_ALGO_SUPER2) {
-        DevBuf upre, gunits;
+        PoolBuf upre(c, 20), gunits(c, 21);
         rc = upre.alloc(8 * (n_rec + 1)); if (rc) return rc;
         rc = gunits.alloc(8 * n_genomes); if (rc) return rc;
         hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 255) / 256)), dim3(256), 0, c->stream, rec_start, rec_len,
