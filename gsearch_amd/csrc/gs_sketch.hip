@@ -490,25 +490,18 @@ __global__ void k_prob_init(uint64_t *q, uint64_t *qprev, uint64_t *sig, uint64_
         q[i] = GS_INF_BITS; qprev[i] = GS_INF_BITS; sig[i] = ~(uint64_t)0; sigpass[i] = ~(uint64_t)0;
     }
 }
-__global__ void k_prob_wmax(const uint64_t *ukey, const uint32_t *ucnt, uint64_t ne, uint32_t vbits, uint32_t *wmax)
-{
-    // hundreds of millions of elements, a few hundred destination words: read first (a stale, smaller value only costs a
-    // redundant atomic) - unconditional atomics serialise on the same addresses (2 s per 128 genomes)
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t *w = &wmax[vbits >= 64 ? 0 : (ukey[e] >> vbits)];
-        const uint32_t cnt = ucnt[e];
-        if (cnt > *(volatile uint32_t *)w) atomicMax(w, cnt);
-    }
-}
 // pass `it`, phase A: i-th point of every live element -> q[b] = min
 __global__ void k_prob_point(const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ ucnt, uint64_t ne, uint32_t vbits, uint32_t m, uint64_t zone,
                              ProbConst pc, uint32_t it, const double *__restrict__ qmax, uint64_t *__restrict__ q, uint64_t *__restrict__ cand_h,
-                             uint32_t *__restrict__ cand_b)
+                             uint32_t *__restrict__ cand_b, uint32_t *__restrict__ wmax)
 {
     const uint64_t vmask = vbits >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << vbits) - 1);
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t key = ukey[e];
         const uint64_t gl = vbits >= 64 ? 0 : (key >> vbits), v = key & vmask;
+        // largest multiplicity per genome (pass 1 only): read first - hundreds of millions of elements, a few hundred words; a stale
+        // smaller value only costs a redundant atomic, unconditional atomics serialise on the same addresses
+        if (wmax) { const uint32_t cnt = ucnt[e]; if (cnt > *(volatile uint32_t *)&wmax[gl]) atomicMax(&wmax[gl], cnt); }
         const double winv = 1.0 / (double)ucnt[e];
         const double base = winv * (double)(it - 1);
         uint32_t b = 0xFFFFFFFFu; uint64_t hb = 0;
@@ -698,7 +691,6 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
             if ((rc = candh.alloc(8 * ne))) return rc;
             if ((rc = candb.alloc(4 * ne))) return rc;
             const uint32_t eg = (uint32_t)std::min<uint64_t>((ne + 255) / 256, (uint64_t)c->n_cu * 16);
-            hipLaunchKernelGGL(k_prob_wmax, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ucnt.as<uint32_t>(), ne, vbits, wmax.as<uint32_t>());
             const uint32_t ACT_CAP = 1u << 24;                       // 16 M live elements keep their generator state (0.5 GB)
             PoolBuf akey(c, 16), acnt(c, 17), astate(c, 18), nlist(c, 19);
             uint32_t n_list = 0; bool use_list = false;
@@ -706,7 +698,7 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
                 GS_HIP_CHECK(hipMemsetAsync(nact.p, 0, 4, c->stream));
                 if (!use_list) {
                     hipLaunchKernelGGL(k_prob_point, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ucnt.as<uint32_t>(), ne, vbits, m, zone, pc, it, qmax.as<double>(),
-                                       q.as<uint64_t>(), candh.as<uint64_t>(), candb.as<uint32_t>());
+                                       q.as<uint64_t>(), candh.as<uint64_t>(), candb.as<uint32_t>(), it == 1 ? wmax.as<uint32_t>() : nullptr);
                     hipLaunchKernelGGL(k_prob_claim, dim3(eg), dim3(256), 0, c->stream, vals.as<uint64_t>(), ne, vbits, m, q.as<uint64_t>(), candh.as<uint64_t>(), candb.as<uint32_t>(), sigpass.as<uint64_t>());
                 } else {
                     const uint32_t lg = std::max<uint32_t>(1, std::min<uint32_t>((n_list + 255) / 256, (uint32_t)c->n_cu * 16));
