@@ -39,15 +39,24 @@ __device__ __forceinline__ uint32_t aa_code_reg(uint32_t ch)
 __global__ void k_unit_prefix(const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *genome_rec_off,
                               uint64_t n_genomes, uint32_t k, uint64_t *rec_upre, uint64_t *gen_units)
 {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one wavefront per genome, 64 records per trip (a proteome has thousands of records: a serial loop of dependent loads per
+    // genome cost more than sketching it)
+    const uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_genomes) return;
-    uint64_t acc = 0;
-    for (uint64_t r = genome_rec_off[g]; r < genome_rec_off[g + 1]; r++) {
-        rec_upre[r] = acc;
-        uint64_t len = rec_len[r];
-        if (len >= k) { uint64_t s = rec_start[r]; acc += ((s + len - 1) >> 5) - (s >> 5) + 1; }
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1];
+    uint64_t base = 0;
+    for (uint64_t rb = r0; rb < r1; rb += 64) {
+        const uint64_t r = rb + lane;
+        uint64_t u = 0;
+        if (r < r1) { const uint64_t len = rec_len[r]; if (len >= k) { const uint64_t s = rec_start[r]; u = ((s + len - 1) >> 5) - (s >> 5) + 1; } }
+        uint64_t inc = u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+        if (r < r1) rec_upre[r] = base + inc - u;
+        base += __shfl(inc, 63);
     }
-    gen_units[g] = acc;
+    if (lane == 0) gen_units[g] = base;
 }
 
 // level-0 candidate of every slot-min sketcher (SPEC 3.1 / 3.2): element hash -> (key, slot) -> min.
@@ -461,11 +470,22 @@ __device__ __forceinline__ double texp_sample(const ProbConst &t, Rng &g)
 // k-mers per record -> exclusive prefix inside each genome
 __global__ void k_kmer_prefix(const uint64_t *rec_len, const uint64_t *genome_rec_off, uint64_t n_genomes, uint32_t k, uint64_t *rec_kpre, uint64_t *gen_kmers)
 {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);       // one wavefront per genome
     if (g >= n_genomes) return;
-    uint64_t acc = 0;
-    for (uint64_t r = genome_rec_off[g]; r < genome_rec_off[g + 1]; r++) { rec_kpre[r] = acc; uint64_t len = rec_len[r]; if (len >= k) acc += len - k + 1; }
-    gen_kmers[g] = acc;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1];
+    uint64_t base = 0;
+    for (uint64_t rb = r0; rb < r1; rb += 64) {
+        const uint64_t r = rb + lane;
+        uint64_t u = 0;
+        if (r < r1) { const uint64_t len = rec_len[r]; if (len >= k) u = len - k + 1; }
+        uint64_t inc = u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+        if (r < r1) rec_kpre[r] = base + inc - u;
+        base += __shfl(inc, 63);
+    }
+    if (lane == 0) gen_kmers[g] = base;
 }
 struct ValueEmit {
     uint64_t *out; const uint64_t *rec_start; const uint64_t *rec_kpre; uint64_t base; uint64_t tag; uint32_t k;
@@ -624,7 +644,7 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
     if ((rc = gunits.alloc(8 * n_genomes))) return rc;
     if ((rc = kpre.alloc(8 * (n_rec + 1)))) return rc;
     if ((rc = gkm.alloc(8 * n_genomes))) return rc;
-    const uint32_t gb = (uint32_t)((n_genomes + 255) / 256);
+    const uint32_t gb = (uint32_t)((n_genomes + 3) / 4);                 // one wavefront per genome
     hipLaunchKernelGGL(k_unit_prefix, dim3(gb), dim3(256), 0, c->stream, rec_start, rec_len, genome_rec_off, n_genomes, k, upre.as<uint64_t>(), gunits.as<uint64_t>());
     hipLaunchKernelGGL(k_kmer_prefix, dim3(gb), dim3(256), 0, c->stream, rec_len, genome_rec_off, n_genomes, k, kpre.as<uint64_t>(), gkm.as<uint64_t>());
     GS_HIP_CHECK(hipGetLastError());
@@ -755,7 +775,7 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
         rc = gunits.alloc(8 * n_genomes); if (rc) return rc;
         rc = table.alloc((size_t)n_genomes * m * 4); if (rc) return rc;
         if (p->algo == GS_ALGO_REVOPTDENS) { rc = win.alloc((size_t)n_genomes * m * 4); if (rc) return rc; }
-        hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 255) / 256)), dim3(256), 0, c->stream, rec_start, rec_len,
+        hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 3) / 4)), dim3(256), 0, c->stream, rec_start, rec_len,
                            genome_rec_off, n_genomes, p->k, upre.as<uint64_t>(), gunits.as<uint64_t>());
         GS_HIP_CHECK(hipGetLastError());
         uint64_t avg_units = (p->data_t == GS_DATA_AA ? seq_bytes / 32 : seq_bytes / 8) / n_genomes + 1;
@@ -769,7 +789,7 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
         PoolBuf upre(c, 20), gunits(c, 21);
         rc = upre.alloc(8 * (n_rec + 1)); if (rc) return rc;
         rc = gunits.alloc(8 * n_genomes); if (rc) return rc;
-        hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 255) / 256)), dim3(256), 0, c->stream, rec_start, rec_len,
+        hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 3) / 4)), dim3(256), 0, c->stream, rec_start, rec_len,
                            genome_rec_off, n_genomes, p->k, upre.as<uint64_t>(), gunits.as<uint64_t>());
         GS_HIP_CHECK(hipGetLastError());
         const uint64_t avg_units = (p->data_t == GS_DATA_AA ? seq_bytes / 32 : seq_bytes / 8) / n_genomes + 1;
