@@ -1213,23 +1213,22 @@ static DistMode env_mode()
     return MODE_AUTO;
 }
 static bool use_join(const gs_index *ix);
-// per-query cost model (seconds), constants measured on MI355X (profiles/):
-//   gather : frac*n evaluations, each streams one row at ~5.5e12 B/s
-//   dense  : the count matrix of the batch — match-join: the column store once per BATCH (~5e12 B/s) + ~3 ms of sort/convert;
-//            compare tile: n*m element compares at ~1.6e13/s per query — plus ~2 ns per looked-up evaluation
+// cost model of a batch of nq traversals that evaluate frac*n nodes each (seconds; constants measured on MI355X, profiles/):
+//   gather : one row streamed per evaluation: ~5.5e12 B/s for the whole GPU, but one workgroup per query and a workgroup alone
+//            pulls ~8e10 B/s, so a small batch is bound by the per-query stream
+//   dense  : the count matrix of the batch first - match-join: the column store once per batch (~3.5e12 B/s for a few hundred
+//            queries, ~1e12 B/s effective for thousands: the probe work per value grows) + ~3 ms of fixed cost; compare tile:
+//            n*m element compares at ~1.6e13/s per query - then latency-bound traversals: ~75 ns per evaluation, 768 in flight
 static bool dense_pays(const gs_index *ix, double frac, uint64_t nq)
 {
-    const double n = (double)ix->n;
-    const double gather = frac * n * (double)ix->rowbytes / 5.5e12;
+    const double n = (double)ix->n, q = (double)std::max<uint64_t>(nq, 1), evals = frac * n;
+    const double gather = evals * (double)ix->rowbytes * std::max(q / 5.5e12, 1.0 / 8.0e10);
     double dense;
-    // measured (profiles/r01_v8, tools/join_probe.py): the join streams the column store at ~3.5 TB/s for an insert batch (256
-    // queries) and ~1 TB/s effective for thousands of queries (probe work per value grows); a dense-mode evaluation costs ~0.1 ns
-    if (use_join(ix)) dense = (n * (double)ix->rowbytes / (nq <= 512 ? 3.5e12 : 1.0e12) + 3e-3) / (double)std::max<uint64_t>(nq, 1) + frac * n * 0.3e-9;
-    else dense = n * (double)ix->prm.m / (ix->prm.kind == GS_KIND_U64 ? 1.4e13 : 1.6e13) + frac * n * 2e-9;
+    if (use_join(ix)) dense = n * (double)ix->rowbytes / (nq <= 512 ? 3.5e12 : 1.0e12) * std::ceil(q / (double)match_join_max_queries()) + 3e-3;
+    else dense = std::ceil(q / 128.0) * 128.0 * n * (double)ix->prm.m / (ix->prm.kind == GS_KIND_U64 ? 1.4e13 : 1.6e13);       // 128-query tiles
+    dense += evals * 75e-9 * std::max(1.0, q / 768.0);
     return dense < gather;
 }
-
-// ---- how the dense count matrix is produced: equi-join over a column-major copy (gs_join.hip) or the compare tile kernel
 static bool use_join(const gs_index *ix)
 {
     const char *e = getenv("GS_DENSE_IMPL");
@@ -1379,9 +1378,9 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     DevBuf tmp_evals;
     // a traversal evaluates at least min(n, ef) nodes (R must fill before the stop rule can fire): when that lower bound already
     // makes the dense strategy cheaper there is nothing to probe
-    const bool lb_dense = mode == MODE_AUTO && ix->prm.m <= 65535 && nq >= 128 && ix->n >= 4096 &&
-                          dense_pays(ix, (double)std::min<uint64_t>(ix->n, efs) / (double)ix->n, nq);
-    if (mode == MODE_AUTO && !lb_dense && ix->search_frac < 0 && nq >= 256 && ix->n >= 4096) {
+    const bool eligible = mode == MODE_AUTO && ix->prm.m <= 65535 && ix->n >= 4096;
+    const bool lb_dense = eligible && dense_pays(ix, (double)std::min<uint64_t>(ix->n, efs) / (double)ix->n, nq);
+    if (eligible && !lb_dense && ix->search_frac < 0 && nq >= 256) {
         // probe: the first queries go the gather way and tell which fraction of the graph a traversal evaluates
         const uint64_t np = 128;
         uint64_t *ev = evals;
@@ -1395,10 +1394,23 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
         done = np;
     }
     const uint64_t rest = nq - done;
-    bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || lb_dense || (mode == MODE_AUTO && ix->search_frac >= 0 && rest >= 128 && dense_pays(ix, ix->search_frac, rest)));
+    // evaluated fraction: measured by an earlier search, else the one the insertions of this index measured (same graph, ef_construction)
+    const double frac_known = ix->search_frac >= 0 ? ix->search_frac : ix->insert_frac;
+    bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || lb_dense || (eligible && frac_known >= 0 && rest >= 1 && dense_pays(ix, frac_known, rest)));
     if (!dense) {
-        if (rest) return search_launch(ix, q + done * ix->stride, rest, knbn, ef, nullptr, 0, ids + done * knbn, dist + done * knbn,
-                                       count ? count + done : nullptr, evals ? evals + done : nullptr);
+        if (rest) {
+            uint64_t *ev = evals ? evals + done : nullptr;
+            if (!ev && eligible && ix->search_frac < 0) { if ((rc = tmp_evals.alloc(8 * rest))) return rc; ev = tmp_evals.as<uint64_t>(); }
+            if ((rc = search_launch(ix, q + done * ix->stride, rest, knbn, ef, nullptr, 0, ids + done * knbn, dist + done * knbn, count ? count + done : nullptr, ev))) return rc;
+            if (eligible && ix->search_frac < 0 && ev) {       // learn the evaluated fraction from this call (small batches never probe)
+                const uint64_t ns = std::min<uint64_t>(rest, 128);
+                std::vector<uint64_t> h(ns);
+                GS_HIP_CHECK(hipMemcpyAsync(h.data(), ev, 8 * ns, hipMemcpyDeviceToHost, c->stream));
+                GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+                double sum = 0; for (uint64_t v : h) sum += (double)v;
+                ix->search_frac = sum / (double)ns / (double)ix->n;
+            }
+        }
         return GS_OK;
     }
     const uint64_t ld = round_up(ix->n, 8);

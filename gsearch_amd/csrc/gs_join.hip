@@ -280,7 +280,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         const double scale = (double)m / (double)nsamp;
         const double atomics = (double)(hr[0] - hr[1]) * scale + (double)hr[1] * scale / 64.0;       // absorbed runs still flush now and then
         const double t_join = (double)n * m * sizeof(T) / 3.5e12 + atomics / 1.6e10 + (double)hr[0] * scale / 2.0e11;
-        const double t_tile = (double)nq * (double)n * (double)m / (KIND == GS_KIND_U64 ? 1.4e13 : 1.6e13);
+        const double t_tile = (double)((nq + 127) / 128 * 128) * (double)n * (double)m / (KIND == GS_KIND_U64 ? 1.4e13 : 1.6e13);   // 128-query tiles
         const char *force = getenv("GS_JOIN_DECLINE");
         const bool decline = force ? atoi(force) != 0 : t_join > t_tile;
         if (getenv("GS_JOIN_VERBOSE"))

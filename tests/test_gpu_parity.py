@@ -612,3 +612,24 @@ def test_join_declines_to_tile_kernel_on_redundant_batches(gpu_ctx, monkeypatch,
     err = capfd.readouterr().err
     if force is None:
         assert "-> est." in err and ": tile" in err                 # the natural decision on this data is the tile kernel
+
+
+@pytest.mark.parametrize("mode", ["dense", "auto"])
+def test_tiny_query_batches(gpu_ctx, monkeypatch, mode):
+    """one, two, three queries at a time (the join builds a 64-entry table, one traversal workgroup); auto mode learns the evaluated
+    fraction from its first gather call and may switch strategy for the following ones - answers never change"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", mode)
+    m = 64
+    db = H.synth_sig_db(40, 120, m, 77, jlo=0.0, jhi=0.7)           # 4800 nodes
+    oix = O.Index(np.float32, m, 8, 40, seed=3)
+    oix.parallel_insert(db, batch=256)
+    hn = G.Hnsw.new(8, 100000, 16, 40, G.DistHamming(), seed=3, insert_batch=256)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    q = H.queries_from(db, 12, 9, frac=0.2)
+    want = oix.parallel_search(q, 5, 300)
+    for lo, hi in [(0, 1), (1, 3), (3, 6), (6, 7), (7, 12)]:
+        got = hn.search_arrays(q[lo:hi], 5, 300)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b[lo:hi])
