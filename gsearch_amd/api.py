@@ -61,6 +61,10 @@ class Context:
     def sync(self):
         check(self.L.gs_ctx_sync(self.h))
 
+    def release_scratch(self):
+        """give back the device scratch the context keeps between calls (it grows on demand)"""
+        check(self.L.gs_ctx_release_scratch(self.h))
+
     def device_info(self):
         ncu, hbm, name = C.c_int(), C.c_uint64(), C.create_string_buffer(128)
         check(self.L.gs_ctx_device_info(self.h, C.byref(ncu), C.byref(hbm), name, 128))

@@ -31,6 +31,7 @@ public:
     Context &operator=(const Context &) = delete;
     gs_ctx *get() const { return h_; }
     void sync() { check(gs_ctx_sync(h_)); }
+    void release_scratch() { check(gs_ctx_release_scratch(h_)); }   // device scratch kept between calls
 private:
     gs_ctx *h_ = nullptr;
 };
