@@ -351,7 +351,7 @@ def run_request(args, torch, rank, world, local):
                 os.environ["GS_DIST_MODE"] = prev_mode
         # physical HBM traffic per launch from the committed rocprofv3 PMC summary of this same workload (separate --pmc passes)
         try:
-            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")))["kernels"]
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["kernels"]
             pmc = pmc_all.get(dom["kernel"])
             if N == 300000 and qps in (2500, 10000) and m == 18000:      # 10000 = launches of 3276+3276+3276+172 queries: 2500 on average
                 for kk in kernels:
@@ -360,7 +360,7 @@ def run_request(args, torch, rank, world, local):
             if pmc and N == 300000 and qps in (2500, 10000) and m == 18000:
                 out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_GBps"] = pmc["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9     # physical HBM rate of the launch
-                out["roofline"]["traffic_source"] = "profiles/r01_v8_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+                out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
         except Exception:
             pass
         if world > 1:                                        # parity sample and CPU baseline: rank 0 at N=1 only
