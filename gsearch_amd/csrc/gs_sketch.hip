@@ -402,9 +402,12 @@ static int run_smh(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     std::vector<uint32_t> list;
     for (uint64_t g = 0; g < n_genomes; g++) if (h[g]) list.push_back((uint32_t)g);
     const bool aa = p->data_t == GS_DATA_AA;
-    for (size_t l0 = 0; l0 < list.size(); l0 += 4096) {
-        const uint32_t nc = (uint32_t)std::min<size_t>(4096, list.size() - l0);
-        DevBuf dl, scratch;
+    // one lane per cold genome: take as many genomes per launch as 16 GB of per-lane scratch (32 m bytes each) allows - a launch lasts
+    // as long as its slowest lane, so 4096-genome chunks serialised 25 launches for 10^5 small genomes
+    const size_t per_launch = std::max<size_t>(4096, std::min<size_t>(((size_t)16 << 30) / ((size_t)32 * m), (size_t)1 << 20));
+    for (size_t l0 = 0; l0 < list.size(); l0 += per_launch) {
+        const uint32_t nc = (uint32_t)std::min<size_t>(per_launch, list.size() - l0);
+        PoolBuf dl(c, 26), scratch(c, 27);
         if ((rc = dl.alloc(4 * (size_t)nc))) return rc;
         if ((rc = scratch.alloc((size_t)nc * 32 * m))) return rc;
         GS_HIP_CHECK(hipMemcpyAsync(dl.p, list.data() + l0, 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
