@@ -310,6 +310,96 @@ __device__ void walk_genome_seq(const uint8_t *seq, const uint64_t *rec_start, c
         }
     }
 }
+// ---- cold path, parallel form: one workgroup per genome, every lane walks its own elements. The signature is an order-free
+// lexicographic minimum over (level j, r_j) keys (SPEC 3.2), so the slots take atomicMin of packed keys in LDS and the histogram
+// bound `a` of the paper (largest level still held by a slot; only a pruning device) is shared: hist[] is incremented BEFORE a key is
+// published and decremented after it is displaced, so it never under-counts a level that holds a slot and `a` can only be lowered
+// when that is safe. Lane-private Fisher-Yates state (perm / stamp arrays, m words each) lives in global scratch, element i of lane
+// l at [i * CW_T + l]. u64 signatures need 64 + 16 bits per key: pass A orders by (level, top 48 bits of r), pass B re-walks the
+// elements and takes the minimum of the full r among the visits that tie with the winner.
+constexpr int CW_T = 256;
+template <int ALGO, int VBITS, typename T, bool PASS_B>
+struct SmhWgEmit {
+    uint64_t *K, *K2; uint32_t *hist, *sa, *q, *perm; uint32_t m; uint32_t *stamp;
+    static __device__ __forceinline__ uint64_t pack(uint32_t j, uint64_t r) { return sizeof(T) == 8 ? (((uint64_t)j << 48) | (r >> 16)) : (((uint64_t)j << 32) | r); }
+    static __device__ __forceinline__ uint32_t level(uint64_t key) { return (uint32_t)(key >> (sizeof(T) == 8 ? 48 : 32)); }
+    __device__ void operator()(uint64_t v, uint64_t, uint64_t) const
+    {
+        Rng g; g.seed(elem_hash<ALGO, VBITS>(v));
+        const uint32_t st = (*stamp)++, l = threadIdx.x;
+        for (uint32_t j = 0; j <= *(volatile uint32_t *)&sa[0]; j++) {
+            uint64_t r;
+            if (ALGO == ALGO_SUPER) r = g.r23();
+            else r = sizeof(T) == 8 ? g.next64() : (uint64_t)g.next32();
+            const uint64_t range = (uint64_t)(m - j);
+            const uint32_t t = j + (uint32_t)rng_uint(g, range, uint_zone(range));
+            const uint64_t ij = (uint64_t)j * CW_T + l, it = (uint64_t)t * CW_T + l;
+            if (q[ij] != st) { q[ij] = st; perm[ij] = j; }
+            if (q[it] != st) { q[it] = st; perm[it] = t; }
+            const uint32_t tmp = perm[ij]; perm[ij] = perm[it]; perm[it] = tmp;
+            const uint32_t sl = perm[ij];
+            const uint64_t key = pack(j, r);
+            if (PASS_B) { if (key == K[sl]) atomicMin((unsigned long long *)&K2[sl], (unsigned long long)r); continue; }
+            if (key < K[sl]) {                                    // a stale (larger) read only costs a redundant attempt
+                atomicAdd(&hist[j], 1u);
+                const uint64_t old = atomicMin((unsigned long long *)&K[sl], (unsigned long long)key);
+                if (key < old) {
+                    const uint32_t jp = old == ~(uint64_t)0 ? m - 1 : level(old);
+                    atomicSub(&hist[jp], 1u);                     // jp == j: same level, smaller r -> undoes the increment
+                    uint32_t a0 = *(volatile uint32_t *)&sa[0];
+                    const uint32_t a1 = a0;
+                    while (a0 > 0 && *(volatile uint32_t *)&hist[a0] == 0) a0--;
+                    if (a0 < a1) atomicMin(&sa[0], a0);
+                } else atomicSub(&hist[j], 1u);                   // another lane got there first
+            }
+        }
+    }
+};
+template <bool AA, int ALGO, int VBITS, typename T>
+__global__ __launch_bounds__(CW_T) void k_smh_cold_wg(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
+                                                      const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off,
+                                                      const uint64_t *__restrict__ gen_units, const uint32_t *__restrict__ cold_list, uint32_t ncold, uint32_t k,
+                                                      uint32_t m, uint32_t *__restrict__ lane_q, uint32_t *__restrict__ lane_perm,
+                                                      unsigned long long *__restrict__ counter, void *__restrict__ sig)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_cw[];
+    uint64_t *K = (uint64_t *)s_cw;
+    uint64_t *K2 = sizeof(T) == 8 ? K + m : K;
+    uint32_t *hist = (uint32_t *)(K + (sizeof(T) == 8 ? 2 * (size_t)m : (size_t)m));
+    uint32_t *sa = hist + m;                                      // sa[0] = a, sa[1] = work item
+    uint32_t *q = lane_q + (uint64_t)blockIdx.x * m * CW_T, *perm = lane_perm + (uint64_t)blockIdx.x * m * CW_T;
+    uint32_t stamp = 0;                                           // unique per (lane, element) for the whole launch; the host fills q with 0xFF
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sa[1] = (uint32_t)atomicAdd(counter, 1ull);
+        __syncthreads();
+        const uint32_t c = sa[1];
+        if (c >= ncold) break;
+        const uint64_t g = cold_list[c];
+        for (uint32_t i = threadIdx.x; i < m; i += CW_T) { K[i] = ~(uint64_t)0; if (sizeof(T) == 8) K2[i] = ~(uint64_t)0; hist[i] = 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) { hist[m - 1] = m; sa[0] = m - 1; }
+        __syncthreads();
+        const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
+        {
+            SmhWgEmit<ALGO, VBITS, T, false> emit{K, K2, hist, sa, q, perm, m, &stamp};
+            walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, 0, 1, emit);
+        }
+        __syncthreads();
+        if (sizeof(T) == 8) {
+            SmhWgEmit<ALGO, VBITS, T, true> emit{K, K2, hist, sa, q, perm, m, &stamp};
+            walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, 0, 1, emit);
+            __syncthreads();
+        }
+        for (uint32_t i = threadIdx.x; i < m; i += CW_T) {
+            const uint64_t key = K[i];
+            if (ALGO == ALGO_SUPER) ((float *)sig)[g * (uint64_t)m + i] = key == ~(uint64_t)0 ? INFINITY : (float)(uint32_t)(key >> 32) + (float)(uint32_t)key * 0x1.0p-23f;
+            else if (sizeof(T) == 8) ((T *)sig)[g * (uint64_t)m + i] = (T)K2[i];
+            else ((T *)sig)[g * (uint64_t)m + i] = key == ~(uint64_t)0 ? (T)~(T)0 : (T)(uint32_t)key;
+        }
+    }
+}
+
 template <bool AA, int ALGO, int VBITS, typename T>
 __global__ void k_smh_cold(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
                            const uint64_t *__restrict__ genome_rec_off, const uint32_t *__restrict__ cold_list, uint32_t ncold, uint32_t k, uint32_t m,
@@ -402,6 +492,32 @@ static int run_smh(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     std::vector<uint32_t> list;
     for (uint64_t g = 0; g < n_genomes; g++) if (h[g]) list.push_back((uint32_t)g);
     const bool aa = p->data_t == GS_DATA_AA;
+    // parallel form (one workgroup per genome) when the slot keys + level histogram fit in LDS
+    const size_t lds_wg = (sizeof(T) == 8 ? 20 : 12) * (size_t)m + 16;
+    if (!list.empty() && lds_wg <= 150 * 1024 && m <= 65535 && !getenv("GS_SMH_COLD_SERIAL")) {
+        const uint32_t nc = (uint32_t)list.size();
+        const uint32_t wgs = std::min<uint32_t>(nc, (uint32_t)c->n_cu * 2);
+        PoolBuf dl(c, 26), lq(c, 27), lp(c, 37), cnt(c, 38);
+        if ((rc = dl.alloc(4 * (size_t)nc))) return rc;
+        if ((rc = lq.alloc((size_t)4 * wgs * m * CW_T))) return rc;
+        if ((rc = lp.alloc((size_t)4 * wgs * m * CW_T))) return rc;
+        if ((rc = cnt.alloc(64))) return rc;
+        GS_HIP_CHECK(hipMemcpyAsync(dl.p, list.data(), 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
+        GS_HIP_CHECK(hipMemsetAsync(lq.p, 0xFF, (size_t)4 * wgs * m * CW_T, c->stream));
+        GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 8, c->stream));
+#define GS_LAUNCH_COLDWG(AAV)                                                                                                  \
+    do {                                                                                                                       \
+        auto kern = k_smh_cold_wg<AAV, ALGO, VBITS, T>;                                                                        \
+        if (lds_wg > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg)); \
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(CW_T), lds_wg, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, p->k, m, \
+                           lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), sig_out);                       \
+    } while (0)
+        if (aa) GS_LAUNCH_COLDWG(true); else GS_LAUNCH_COLDWG(false);
+#undef GS_LAUNCH_COLDWG
+        GS_HIP_CHECK(hipGetLastError());
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return GS_OK;
+    }
     // one lane per cold genome: take as many genomes per launch as 16 GB of per-lane scratch (32 m bytes each) allows - a launch lasts
     // as long as its slowest lane, so 4096-genome chunks serialised 25 launches for 10^5 small genomes
     const size_t per_launch = std::max<size_t>(4096, std::min<size_t>(((size_t)16 << 30) / ((size_t)32 * m), (size_t)1 << 20));

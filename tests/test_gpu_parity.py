@@ -202,15 +202,26 @@ def test_sketch_super_matches_oracle(gpu_ctx, k, m, algo, data):
 
 
 @pytest.mark.parametrize("algo,data,k", [("super", "dna", 21), ("super2", "dna", 21), ("super2", "dna", 12), ("super2", "aa", 7)])
-def test_sketch_super_cold_path_matches_oracle(gpu_ctx, algo, data, k):
-    """few k-mers, many slots: slots stay empty after level 0 -> exact sequential walk on the device"""
+@pytest.mark.parametrize("serial", [False, True])
+def test_sketch_super_cold_path_matches_oracle(gpu_ctx, algo, data, k, serial, monkeypatch):
+    """few k-mers, many slots: slots stay empty after level 0 -> exact walk on the device: one workgroup per genome with atomicMin on
+    packed (level, r) keys, or (large sketches; forced here) the sequential one-lane-per-genome kernel"""
     import gsearch_amd as G
+    if serial:
+        monkeypatch.setenv("GS_SMH_COLD_SERIAL", "1")
     rng = np.random.default_rng(17)
     if data == "dna":
         genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (30, 500, 3000)] + [[b"ACGT"]]
     else:
         genomes = [[H.aa_ascii(rng.integers(0, 20, n))] for n in (20, 400, 2500)] + [[b"MK"]]
     genomes.append([H.dna_ascii(H.rand_dna(rng, 40000))] if data == "dna" else [H.aa_ascii(rng.integers(0, 20, 40000))])
+    # several records, one of them shorter than k, and a genome whose k-mers all repeat
+    if data == "dna":
+        genomes.append([H.dna_ascii(H.rand_dna(rng, 700)), b"ACG", H.dna_ascii(H.rand_dna(rng, 90))])
+        genomes.append([b"ACGT" * 40])
+    else:
+        genomes.append([H.aa_ascii(rng.integers(0, 20, 300)), b"MK", H.aa_ascii(rng.integers(0, 20, 60))])
+        genomes.append([b"MKV" * 30])
     sk = G.sketcher_for(G.SeqSketcherParams(k, 1024, algo, data))
     got = sk.sketch_genomes(genomes)
     ref = _oracle_sketch(k, 1024, algo, genomes, data)
