@@ -147,7 +147,8 @@ def run_sketch(args, torch, rank, world, local):
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": None, "kernel": "k_sketch_oph", "avg_launch_ms": avg_ms, "launches": kern_n,
                            "algorithmic_bytes_per_launch": alg_bytes_launch,
-                           "note": "hash-bound kernel: 0.264 B/k-mer of HBM traffic against ~250 VALU ops/k-mer (DESIGN.md)",
+                           "note": "VALU-bound kernel: 0.264 B/k-mer of HBM traffic against 113.7 VALU wave-instructions per k-mer; rocprofv3 SQ counters show the VALU pipes saturated (profiles/r01_sketch_min_pmc_valu.txt, DESIGN.md 3.1)",
+                           "valu_instr_per_kmer": 113.7, "valu_busy_frac_pmc": 1.0,
                            "kmers_per_sec_kernel": kmers_per_genome * ng / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
         # parity spot check + CPU baseline (oracle = checker / baseline only, never the measured path)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
