@@ -3,14 +3,18 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sketch|request]
 
-One rank per GPU (launched by torch.distributed.run for N > 1). A *step* is one pass of the hot path over one
-batch of synthetic input that is already resident in HBM:
+One rank per GPU. `python bench.py --gpus N` starts the N ranks itself (gsearch_amd.sharding.ensure_launched re-executes this
+script under torch.distributed.run on 127.0.0.1); when a launcher already set RANK/WORLD_SIZE the script is one of its ranks.
+A *step* is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
 
   request (default; BASELINE.json configs[2]/[3]): sketch 10 000 query genomes (5 Mbp) + HNSW parallel_search (n=50, ef=5000)
           against a 300k-genome OptDens HNSW built on the GPU from synthetic genomes during (untimed) setup.
   sketch  (BASELINE.json configs[1]): 10k synthetic 5 Mbp genomes, k=21, s=18000, --algo optdens, per rank.
 
-Rank 0 prints ONE JSON line (metric/value/... plus `roofline` and `cpu_baseline`, see DESIGN.md "measurement").
+Rank 0 prints ONE JSON line (metric/value/... plus `roofline`, `kernels` and `cpu_baseline`; DESIGN.md "measurement").
+Every kernel is priced against the ceiling of its real class: HBM bytes for the row-gather distance kernel,
+memory-side atomics/s for the match-join, VALU issue for the sketch kernel, and for the latency-bound dense traversal its
+algorithmic bytes (adjacency rows + 2-byte count lookups) against HBM peak next to pops/s.
 """
 import argparse
 import json
@@ -24,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ATOMICS_PEAK = 1.6e10          # memory-side (device-scope) 32-bit atomics/s measured on MI355X: profiles/r01_match_join_pmc.txt
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md:52-54: a wave64 VALU op issues in 2 cycles (SIMD-32)
 MASK64 = (1 << 64) - 1
 
 
@@ -46,57 +52,121 @@ def synth_genome_packed(seed, g, length):
     return x.view(np.uint8)
 
 
-def dist_init(n_gpus):
-    import torch
-    rank, world, local = 0, 1, 0
-    if n_gpus > 1 or "RANK" in os.environ:
-        import torch.distributed as dist
-        rank = int(os.environ.get("RANK", "0"))
-        world = int(os.environ.get("WORLD_SIZE", "1"))
-        local = int(os.environ.get("LOCAL_RANK", str(rank)))
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
-    return torch, rank, world, local
+class Dist:
+    """rank bookkeeping + the few collectives the bench itself needs (barrier, max/sum of a scalar)"""
 
+    def __init__(self, backend):
+        import torch
+        from gsearch_amd import sharding as S
+        self.torch = torch
+        self.rank, self.world, self.local = S.rank_env()
+        self.backend = backend
+        self.on = "RANK" in os.environ            # under a launcher the collectives run even with one rank
+        if backend == "nccl":
+            torch.cuda.set_device(self.local)
+        if self.on:
+            import torch.distributed as td
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            kw = {"device_id": torch.device("cuda", self.local)} if backend == "nccl" else {}
+            td.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+        self.device = torch.device("cuda", self.local) if backend == "nccl" else torch.device("cpu")
 
-def barrier_sync(torch, world):
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
+    def barrier_sync(self):
+        if self.on:
+            import torch.distributed as td
+            td.barrier()
+        if self.backend == "nccl":
+            self.torch.cuda.synchronize()
 
+    def _reduce(self, value, op):
+        if not self.on:
+            return value
+        import torch.distributed as td
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device)
+        td.all_reduce(t, op=op)
+        return float(t.item())
 
-def max_over_ranks(torch, world, value):
-    if world == 1:
-        return value
-    import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    def max(self, v):
+        import torch.distributed as td
+        return self._reduce(v, td.ReduceOp.MAX)
 
+    def sum(self, v):
+        import torch.distributed as td
+        return self._reduce(v, td.ReduceOp.SUM)
 
-def sum_over_ranks(torch, world, value):
-    if world == 1:
-        return value
-    import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+    def finish(self):
+        if self.on:
+            import torch.distributed as td
+            td.barrier()                      # rank 0 may still be timing the CPU baseline: leave together
+            td.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------------
-def run_sketch(args, torch, rank, world, local):
+def run_selftest_launch(args, D):
+    """launch-path self-test without GPUs (tests/test_bench_launch.py): the same launcher, rank bookkeeping, barrier/max timing and
+    the packed single all-gather as the real run, with a stub searcher whose answers are a known function of the global query id."""
+    from gsearch_amd import sharding as S
+    torch = D.torch
+    nq, knbn = 37, 5
+    ex = S.TopkExchange(nq, knbn, D.world, D.device)
+    gq = torch.arange(D.rank * nq, (D.rank + 1) * nq, dtype=torch.int64).view(nq, 1)
+    j = torch.arange(knbn, dtype=torch.int64).view(1, knbn)
+    ex.ids.copy_(gq * 1000 + j)
+    ex.dist.copy_((gq * 8 + j).to(torch.float32) / 64.0)
+    D.barrier_sync()
+    t0 = time.perf_counter()
+    ex.exchange()
+    D.barrier_sync()
+    dt = D.max(time.perf_counter() - t0)
+    ids, dist = ex.gathered()
+    allq = torch.arange(D.world * nq, dtype=torch.int64).view(-1, 1)
+    ok = bool(torch.equal(ids, allq * 1000 + j) and torch.equal(dist, (allq * 8 + j).to(torch.float32) / 64.0))
+    ranks = D.sum(float(1 << D.rank))
+    if D.rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": D.world, "backend": D.backend, "rank_mask": int(ranks), "collectives_per_step": 1,
+                          "gathered_equals_expected": ok, "seconds": dt}))
+
+
+# ------------------------------------------------------------------------------------------------------
+def cpu_sketch_baseline(O, op, args, kmers_per_genome, words, cores):
+    """oracle sketch (OpenMP, one task per genome - the reference's decomposition, dnasketch.rs:322-357) on a bounded sample"""
+    L = args.genome_len
+    ns = max(args.cpu_sample, cores)
+    pk = [synth_genome_packed(args.seed, i, L) for i in range(8)]
+    wpad = words * 8                                   # the sample re-uses 8 distinct genomes round-robin: same work, bounded memory
+    buf = np.zeros(len(pk) * wpad + 16, np.uint8)
+    for i, b in enumerate(pk):
+        buf[i * wpad:(i + 1) * wpad] = b
+    srs = (np.arange(ns, dtype=np.uint64) % np.uint64(len(pk))) * np.uint64(words * 32)
+    t0 = time.perf_counter()
+    O.sketch_batch(op, buf, srs, np.full(ns, L, np.uint64), np.arange(ns + 1, dtype=np.uint64), nthreads=cores)
+    cdt = time.perf_counter() - t0
+    return {"value": kmers_per_genome * ns / cdt, "unit": "k-mers/s", "cores": cores, "threads": cores, "kind": "port",
+            "sample": "%d genomes x %.1f Mbp, k=%d s=%d optdens, oracle/gs_oracle.c with OpenMP on all %d host threads (one task per genome), %.1f s wall"
+                      % (ns, L / 1e6, args.kmer, args.sketch_size, cores, cdt),
+            "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
+
+
+def sketch_valu_model(kmers_per_sec):
+    """VALU issue model of k_sketch_min from the committed ISA instruction mix (tools/isa_mix.py -> profiles/*_sketch_isa_mix.json)"""
+    path = os.path.join(ROOT, "profiles", "r02_sketch_isa_mix.json")
+    if not os.path.exists(path):
+        return None
+    mix = json.load(open(path))
+    cyc = mix["issue_cycles_per_kmer"]                     # sum over instruction classes of count x issue cycles (2-cycle base, measured weights)
+    peak = SIMDS * CLOCK_HZ / cyc * 64                     # k-mers/s if every SIMD issued nothing but this stream
+    return {"bound": "valu", "valu_wave_instr_per_kmer": mix["valu_per_kmer"], "issue_cycles_per_kmer_per_lane_x64": cyc,
+            "kmers_per_sec_at_issue_ceiling": peak, "frac": kmers_per_sec / peak, "source": "profiles/r02_sketch_isa_mix.json (static ISA count, tools/isa_mix.py)"}
+
+
+def run_sketch(args, D):
     import ctypes as C
     import gsearch_amd as G
-    from gsearch_amd.api import _p
 
     k, m, L = args.kmer, args.sketch_size, args.genome_len
     ng = args.genomes                      # per rank (weak scaling)
-    ctx = G.Context(local)
+    ctx = G.Context(D.local)
     lib = ctx.L
     prm = G.SeqSketcherParams(k, m, "optdens")
     words = (L + 31) // 32
@@ -108,7 +178,7 @@ def run_sketch(args, torch, rank, world, local):
     goff = np.arange(ng + 1, dtype=np.uint64)
     d_rs, d_rl, d_goff = ctx.alloc(rs.nbytes), ctx.alloc(rl.nbytes), ctx.alloc(goff.nbytes)
     ctx.upload(d_rs, rs); ctx.upload(d_rl, rl); ctx.upload(d_goff, goff)
-    first = rank * ng
+    first = D.rank * ng
     G._lib.check(lib.gs_synth_dna_dev(ctx.h, args.seed, first, ng, L, d_seq))
     ctx.sync()
 
@@ -119,37 +189,36 @@ def run_sketch(args, torch, rank, world, local):
         step()
     ctx.profile(True)
     ctx.profile_read(0, reset=True)
-    barrier_sync(torch, world)
+    D.barrier_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier_sync(torch, world)
-    dt = max_over_ranks(torch, world, time.perf_counter() - t0)
+    D.barrier_sync()
+    dt = D.max(time.perf_counter() - t0)
     kern_ms, kern_n = ctx.profile_read(0, reset=True)
     ctx.profile(False)
 
     kmers_per_genome = L - k + 1
-    total_kmers = float(kmers_per_genome) * ng * world * args.steps
-    value = total_kmers / dt
+    value = float(kmers_per_genome) * ng * D.world * args.steps / dt
     out = {
-        "metric": "sketch k-mers/sec", "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps,
+        "metric": "sketch k-mers/sec", "value": value, "unit": "k-mers/s", "n_gpus": D.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "sketch-only: %d synthetic %.1f Mbp genomes per GPU, k=%d s=%d optdens (BASELINE configs[1])" % (ng, L / 1e6, k, m),
                    "genomes_per_gpu": ng, "genome_len": L, "kmer_size": k, "sketch_size": m, "algo": "optdens"},
-        "genomes_per_sec": ng * world * args.steps / dt,
+        "genomes_per_sec": ng * D.world * args.steps / dt,
     }
-    if rank == 0:
-        # roofline of the dominant kernel (k_sketch_oph): algorithmic bytes = ceil(L/4) + m*4 per genome
+    if D.rank == 0:
+        # roofline of the dominant kernel (k_sketch_min): algorithmic bytes = ceil(L/4) + m*4 per genome
         alg_bytes_launch = (float((L + 3) // 4) + m * 4.0) * ng
         avg_ms = kern_ms / max(kern_n, 1)
         achieved = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kps = kmers_per_genome * ng / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "k_sketch_oph", "avg_launch_ms": avg_ms, "launches": kern_n,
-                           "algorithmic_bytes_per_launch": alg_bytes_launch,
-                           "note": "VALU-bound kernel: 0.264 B/k-mer of HBM traffic against 113.7 VALU wave-instructions per k-mer; rocprofv3 SQ counters show the VALU pipes saturated (profiles/r01_sketch_min_pmc_valu.txt, DESIGN.md 3.1)",
-                           "valu_instr_per_kmer": 113.7, "valu_busy_frac_pmc": 1.0,
-                           "kmers_per_sec_kernel": kmers_per_genome * ng / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
+                           "traffic": pmc_traffic("k_sketch_min"), "kernel": "k_sketch_min", "avg_launch_ms": avg_ms, "launches": kern_n,
+                           "algorithmic_bytes_per_launch": alg_bytes_launch, "kmers_per_sec_kernel": kps, "class": "valu",
+                           "note": "hash-bound kernel: 0.264 B of HBM traffic per k-mer; the binding resource is VALU issue (valu_model)"}
+        out["roofline"]["valu_model"] = sketch_valu_model(kps)
         # parity spot check + CPU baseline (oracle = checker / baseline only, never the measured path)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -162,36 +231,41 @@ def run_sketch(args, torch, rank, world, local):
             ref = O.sketch_batch(op, pk, np.zeros(1, np.uint64), np.array([L], np.uint64), np.array([0, 1], np.uint64))
             ok &= bool(np.array_equal(ref.view(np.uint32)[0], sig_dev.view(np.uint32)[g]))
         out["parity_checked"] = {"genomes": chk, "bit_exact_vs_oracle": ok}
-        cores = os.cpu_count() or 1
-        ns = args.cpu_sample
-        pk = [synth_genome_packed(args.seed, i, L) for i in range(min(ns, 8))]
-        # the sample re-uses 8 distinct genomes round-robin: identical work per genome, bounded host memory
-        wpad = words * 8
-        buf = np.zeros(len(pk) * wpad + 16, np.uint8)
-        for i, b in enumerate(pk):
-            buf[i * wpad:(i + 1) * wpad] = b
-        srs = (np.arange(ns, dtype=np.uint64) % np.uint64(len(pk))) * np.uint64(words * 32)
-        srl = np.full(ns, L, np.uint64)
-        t0 = time.perf_counter()
-        O.sketch_batch(op, buf, srs, srl, np.arange(ns + 1, dtype=np.uint64), nthreads=cores)
-        cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": kmers_per_genome * ns / cdt, "unit": "k-mers/s", "cores": cores, "kind": "port",
-                               "sample": "%d genomes x %.1f Mbp, k=%d s=%d optdens, oracle/gs_oracle.c with OpenMP (one task per genome), %.1f s wall"
-                                         % (ns, L / 1e6, k, m, cdt),
-                               "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
+        out["cpu_baseline"] = cpu_sketch_baseline(O, op, args, kmers_per_genome, words, os.cpu_count() or 1) if D.world == 1 else None
         print(json.dumps(out))
     for p in (d_seq, d_sig, d_rs, d_rl, d_goff):
         ctx.free(p)
 
 
+_PMC = None
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from rocprofv3 --pmc passes over THIS command, when a sidecar produced by tools/pmc_bench.sh
+    in the same session is named by GS_PMC_SIDECAR (the raw counter CSVs it condenses are committed next to it under profiles/).
+    None otherwise - the bench never looks numbers up by configuration."""
+    global _PMC
+    if _PMC is None:
+        _PMC = {}
+        p = os.environ.get("GS_PMC_SIDECAR")
+        if p and os.path.exists(p):
+            try:
+                _PMC = json.load(open(p))
+            except Exception:
+                _PMC = {}
+    k = _PMC.get("kernels", {}).get(kernel)
+    return None if not k else k.get("hbm_bytes_per_launch")
+
+
 # ------------------------------------------------------------------------------------------------------
-def run_request(args, torch, rank, world, local):
+def run_request(args, D):
     """BASELINE configs[2] (and [3] for N>1): `request` = sketch the query genomes + HNSW parallel_search (ef=5000, n=50)
     against a prebuilt OptDens HNSW (M=128, efc=1600, scale 0.25) over `--db-genomes` synthetic genomes, DB replicated
-    per GPU, queries sharded, top-k all-gathered over RCCL."""
+    per GPU, queries sharded, top-k all-gathered over RCCL (one packed collective per step)."""
     import ctypes as C
     import gsearch_amd as G
-    from gsearch_amd.api import _p
+    from gsearch_amd import sharding as S
+    torch = D.torch
     chk = G._lib.check
 
     k, m, L = args.kmer, args.sketch_size, args.genome_len
@@ -199,7 +273,7 @@ def run_request(args, torch, rank, world, local):
     knbn, ef = args.knbn, args.ef_search
     n_roots = max(N // args.per_root, 1)
     mu_lo, mu_hi = 0.001, 0.08
-    ctx = G.Context(local)
+    ctx = G.Context(D.local)
     lib = ctx.L
     prm = G.SeqSketcherParams(k, m, "optdens")
     words = (L + 31) // 32
@@ -226,7 +300,7 @@ def run_request(args, torch, rank, world, local):
         chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, g0, n, L, n_roots, mu_lo, mu_hi, d_seq))
         sketch_dev(d_seq, n, d_sig, d_rs, d_rl, d_goff)
         chk(lib.gs_index_parallel_insert_dev(hn.h, d_sig, n))
-        if rank == 0 and args.verbose:
+        if D.rank == 0 and args.verbose:
             print("# built %d / %d in %.1fs" % (g0 + n, N, time.perf_counter() - t_b), file=sys.stderr, flush=True)
     ctx.sync()
     build_s = time.perf_counter() - t_b
@@ -234,18 +308,13 @@ def run_request(args, torch, rank, world, local):
 
     # ---- query genomes resident in HBM before the timed region: fresh mutants of the DB's roots
     d_qseq = ctx.alloc(nq_rank * gbytes + 64)
-    q_first = 1_000_000_000 + rank * nq_rank
+    q_first = 1_000_000_000 + D.rank * nq_rank
     chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, q_first, nq_rank, L, n_roots, mu_lo, mu_hi, d_qseq))
     d_qsig = ctx.alloc(qps * m * 4)
-    ids_t = torch.empty((qps, knbn), dtype=torch.int64, device="cuda")
-    dist_t = torch.empty((qps, knbn), dtype=torch.float32, device="cuda")
-    cnt_t = torch.empty((qps,), dtype=torch.int32, device="cuda")
-    ev_t = torch.zeros((qps,), dtype=torch.int64, device="cuda")
-    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the all-gather runs even with one rank
-    if use_dist:
-        import torch.distributed as dist
-        all_ids = torch.empty((world * qps, knbn), dtype=torch.int64, device="cuda")
-        all_dist = torch.empty((world * qps, knbn), dtype=torch.float32, device="cuda")
+    ex = S.TopkExchange(qps, knbn, D.world if D.on else 1, D.device)       # ids + distances in one send buffer -> ONE all-gather per step
+    ids_t, dist_t = ex.ids, ex.dist
+    cnt_t = torch.empty((qps,), dtype=torch.int32, device=D.device)
+    ev_t = torch.zeros((qps,), dtype=torch.int64, device=D.device)
     nsteps_q = max(nq_rank // qps, 1)
     evals_steps = []
 
@@ -253,15 +322,16 @@ def run_request(args, torch, rank, world, local):
         b = i % nsteps_q
         sketch_dev(d_qseq + b * qps * gbytes, qps, d_qsig, d_rs, d_rl, d_goff)
         chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, qps, knbn, ef, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), ev_t.data_ptr()))
-        if use_dist:       # RCCL all-gather of the per-rank top-k blocks (ids + distances), SURVEY 8e
-            dist.all_gather_into_tensor(all_ids, ids_t)
-            dist.all_gather_into_tensor(all_dist, dist_t)
+        if D.on:           # RCCL all-gather of the per-rank top-k blocks
+            ex.exchange()
 
     for i in range(args.warmup):
         step(args.steps + i)
     ctx.profile(True)
-    ctx.profile_read(2, reset=True); ctx.profile_read(0, reset=True)
-    barrier_sync(torch, world)
+    for fam in range(4):
+        ctx.profile_read(fam, reset=True)
+    stats0 = hn.search_stats(reset=True)
+    D.barrier_sync()
     t0 = time.perf_counter()
     step_ms = []
     for i in range(args.steps):
@@ -269,146 +339,170 @@ def run_request(args, torch, rank, world, local):
         step(i)
         step_ms.append((time.perf_counter() - t_s) * 1e3)      # the library calls return when their results are ready
         evals_steps.append(ev_t.clone())
-    barrier_sync(torch, world)
-    dt = max_over_ranks(torch, world, time.perf_counter() - t0)
+    D.barrier_sync()
+    dt = D.max(time.perf_counter() - t0)
     srch_ms, srch_n = ctx.profile_read(2, reset=True)
     tile_ms, tile_n = ctx.profile_read(1, reset=True)
     sk_ms, sk_n = ctx.profile_read(0, reset=True)
     ctx.profile(False)
+    st = hn.search_stats(reset=True)
+    del stats0
     evals_total = float(sum(int(e.sum().item()) for e in evals_steps))
-    value = world * qps * args.steps / dt
+    value = D.world * qps * args.steps / dt
     out = {
-        "metric": "query genomes/sec", "value": value, "unit": "genomes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "query genomes/sec", "value": value, "unit": "genomes/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "request: %d query genomes x %.1f Mbp per GPU per step (k=%d s=%d optdens sketch + HNSW search n=%d ef=%d) against a %d-genome "
                                "OptDens HNSW (M=%d efc=%d scale %.2f) built on the GPU, DB replicated per GPU, queries sharded (BASELINE configs[2]/[3])"
                                % (qps, L / 1e6, k, m, knbn, ef, N, args.max_nb_conn, args.ef_construction, args.scale_modify),
                    "db_genomes": N, "queries_per_gpu_per_step": qps, "genome_len": L, "kmer_size": k, "sketch_size": m, "knbn": knbn, "ef_search": ef,
-                   "max_nb_conn": args.max_nb_conn, "ef_construction": args.ef_construction},
+                   "max_nb_conn": args.max_nb_conn, "ef_construction": args.ef_construction, "collectives_per_step": 1 if D.on else 0},
         "step_ms": [round(x, 2) for x in step_ms], "build_seconds": build_s, "build_genomes_per_sec": N / build_s, "dist_evals_per_query": evals_total / (qps * args.steps),
         "sketch_kmers_per_sec": (L - k + 1) * qps * sk_n / (sk_ms * 1e-3) if sk_ms > 0 else None,
     }
-    if rank == 0:
-        # per-kernel accounting over the timed region (HIP events around every launch on the library's stream)
-        row_bytes = m * 4.0                                           # 72 000 B per (query,candidate) evaluation, SURVEY 8d
-        kernels = []
-        join = os.environ.get("GS_DENSE_IMPL", "join") != "tile"
-        if tile_n:   # dense mode: the counts of every (query, node) pair of the step are produced up front
-            pairs_total = float(qps) * N * args.steps          # (the gather-mode probe of the very first call happens during warm-up)
-            avg_ms = tile_ms / tile_n
-            kd = {"kernel": "k_match_join" if join else "k_hamming_qxc",
-                  "role": ("equi-join of the query batch with the column-major DB copy (all query x node pairs)" if join
-                           else "dense DistHamming compare tile (all query x node pairs)"),
-                  "total_ms": tile_ms, "launches": tile_n, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": pairs_total / tile_n * row_bytes,
-                  "achieved_GBps": pairs_total * row_bytes / (tile_ms * 1e-3) / 1e9}
-            if join:
-                kd["physical_stream_bytes_per_launch"] = float(N) * row_bytes + 2.0 * qps * N * (tile_n / float(args.steps))
-                kd["physical_stream_GBps"] = kd["physical_stream_bytes_per_launch"] * tile_n / (tile_ms * 1e-3) / 1e9
-            else:
-                valu_peak = 256 * 4 * 64 / (2 * 2.0) * 2.4e9                  # 2 VALU instr per pair-element, 2 cycles per wave64 instr, 2.4 GHz
-                kd.update({"pair_elements_per_sec": pairs_total * m / (tile_ms * 1e-3), "valu_peak_pair_elements_per_sec": valu_peak,
-                           "valu_frac": pairs_total * m / (tile_ms * 1e-3) / valu_peak})
-            kernels.append(kd)
-        kernels.append({"kernel": "k_hnsw_search_dense" if tile_n else "k_hnsw_search",
-                        "role": "HNSW traversal (dense mode: looks the counts up in the query x node matrix)" if tile_n else "HNSW traversal (gather mode: streams one row per evaluation)",
-                        "total_ms": srch_ms,
-                        "launches": srch_n, "avg_launch_ms": srch_ms / max(srch_n, 1),
-                        "algorithmic_bytes_per_launch": evals_total / max(srch_n, 1) * row_bytes,
-                        "achieved_GBps": evals_total * row_bytes / (srch_ms * 1e-3) / 1e9 if srch_ms > 0 else 0.0})
-        kernels.append({"kernel": "k_sketch_min", "role": "query sketching", "total_ms": sk_ms, "launches": sk_n})
-        dom = max([kk for kk in kernels if kk["kernel"] != "k_sketch_min"], key=lambda kk: kk["total_ms"])
-        out["roofline"] = {"bound": "hbm", "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved_GBps"] / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
-                           "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                           "note": ("dense mode: the tile kernel reads each candidate row once per 128 queries, so the algorithmic bytes (72 kB per "
-                                    "evaluated pair) exceed physical HBM traffic and frac > 1; its binding resource is VALU issue (valu_frac)")
-                                   if dom["kernel"] == "k_hamming_qxc" else
-                                   ("dense mode: DistHamming counts come from the match-join / tile matrix and the traversal only looks them up, so the "
-                                    "72 kB-per-evaluation figure of SURVEY 8d is nominal (frac > 1 = HBM bytes avoided, not bandwidth); the traversal "
-                                    "itself is latency-bound (DESIGN.md 3.6)" if tile_n
-                                    else "gather mode: one 72 kB row streamed from HBM per evaluation")}
-        out["kernels"] = kernels
-        # the row-streaming (gather) form of the same search on a sub-batch: the HBM-bound DistHamming kernel the north star prices
-        # against the HBM roofline (>= 40 % target); results are identical, only the evaluation strategy differs
-        ng_q = min(256, qps)
-        prev_mode = os.environ.get("GS_DIST_MODE")
-        os.environ["GS_DIST_MODE"] = "gather"
-        try:
-            ev_g = torch.zeros((ng_q,), dtype=torch.int64, device="cuda")
-            ids_g2 = torch.empty((ng_q, knbn), dtype=torch.int64, device="cuda")
-            dist_g2 = torch.empty((ng_q, knbn), dtype=torch.float32, device="cuda")
-            ctx.profile(True); ctx.profile_read(2, reset=True)
-            chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, ng_q, knbn, ef, ids_g2.data_ptr(), dist_g2.data_ptr(), cnt_t.data_ptr(), ev_g.data_ptr()))
-            g_ms, g_n = ctx.profile_read(2, reset=True); ctx.profile(False)
-            g_bytes = float(ev_g.sum().item()) * row_bytes
-            out["roofline_gather_mode"] = {"bound": "hbm", "kernel": "k_hnsw_search (GS_DIST_MODE=gather)", "queries": ng_q, "launch_ms": g_ms / max(g_n, 1),
-                                           "algorithmic_bytes": g_bytes, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "same_answers_as_dense": bool(torch.equal(ids_g2, ids_t[:ng_q]) and torch.equal(dist_g2, dist_t[:ng_q]))}
-        finally:
-            if prev_mode is None:
-                os.environ.pop("GS_DIST_MODE", None)
-            else:
-                os.environ["GS_DIST_MODE"] = prev_mode
-        # physical HBM traffic per launch from the committed rocprofv3 PMC summary of this same workload (separate --pmc passes)
-        try:
-            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["kernels"]
-            pmc = pmc_all.get(dom["kernel"])
-            if N == 300000 and qps in (2500, 10000) and m == 18000:      # 10000 = launches of 3276+3276+3276+172 queries: 2500 on average
-                for kk in kernels:
-                    if kk["kernel"] in pmc_all and kk["kernel"] != "k_match_join":   # the join's largest-grid launches are insert-time ones
-                        kk["pmc_hbm_bytes_per_launch"] = pmc_all[kk["kernel"]]["hbm_bytes_per_launch"]
-            if pmc and N == 300000 and qps in (2500, 10000) and m == 18000:
-                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_GBps"] = pmc["hbm_bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9     # physical HBM rate of the launch
-                out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
-        except Exception:
-            pass
-        if world > 1:                                        # parity sample and CPU baseline: rank 0 at N=1 only
+    if D.rank == 0:
+        out.update(request_accounting(args, ctx, hn, lib, chk, torch, D, dict(
+            srch=(srch_ms, srch_n), tile=(tile_ms, tile_n), sk=(sk_ms, sk_n), stats=st, evals_total=evals_total, d_qsig=d_qsig, ids_t=ids_t,
+            dist_t=dist_t, cnt_t=cnt_t)))
+        if D.world > 1:                                        # parity sample and CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = None
-            print(json.dumps(out))
-            return
-        # ---- parity / recall / CPU baseline on a bounded sample of the last step's queries
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        ns = min(args.cpu_sample_queries, qps)
-        last = (args.steps - 1) % nsteps_q
-        qsig = ctx.download(d_qsig, (qps, m), np.float32)[:ns]
-        ids_g = ids_t.cpu().numpy().view(np.uint64)[:ns]
-        dist_g = dist_t.cpu().numpy()[:ns]
-        # (a) sketch parity + CPU sketch time for the sample's genomes
-        op = O.params(k, m, "optdens")
-        qbytes = ctx.download(d_qseq + last * qps * gbytes, (ns, gbytes), np.uint8)
-        buf = np.concatenate([qbytes.reshape(-1), np.zeros(16, np.uint8)])
-        cores = os.cpu_count() or 1
-        t0 = time.perf_counter()
-        osig = O.sketch_batch(op, buf, np.arange(ns, dtype=np.uint64) * np.uint64(words * 32), np.full(ns, L, np.uint64),
-                              np.arange(ns + 1, dtype=np.uint64), nthreads=cores)
-        cpu_sketch_s = time.perf_counter() - t0
-        sketch_ok = bool(np.array_equal(osig.view(np.uint32), qsig.view(np.uint32)))
-        # (b) the same graph searched by the oracle (CPU, all cores)
-        db = hn.get_data()
-        oix = O.Index(np.float32, m, args.max_nb_conn, args.ef_construction, scale_modify=args.scale_modify, seed=args.seed)
-        oix.import_graph(db, hn.export_graph())
-        t0 = time.perf_counter()
-        oids, odist, ocnt, oev = oix.parallel_search(qsig, knbn, ef, nthreads=min(cores, ns))
-        cpu_search_s = time.perf_counter() - t0
-        ids_ok = bool(np.array_equal(oids, ids_g)) and bool(np.array_equal(odist.view(np.uint32), dist_g.view(np.uint32)))
-        evals_ok = bool(np.array_equal(oev, ev_t.cpu().numpy().view(np.uint64)[:ns]))
-        # (c) recall@knbn against exhaustive search (tie-aware: a neighbour counts if it is within the k-th exact distance)
-        nb = min(ns, 32)
-        bi, bd = hn.bruteforce_search(qsig[:nb], knbn)
-        rec_gpu = float(np.mean([(dist_g[i] <= bd[i, -1]).mean() for i in range(nb)]))
-        rec_cpu = float(np.mean([(odist[i] <= bd[i, -1]).mean() for i in range(nb)]))
-        ani_err = float(max(abs(G.ani(float(d), k) - O.ani(float(d), k)) for d in dist_g[0][: min(knbn, 8)]))
-        out["parity_checked"] = {"queries": ns, "sketch_bit_exact_vs_oracle": sketch_ok, "neighbour_ids_and_distances_equal_oracle": ids_ok, "dist_evaluation_counts_equal_oracle": evals_ok,
-                                 "max_ani_abs_err": ani_err}
-        out["recall_at_%d" % knbn] = {"gpu": rec_gpu, "cpu_oracle": rec_cpu, "queries": nb, "reference": "exhaustive DistHamming top-k, tie-aware"}
-        out["cpu_baseline"] = {"value": ns / (cpu_sketch_s + cpu_search_s), "unit": "genomes/s", "cores": min(cores, ns), "kind": "port",
-                               "sample": "%d of the step's query genomes: oracle sketch %.2fs + oracle parallel_search (same graph, ef=%d) %.2fs, OpenMP over genomes/queries"
-                                         % (ns, cpu_sketch_s, ef, cpu_search_s),
-                               "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
+        else:
+            out.update(request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, nsteps_q, gbytes, words))
         print(json.dumps(out))
+
+
+def request_accounting(args, ctx, hn, lib, chk, torch, D, r):
+    """per-kernel accounting over the timed region (HIP events around every launch on the library's stream + device-side work counters)"""
+    m, N, qps, knbn, ef = args.sketch_size, args.db_genomes, args.queries_per_step, args.knbn, args.ef_search
+    L, k = args.genome_len, args.kmer
+    row_bytes = m * 4.0                                           # 72 000 B per (query,candidate) evaluation, SURVEY 8d
+    (srch_ms, srch_n), (tile_ms, tile_n), (sk_ms, sk_n), st, evals_total = r["srch"], r["tile"], r["sk"], r["stats"], r["evals_total"]
+    kernels = []
+    join = os.environ.get("GS_DENSE_IMPL", "join") != "tile"
+    dense = tile_n > 0
+    if dense:   # dense mode: the counts of every (query, node) pair of the step are produced up front
+        pairs_total = float(qps) * N * args.steps
+        avg_ms = tile_ms / tile_n
+        kd = {"kernel": "k_match_join" if join else "k_hamming_qxc", "total_ms": tile_ms, "launches": tile_n, "avg_launch_ms": avg_ms,
+              "role": ("equi-join of the query batch with the column-major DB copy (all query x node pairs)" if join
+                       else "dense DistHamming compare tile (all query x node pairs)"),
+              "nominal_bytes_avoided_per_launch": pairs_total / tile_n * row_bytes}
+        if join:
+            col_bytes = float(N) * row_bytes                                   # the column store is streamed once per launch
+            atom = st.get("join_atomics", 0)
+            kd.update({"class": "atomics", "algorithmic_bytes_per_launch": col_bytes + 2.0 * pairs_total / tile_n,
+                       "column_stream_GBps": col_bytes * tile_n / (tile_ms * 1e-3) / 1e9, "atomics_per_launch": atom / tile_n,
+                       "atomics_per_sec": atom / (tile_ms * 1e-3), "atomics_peak_per_sec": ATOMICS_PEAK, "frac_of_atomics_ceiling": atom / (tile_ms * 1e-3) / ATOMICS_PEAK,
+                       "traffic": pmc_traffic("k_match_join")})
+            kd["achieved_GBps"] = kd["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+        else:
+            valu_peak = SIMDS * 64 / (2 * 2.0) * CLOCK_HZ                      # 2 VALU instr per pair-element, 2 cycles per wave64 instr
+            kd.update({"class": "valu", "pair_elements_per_sec": pairs_total * m / (tile_ms * 1e-3), "valu_peak_pair_elements_per_sec": valu_peak,
+                       "valu_frac": pairs_total * m / (tile_ms * 1e-3) / valu_peak, "algorithmic_bytes_per_launch": pairs_total / tile_n * row_bytes / 128.0,
+                       "traffic": pmc_traffic("k_hamming_qxc")})
+            kd["achieved_GBps"] = kd["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+        kernels.append(kd)
+    avg_s = srch_ms / max(srch_n, 1)
+    if dense:
+        # algorithmic bytes of the dense traversal: the adjacency row of every popped candidate (deg x 4 B) + one 2-byte count per evaluation
+        alg = (st.get("adj_bytes", 0) + 2.0 * evals_total) / max(srch_n, 1)
+        pops = st.get("pops", 0)
+        kt = {"kernel": "k_hnsw_search_dense", "class": "latency", "role": "HNSW traversal (dense mode: looks the counts up in the query x node matrix)",
+              "total_ms": srch_ms, "launches": srch_n, "avg_launch_ms": avg_s, "algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (avg_s * 1e-3) / 1e9 if avg_s else 0.0,
+              "pops_per_query": pops / max(qps * args.steps, 1), "accepting_pops_per_query": st.get("accepting_pops", 0) / max(qps * args.steps, 1),
+              "pops_per_sec": pops / (srch_ms * 1e-3) if srch_ms else 0.0, "workgroups_in_flight": st.get("wg_in_flight", 0),
+              "ns_per_pop_per_workgroup": (srch_ms * 1e6 * st.get("wg_in_flight", 0) / pops) if pops else None,
+              "nominal_bytes_avoided_per_launch": evals_total / max(srch_n, 1) * row_bytes, "traffic": pmc_traffic("k_hnsw_search_dense")}
+    else:
+        alg = evals_total / max(srch_n, 1) * row_bytes
+        kt = {"kernel": "k_hnsw_search", "class": "hbm", "role": "HNSW traversal (gather mode: streams one row per evaluation)", "total_ms": srch_ms, "launches": srch_n,
+              "avg_launch_ms": avg_s, "algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (avg_s * 1e-3) / 1e9 if avg_s else 0.0, "traffic": pmc_traffic("k_hnsw_search")}
+    kernels.append(kt)
+    kps = (L - k + 1) * qps * sk_n / (sk_ms * 1e-3) if sk_ms > 0 else 0.0
+    sk_alg = (float((L + 3) // 4) + m * 4.0) * qps
+    kernels.append({"kernel": "k_sketch_min", "class": "valu", "role": "query sketching", "total_ms": sk_ms, "launches": sk_n, "avg_launch_ms": sk_ms / max(sk_n, 1),
+                    "algorithmic_bytes_per_launch": sk_alg, "achieved_GBps": sk_alg * sk_n / (sk_ms * 1e-3) / 1e9 if sk_ms else 0.0, "kmers_per_sec": kps,
+                    "valu_model": sketch_valu_model(kps), "traffic": pmc_traffic("k_sketch_min")})
+    dom = max(kernels, key=lambda kk: kk["total_ms"])
+    out = {"kernels": kernels}
+    out["roofline"] = {"bound": "hbm", "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved_GBps"] / HBM_PEAK_GBS,
+                       "traffic": dom.get("traffic"), "kernel": dom["kernel"], "class": dom.get("class"), "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
+                       "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                       "note": "dominant kernel of the step by summed launch time; `achieved` = its algorithmic bytes / measured launch time (HIP events). "
+                               "`class` names the resource that really binds it (see `kernels`); the HBM-bound distance kernel of the north star is `roofline_gather_mode`"}
+    if dom.get("traffic"):
+        out["roofline"]["traffic_GBps"] = dom["traffic"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
+        out["roofline"]["traffic_source"] = os.environ.get("GS_PMC_SIDECAR")
+    # the row-streaming (gather) form of the same search on a sub-batch: the HBM-bound DistHamming kernel the north star prices
+    # against the HBM roofline (>= 40 % target); results are identical, only the evaluation strategy differs
+    ng_q = min(256, qps)
+    prev_mode = os.environ.get("GS_DIST_MODE")
+    os.environ["GS_DIST_MODE"] = "gather"
+    try:
+        ev_g = torch.zeros((ng_q,), dtype=torch.int64, device="cuda")
+        ids_g2 = torch.empty((ng_q, knbn), dtype=torch.int64, device="cuda")
+        dist_g2 = torch.empty((ng_q, knbn), dtype=torch.float32, device="cuda")
+        ctx.profile(True); ctx.profile_read(2, reset=True)
+        chk(lib.gs_index_parallel_search_dev(hn.h, r["d_qsig"], ng_q, knbn, ef, ids_g2.data_ptr(), dist_g2.data_ptr(), r["cnt_t"].data_ptr(), ev_g.data_ptr()))
+        g_ms, g_n = ctx.profile_read(2, reset=True); ctx.profile(False)
+        g_bytes = float(ev_g.sum().item()) * row_bytes
+        out["roofline_gather_mode"] = {"bound": "hbm", "kernel": "k_hnsw_search (GS_DIST_MODE=gather)", "queries": ng_q, "launch_ms": g_ms / max(g_n, 1),
+                                       "algorithmic_bytes": g_bytes, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_hnsw_search"),
+                                       "same_answers_as_dense": bool(torch.equal(ids_g2, r["ids_t"][:ng_q]) and torch.equal(dist_g2, r["dist_t"][:ng_q]))}
+    finally:
+        if prev_mode is None:
+            os.environ.pop("GS_DIST_MODE", None)
+        else:
+            os.environ["GS_DIST_MODE"] = prev_mode
+    return out
+
+
+def request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, nsteps_q, gbytes, words):
+    """parity / recall / CPU baseline on a bounded sample of the last step's queries (rank 0, N = 1 only)"""
+    import gsearch_amd as G
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    k, m, L, qps, knbn, ef = args.kmer, args.sketch_size, args.genome_len, args.queries_per_step, args.knbn, args.ef_search
+    cores = os.cpu_count() or 1
+    ns = min(max(args.cpu_sample_queries, cores), qps)             # at least one query per host thread: the CPU leg uses every core
+    last = (args.steps - 1) % nsteps_q
+    qsig = ctx.download(d_qsig, (qps, m), np.float32)[:ns]
+    ids_g = ids_t.cpu().numpy().view(np.uint64)[:ns]
+    dist_g = dist_t.cpu().numpy()[:ns]
+    # (a) sketch parity + CPU sketch time for the sample's genomes
+    op = O.params(k, m, "optdens")
+    qbytes = ctx.download(d_qseq + last * qps * gbytes, (ns, gbytes), np.uint8)
+    buf = np.concatenate([qbytes.reshape(-1), np.zeros(16, np.uint8)])
+    t0 = time.perf_counter()
+    osig = O.sketch_batch(op, buf, np.arange(ns, dtype=np.uint64) * np.uint64(words * 32), np.full(ns, L, np.uint64),
+                          np.arange(ns + 1, dtype=np.uint64), nthreads=cores)
+    cpu_sketch_s = time.perf_counter() - t0
+    sketch_ok = bool(np.array_equal(osig.view(np.uint32), qsig.view(np.uint32)))
+    # (b) the same graph searched by the oracle (CPU, all cores)
+    db = hn.get_data()
+    oix = O.Index(np.float32, m, args.max_nb_conn, args.ef_construction, scale_modify=args.scale_modify, seed=args.seed)
+    oix.import_graph(db, hn.export_graph())
+    t0 = time.perf_counter()
+    oids, odist, ocnt, oev = oix.parallel_search(qsig, knbn, ef, nthreads=min(cores, ns))
+    cpu_search_s = time.perf_counter() - t0
+    ids_ok = bool(np.array_equal(oids, ids_g)) and bool(np.array_equal(odist.view(np.uint32), dist_g.view(np.uint32)))
+    evals_ok = bool(np.array_equal(oev, ev_t.cpu().numpy().view(np.uint64)[:ns]))
+    # (c) recall@knbn against exhaustive search (tie-aware: a neighbour counts if it is within the k-th exact distance)
+    nb = min(ns, 32)
+    bi, bd = hn.bruteforce_search(qsig[:nb], knbn)
+    rec_gpu = float(np.mean([(dist_g[i] <= bd[i, -1]).mean() for i in range(nb)]))
+    rec_cpu = float(np.mean([(odist[i] <= bd[i, -1]).mean() for i in range(nb)]))
+    ani_err = float(max(abs(G.ani(float(d), k) - O.ani(float(d), k)) for d in dist_g[0][: min(knbn, 8)]))
+    out = {}
+    out["parity_checked"] = {"queries": ns, "sketch_bit_exact_vs_oracle": sketch_ok, "neighbour_ids_and_distances_equal_oracle": ids_ok,
+                             "dist_evaluation_counts_equal_oracle": evals_ok, "max_ani_abs_err": ani_err}
+    out["recall_at_%d" % knbn] = {"gpu": rec_gpu, "cpu_oracle": rec_cpu, "queries": nb, "reference": "exhaustive DistHamming top-k, tie-aware"}
+    out["cpu_baseline"] = {"value": ns / (cpu_sketch_s + cpu_search_s), "unit": "genomes/s", "cores": cores, "threads": min(cores, ns), "kind": "port",
+                           "sample": "%d of the step's query genomes on %d OpenMP threads (host reports %d): oracle sketch %.2fs + oracle parallel_search (same graph, ef=%d) %.2fs"
+                                     % (ns, min(cores, ns), cores, cpu_sketch_s, ef, cpu_search_s),
+                           "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
+    return out
 
 
 def main():
@@ -436,16 +530,20 @@ def main():
     ap.add_argument("--build-chunk", type=int, default=8192)
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--selftest-launch", action="store_true", help="GPU-free check of the N-rank launch + single all-gather (gloo, stub searcher)")
     args = ap.parse_args()
-    torch, rank, world, local = dist_init(args.gpus)
-    if args.workload == "sketch":
-        run_sketch(args, torch, rank, world, local)
+    from gsearch_amd import sharding as S
+    rc = S.ensure_launched(args.gpus, os.path.abspath(__file__), sys.argv[1:])     # --gpus N without a launcher: start the N ranks ourselves
+    if rc is not None:
+        sys.exit(rc)
+    D = Dist("gloo" if args.selftest_launch else "nccl")
+    if args.selftest_launch:
+        run_selftest_launch(args, D)
+    elif args.workload == "sketch":
+        run_sketch(args, D)
     else:
-        run_request(args, torch, rank, world, local)
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        dist.barrier()                      # rank 0 may still be timing the CPU baseline: leave together
-        dist.destroy_process_group()
+        run_request(args, D)
+    D.finish()
 
 
 if __name__ == "__main__":

@@ -527,5 +527,15 @@ class Hnsw:
         self.dtype = KIND_DTYPE[self.prm.kind]
         return self
 
+    def search_stats(self, reset=False):
+        """device-side work counters since the last reset (include/gsearch_amd.h gs_index_search_stats)"""
+        if self.h is None:
+            return {}
+        out = np.zeros(8, dtype=np.uint64)
+        check(self.ctx.L.gs_index_search_stats(self.h, _p(out), int(reset)))
+        pops = int(out[1])
+        return {"join_atomics": int(out[0]), "pops": pops, "accepting_pops": int(out[2]), "wg_in_flight": int(out[3]),
+                "adj_bytes": pops * int(out[4])}
+
     def insert_evals(self):
         return 0 if self.h is None else self.ctx.L.gs_index_insert_evals(self.h)

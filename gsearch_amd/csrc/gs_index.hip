@@ -479,12 +479,14 @@ template <bool VLDS>
 __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
                                                            uint32_t *__restrict__ scratch, uint32_t scratch_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
-                                                           uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out, unsigned long long *__restrict__ prof)
+                                                           uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out, unsigned long long *__restrict__ prof,
+                                                           unsigned long long *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t efs = ef > knbn ? ef : knbn;
     const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
+    unsigned long long st_pops = 0, st_acc = 0;                  // work counters (workgroup-uniform): pops / accepting pops of this workgroup
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, ix.n, VLDS);
@@ -624,6 +626,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             for (int w = 0; w < DT / 64; w++) { const uint32_t x = ws[w]; if (w < (int)wv) { off += x & 0xFFFFu; boff += x >> 16; } ne += x & 0xFFFFu; B += x >> 16; }
             const long long p3 = prof ? clock64() : 0;
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) { t_a += p1 - p0; t_b += p2 - p1; t_c += p3 - p2; n_pop++; }
+            st_pops++;
             if (ne == 0) continue;
             evals += ne;
             // closed-form accept rule: e_i is accepted iff #{x in R: c(x) <= c_i} + #{j<i: c_j <= c_i} < ef (and c_i < dmax once R is
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             const long long p4 = prof ? clock64() : 0;
             if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_d += p4 - p3;
             if (na == 0) continue;
-            n_merge++;
+            n_merge++; st_acc++;
             // accepted keys: histogram update, compaction (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
             {
                 if (acc) { hist_add<VLDS>(hs, ci, 1); S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey; }
@@ -809,6 +812,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         }
         if (threadIdx.x == 0) { if (count_out) count_out[qi] = nT; if (evals_out) evals_out[qi] = evals; }
     }
+    if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_acc); }
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
         atomicAdd(&prof[3], (unsigned long long)t_d); atomicAdd(&prof[4], (unsigned long long)t_e); atomicAdd(&prof[5], (unsigned long long)n_pop); atomicAdd(&prof[6], (unsigned long long)n_merge);
@@ -1133,6 +1137,8 @@ struct gs_index {
     // column-major copy of the signatures for the match-join (gs_join.hip)
     gs::DevBuf cols; uint64_t cols_cap = 0, cols_n = 0;
     gs::DevBuf join_scratch[5];
+    gs::DevBuf stats;                 // device work counters: [0] join atomics, [1] dense-traversal pops, [2] accepting pops (gs_index_search_stats)
+    uint64_t stat_wg_in_flight = 0, stat_adj_row_bytes = 0;
     gs::DevBuf rowptr;
     std::vector<gs::DevBuf *> slabs;
     uint64_t pair_cache_bytes = 0, pair_cache_budget = 0;
@@ -1250,6 +1256,14 @@ static int ensure_cols(gs_index *ix, uint64_t upto)
     }
     return GS_OK;
 }
+static int ensure_stats(gs_index *ix)
+{
+    if (ix->stats.p) return GS_OK;
+    int rc = ix->stats.alloc(64);
+    if (rc) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 64, ix->ctx->stream));
+    return GS_OK;
+}
 // counts of nq padded query rows against nodes [0, n): out16[q * ld + e]
 static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_t n, uint16_t *out16, uint64_t ld)
 {
@@ -1258,12 +1272,13 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
     if (!use_join(ix))
         return hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows, nq, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16, ld);
     if ((rc = ensure_cols(ix, n))) return rc;
+    if ((rc = ensure_stats(ix))) return rc;
     const uint64_t jq = match_join_max_queries();
     for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
         const uint64_t nb = std::min<uint64_t>(jq, nq - q0);
         int declined = 0;
         if ((rc = match_join_counts(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch,
-                                    &declined))) return rc;
+                                    &declined, ix->stats.as<unsigned long long>()))) return rc;
         if (declined &&      // too many matches to record one by one (redundant queries against a redundant database): fixed-cost compare kernel
             (rc = hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, nb, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16 + q0 * ld, ld))) return rc;
     }
@@ -1294,6 +1309,8 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     const uint32_t capC = 2 * efs + 2 * (uint32_t)DCN + maxdeg + 64;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu * per_cu);
     int rc;
+    if ((rc = ensure_stats(ix))) return rc;
+    ix->stat_wg_in_flight = grid; ix->stat_adj_row_bytes = (uint64_t)4 * maxdeg + 4;      // a pop loads deg0 and the full 2M-id row
     if ((rc = ix->visited.ensure((size_t)4 * scratch_words * c->n_cu * 3))) return rc;
     if ((rc = ix->cbuf.ensure((size_t)16 * capC * c->n_cu * 3))) return rc;
     GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
@@ -1308,7 +1325,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
         auto kern = k_hnsw_search_dense<V>;                                                                               \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
-                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof);  \
+                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof, ix->stats.as<unsigned long long>());  \
     } while (0)
     if (vlds) GS_LAUNCH_DSEARCH(true);
     else GS_LAUNCH_DSEARCH(false);
@@ -1461,6 +1478,22 @@ void gs_index_destroy(gs_index *ix)
     delete ix;
 }
 uint64_t gs_index_nb_point(const gs_index *ix) { return ix ? ix->n : 0; }
+int gs_index_search_stats(gs_index *ix, uint64_t out[8], int reset)
+{
+    GS_REQUIRE(ix && out, GS_ERR_INVALID, "null argument");
+    gs_ctx *c = ix->ctx;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (ix->stats.p) {
+        GS_HIP_CHECK(hipSetDevice(c->device));
+        unsigned long long h[8];
+        GS_HIP_CHECK(hipMemcpyAsync(h, ix->stats.p, 64, hipMemcpyDeviceToHost, c->stream));
+        if (reset) GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 64, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    }
+    out[3] = ix->stat_wg_in_flight; out[4] = ix->stat_adj_row_bytes;
+    return GS_OK;
+}
 uint64_t gs_index_insert_evals(const gs_index *ix) { return ix ? ix->insert_evals : 0; }
 int gs_index_get_params(const gs_index *ix, gs_index_params *out)
 {

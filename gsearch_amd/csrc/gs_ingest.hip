@@ -88,7 +88,8 @@ __global__ __launch_bounds__(PK_T) void k_pack_write(const uint8_t *__restrict__
 extern "C" {
 
 /* host: record boundaries of a FASTA text. Record r: sequence text = bytes [seq_begin[r], seq_end[r]) (may contain newlines),
- * id = the header's first word. Records whose id contains "capsid" are skipped when skip_capsid != 0 (dnafiles.rs:67). */
+ * id = the header's first word (reporting only). Records whose header line contains "capsid" anywhere are skipped when
+ * skip_capsid != 0 (needletail id() = whole header; dnafiles.rs:62-67, aafiles.rs:78,133,190,256). */
 int gs_fasta_scan(const char *buf, uint64_t n, int skip_capsid, uint64_t cap, uint64_t *seq_begin, uint64_t *seq_end, uint64_t *id_begin,
                   uint32_t *id_len, uint64_t *n_rec_out)
 {
@@ -115,7 +116,11 @@ int gs_fasta_scan(const char *buf, uint64_t n, int skip_capsid, uint64_t cap, ui
         bool skip = false;
         if (skip_capsid) {
             static const char pat[] = "capsid";
-            for (uint64_t t = 0; t + 6 <= idl && !skip; t++) skip = !memcmp(buf + h0 + t, pat, 6);
+            // needletail's id() is the WHOLE header line (description included, line ending stripped); dnafiles.rs:62-67 tests
+            // strid.contains("capsid") on it, so ">NC_1.1 Foo virus capsid protein" is dropped too. The first word is only reported.
+            uint64_t hl = hend > h0 ? hend - h0 : 0;
+            if (hl && buf[h0 + hl - 1] == '\r') hl--;
+            for (uint64_t t = 0; t + 6 <= hl && !skip; t++) skip = !memcmp(buf + h0 + t, pat, 6);
         }
         if (!skip) {
             if (nr < cap) { if (seq_begin) seq_begin[nr] = s0; if (seq_end) seq_end[nr] = j; if (id_begin) id_begin[nr] = h0; if (id_len) id_len[nr] = (uint32_t)idl; }

@@ -82,7 +82,7 @@ struct DevBuf;
 // column-major database copy `cols` ([m][colcap]); out16[q * ld + e] = mismatch count. scratch: 5 reusable buffers.
 uint64_t match_join_max_queries();
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
-                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined = nullptr);
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined = nullptr, unsigned long long *stats = nullptr);
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);
 
 inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }

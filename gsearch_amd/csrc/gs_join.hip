@@ -86,8 +86,8 @@ constexpr int JN = 8;             // nodes per lane: a workgroup owns JT * JN no
 #define GS_JOIN_HIT(st, tagv, e)                                                                              \
     do {                                                                                                      \
         if (((st) & 0xFFFu) == (tagv)) (st) += 0x1000u;                                                       \
-        else if ((st) < 0x2000u) { if (st) join_flush(mm32, ld, (st), (e)); (st) = (tagv) | 0x1000u; }        \
-        else join_flush(mm32, ld, (tagv) | 0x1000u, (e));                                                     \
+        else if ((st) < 0x2000u) { if (st) { join_flush(mm32, ld, (st), (e)); natom++; } (st) = (tagv) | 0x1000u; } \
+        else { join_flush(mm32, ld, (tagv) | 0x1000u, (e)); natom++; }                                        \
     } while (0)
 __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t st, uint64_t e)
 {
@@ -105,7 +105,8 @@ __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t
 // NaN never inserted / never probed), so bitwise equality is the reference's equality.
 template <int KIND, typename T>
 __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
-                                                    uint32_t m, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld)
+                                                    uint32_t m, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
+                                                    unsigned long long *__restrict__ stats)
 {
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     const uint64_t e0 = (uint64_t)blockIdx.x * (JT * JN) + threadIdx.x;      // the lane's nodes: e0 + i * JT, i < JN
     const uint32_t s0 = blockIdx.y * slots_per_wg, s1 = s0 + slots_per_wg < m ? s0 + slots_per_wg : m;
     uint32_t sticky[JN];
+    uint32_t natom = 0;                                           // memory-side atomics this lane sends (work counter for the bench's roofline)
 #pragma unroll
     for (int i = 0; i < JN; i++) sticky[i] = 0;
     T vn[JU];
@@ -177,7 +179,12 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
         }
     }
 #pragma unroll
-    for (int i = 0; i < JN; i++) if (sticky[i]) join_flush(mm32, ld, sticky[i], e0 + (uint64_t)i * JT);
+    for (int i = 0; i < JN; i++) if (sticky[i]) { join_flush(mm32, ld, sticky[i], e0 + (uint64_t)i * JT); natom++; }
+    if (stats) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) natom += __shfl_down(natom, o);
+        if ((threadIdx.x & 63) == 0 && natom) atomicAdd(stats, (unsigned long long)natom);
+    }
 }
 // Match-density probe: what would the join cost on THIS batch? Its work is proportional to the number of matches it has to
 // record, and a redundant query set against a redundant database (hundreds of near-identical genomes on both sides) has orders of
@@ -247,7 +254,7 @@ __global__ void k_match_to_count(uint16_t *mm, uint64_t nq, uint64_t n, uint64_t
 
 template <int KIND, typename T>
 static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstride, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint16_t *out16,
-                     uint64_t ld, DevBuf *scratch /* [5] reusable */, int *declined)
+                     uint64_t ld, DevBuf *scratch /* [5] reusable */, int *declined, unsigned long long *stats)
 {
     int rc;
     if (declined) *declined = 0;
@@ -300,7 +307,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         ProfScope ps(c, FAM_HAMMING);
         auto kern = k_match_join<KIND, T>;
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld);
+        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats);
         GS_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_match_to_count, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, (uint64_t)nq, n, ld, m);
@@ -313,13 +320,13 @@ uint64_t match_join_max_queries() { return JQ_MAX; }
 // `declined` (optional): set to 1 - and out16 is left zeroed - when the sampled match density says the compare tile kernel is the
 // cheaper producer for this batch (the caller then runs it)
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
-                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined)
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined, unsigned long long *stats)
 {
     GS_REQUIRE(nq >= 1 && nq <= (uint64_t)JQ_MAX && m <= 65535 && (ld % 2) == 0 && ((uintptr_t)out16 % 4) == 0, GS_ERR_INVALID, "match_join_counts: bad shape");
     GS_REQUIRE((uint64_t)m * nq < ((uint64_t)1 << 31), GS_ERR_INVALID, "match_join_counts: batch too large");
-    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined);
-    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined);
-    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined);
+    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
+    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
+    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
 }
 
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first)

@@ -6,20 +6,47 @@
 // Input: two FASTA files, every record = one genome ("--block" semantics). Not a CLI replacement: it exists so the C++ mirror
 // is compiled and exercised by tests/test_gpu_parity.py::test_cpp_host_mirror.
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include "../../../include/gsearch_amd.hpp"
 
 using namespace gsearch;
 
-// Rust's {:.5E} (answer.rs:58-63): mantissa with 5 decimals, exponent without padding or '+' sign, e.g. 6.07500E-1
-static std::string rust_5e(float x)
+// GPU-free mode `--answer-fixture FILE`: formats a literal request through gsearch::ReqAnswer (answer.rs:35-76) so the text format
+// can be checked against a hand-derived expected file (tests/golden/reqanswer_*.txt). Lines of FILE, tab separated:
+//   S path fasta_id len            next SeqDict entry
+//   T threshold_f32_bits_hex       out_threshold (dnarequest.rs:83)
+//   Q rank path fasta_id len       starts a request      N d_id distance_f32_bits_hex    a neighbour of it
+//   B hamming_f32_bits_hex k       prints bindash.rs:93-99 compute_distance with 9 decimals on its own line
+static std::vector<std::string> split_tabs(const std::string &l)
 {
-    char buf[64];
-    std::snprintf(buf, sizeof(buf), "%.5E", (double)x);
-    std::string s(buf);
-    const size_t e = s.find('E');
-    return s.substr(0, e) + "E" + std::to_string(std::stoi(s.substr(e + 1)));
+    std::vector<std::string> f; size_t b = 0;
+    for (;;) { size_t e = l.find('\t', b); f.push_back(l.substr(b, e == std::string::npos ? e : e - b)); if (e == std::string::npos) break; b = e + 1; }
+    return f;
+}
+static float f32_from_hex(const std::string &h) { uint32_t u = (uint32_t)std::stoul(h, nullptr, 16); float f; std::memcpy(&f, &u, 4); return f; }
+static int answer_fixture(const char *path)
+{
+    std::ifstream f(path);
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", path); return 1; }
+    SeqDict seqdict; float threshold = 0.99f;
+    struct Req { size_t rank; ItemDict item; std::vector<Neighbour> nb; };
+    std::vector<Req> reqs; std::vector<std::pair<float, size_t>> bd;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        auto t = split_tabs(line);
+        if (t[0] == "S") seqdict.push_back(ItemDict{t[1], t[2], std::stoull(t[3])});
+        else if (t[0] == "T") threshold = f32_from_hex(t[1]);
+        else if (t[0] == "Q") reqs.push_back(Req{std::stoull(t[1]), ItemDict{t[2], t[3], std::stoull(t[4])}, {}});
+        else if (t[0] == "N") reqs.back().nb.push_back(Neighbour{std::stoull(t[1]), f32_from_hex(t[2])});
+        else if (t[0] == "B") bd.emplace_back(f32_from_hex(t[1]), std::stoull(t[2]));
+    }
+    for (auto &r : reqs) ReqAnswer(r.rank, r.item, r.nb).dump(seqdict, threshold, std::cout);
+    std::cout << "\n";
+    for (auto &b : bd) { char buf[64]; std::snprintf(buf, sizeof buf, "%.9f\n", bindash_compute_distance(b.first, b.second)); std::cout << buf; }
+    return 0;
 }
 
 static std::vector<std::pair<std::string, Record>> read_fasta(const char *path)
@@ -37,6 +64,7 @@ static std::vector<std::pair<std::string, Record>> read_fasta(const char *path)
 
 int main(int argc, char **argv)
 {
+    if (argc == 3 && std::string(argv[1]) == "--answer-fixture") return answer_fixture(argv[2]);
     if (argc < 9) { std::fprintf(stderr, "usage: %s db.fa queries.fa k sketch_size max_nb_conn ef_construction ef_search knbn\n", argv[0]); return 2; }
     try {
         const uint32_t k = std::stoul(argv[3]), s = std::stoul(argv[4]), M = std::stoul(argv[5]), efc = std::stoul(argv[6]), ef = std::stoul(argv[7]), knbn = std::stoul(argv[8]);
@@ -62,16 +90,12 @@ int main(int argc, char **argv)
         std::vector<std::vector<float>> qsigs;
         for (auto &q : qs) { std::vector<const Record *> v{&q.second}; qsigs.push_back(sketcher.sketch_compressedkmer_seqs(v)[0]); }
         auto knn = hnsw.parallel_search(qsigs, knbn, ef);
-        const float threshold = 0.99f;
-        for (size_t i = 0; i < knn.size(); i++) {
-            bool has_match = false;
-            for (auto &n : knn[i]) has_match |= n.distance <= threshold;
-            if (!has_match) continue;
-            std::printf("\n%zu\t%s\tfasta_id:\t%s\tlength:\t%zu", i, argv[2], qs[i].first.c_str(), qs[i].second.size());
-            for (auto &n : knn[i])
-                if (n.distance < threshold)
-                    std::printf("\nquery_id:\t%s\tdistance:\t%s\tanswer_fasta_path\t%s\t%s \t answer_seq_len:\t %zu", argv[2], rust_5e(n.distance).c_str(), argv[1], db[n.d_id].first.c_str(), db[n.d_id].second.size());
-        }
+        const float threshold = 0.99f;                       // out_threshold, dnarequest.rs:83
+        SeqDict seqdict;
+        for (auto &g : db) seqdict.push_back(ItemDict{argv[1], g.first, g.second.size()});
+        for (size_t i = 0; i < knn.size(); i++)
+            ReqAnswer(i, ItemDict{argv[2], qs[i].first, qs[i].second.size()}, knn[i]).dump(seqdict, threshold, std::cout);
+        std::cout.flush();
         std::printf("\n");
     } catch (const std::exception &e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
     return 0;

@@ -6,7 +6,71 @@
 * DB sharding (the reference's scripts/multiple_search.sh:71-107 idea): every rank answers all queries on its shard,
   all-gather, k-way merge under the (distance, id) order.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def ensure_launched(n_procs, script, argv, env=None):
+    """`python bench.py --gpus N` must start N ranks by itself. When this process is not already a rank of a torch.distributed.run job
+    (no RANK in the environment) and n_procs > 1, re-exec `script argv` as N local ranks - one process per GPU, rendezvous on
+    127.0.0.1 - wait for them and return their exit code. Returns None when the caller IS a rank (or n_procs <= 1) and should just
+    carry on. The conceptual ancestor is the per-shard loop of scripts/multiple_search.sh:71-107."""
+    if n_procs <= 1 or "RANK" in os.environ:
+        return None
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_procs)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_procs), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=e)
+
+
+def rank_env():
+    """(rank, world, local_rank) of this process under torch.distributed.run; (0, 1, 0) otherwise"""
+    rank = int(os.environ.get("RANK", "0"))
+    return rank, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
+class TopkExchange:
+    """Per-rank answer block of one query batch - ids (i64) and distances (f32) of nq x knbn neighbours - laid out in ONE byte buffer
+    so that the exchange is ONE all-gather per batch (nq*knbn*12 B per rank, latency bound). `ids` / `dist` are views into
+    the send buffer: the search writes its results straight into them."""
+
+    def __init__(self, nq, knbn, world, device):
+        import torch
+        self.nq, self.knbn, self.world = nq, knbn, world
+        self.nb_ids = nq * knbn * 8
+        self.block = self.nb_ids + nq * knbn * 4
+        self.send = torch.zeros(self.block, dtype=torch.uint8, device=device)
+        self.ids = self.send[: self.nb_ids].view(torch.int64).view(nq, knbn)
+        self.dist = self.send[self.nb_ids:].view(torch.float32).view(nq, knbn)
+        self.recv = torch.zeros(world * self.block, dtype=torch.uint8, device=device) if world > 1 else self.send
+
+    def exchange(self):
+        """the ONE collective of a step (RCCL all-gather of the packed blocks; a no-op for a single rank)"""
+        if self.world > 1:
+            import torch.distributed as td
+            td.all_gather_into_tensor(self.recv, self.send)
+
+    def gathered(self):
+        """(all_ids, all_dist) of shape (world*nq, knbn) in rank order, unpacked from the receive buffer"""
+        import torch
+        blocks = self.recv.view(self.world, self.block)
+        ids = blocks[:, : self.nb_ids].contiguous().view(torch.int64).view(self.world * self.nq, self.knbn)
+        dist = blocks[:, self.nb_ids:].contiguous().view(torch.float32).view(self.world * self.nq, self.knbn)
+        return ids, dist
 
 
 def shard_bounds(n, rank, world):

@@ -94,7 +94,8 @@ int gs_sketch_batch_dev(gs_ctx *, const gs_sketch_params *, const void *seq_dev,
                         const uint64_t *genome_rec_off_dev, uint64_t n_genomes, void *sig_out_dev);
 /* ---- FASTA ingest: the reader side of src/dna/dnafiles.rs:43-193 for already-decompressed text ---- */
 /* host: record boundaries. Record r = sequence text bytes [seq_begin[r], seq_end[r]) (newlines included) and the header's first
- * word [id_begin[r], +id_len[r]). Records whose id contains "capsid" are skipped when skip_capsid != 0 (dnafiles.rs:67).
+ * word [id_begin[r], +id_len[r]). Records whose header LINE (needletail id(): description included) contains "capsid" are skipped
+ * when skip_capsid != 0 (dnafiles.rs:62-67).
  * Arrays may be NULL / cap 0 to count only; *n_rec_out = number of records kept. */
 int gs_fasta_scan(const char *buf, uint64_t n, int skip_capsid, uint64_t cap, uint64_t *seq_begin, uint64_t *seq_end,
                   uint64_t *id_begin, uint32_t *id_len, uint64_t *n_rec_out);
@@ -170,6 +171,10 @@ int      gs_index_get_data(gs_index *, uint64_t first, uint64_t n, void *sigs_ou
 int      gs_index_save(gs_index *, const char *path);
 int      gs_index_load(gs_ctx *, const char *path, gs_index **out);
 uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluations spent by inserts so far */
+/* device-side work counters of the searches and dense-mode inserts since the last reset (bench.py prices kernels with them):
+ * out[0] memory-side atomics sent by the match-join, out[1] candidates popped by the dense traversal, out[2] pops that accepted
+ * at least one neighbour, out[3] traversal workgroups in flight (last launch), out[4] bytes of adjacency a pop loads, out[5..7] 0 */
+int      gs_index_search_stats(gs_index *, uint64_t out[8], int reset);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Synthetic inputs generated in HBM (bench / tests): counter-based, reproducible on the host.      */

@@ -8,6 +8,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -151,6 +153,58 @@ inline double calculate_ani(double distance, int kmer, int model) { return gs_an
 
 // hnsw_rs::Neighbour fields gsearch reads (answer.rs:42,55-57)
 struct Neighbour { size_t d_id; float distance; float get_distance() const { return distance; } };
+
+// (path, fasta id, sequence length) of one database / request item: what ReqAnswer::dump reads of
+// utils::idsketch::ItemDict via get_id().get_path(), get_id().get_fasta_id(), get_len() (answer.rs:48-50,56,68-69)
+struct ItemDict { std::string path, fasta_id; size_t len; };
+using SeqDict = std::vector<ItemDict>;
+
+// Rust's {:.5E} on an f32 (answer.rs:60): exact decimal expansion of the value rounded half-even to 5 decimals,
+// exponent without padding and without '+': 6.07500E-1, 0.00000E0
+inline std::string rust_5E(float x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%.5E", (double)x);
+    std::string s(buf);
+    const size_t e = s.find('E');
+    return s.substr(0, e) + "E" + std::to_string(std::stoi(s.substr(e + 1)));
+}
+
+// answer.rs:14-76 ReqAnswer: text record of one request. Only neighbours with distance < threshold are written; the
+// header line is written when any neighbour has distance <= threshold (answer.rs:42 vs :55 - the two tests differ).
+class ReqAnswer {
+public:
+    ReqAnswer(size_t rank, ItemDict req_item, const std::vector<Neighbour> &neighbours) : rank_(rank), req_item_(std::move(req_item)), neighbours_(neighbours) {}
+    size_t dump(const SeqDict &seqdict, float threshold, std::ostream &out) const
+    {
+        bool has_match = false;
+        for (auto &n : neighbours_) has_match |= n.distance <= threshold;
+        size_t nb_match = 0;
+        if (!has_match) return 0;
+        out << "\n" << rank_ << "\t" << req_item_.path << "\tfasta_id:\t" << req_item_.fasta_id << "\tlength:\t" << req_item_.len;
+        for (auto &n : neighbours_) {
+            if (!(n.distance < threshold)) continue;
+            nb_match++;
+            const ItemDict &d = seqdict.at(n.d_id);
+            out << "\nquery_id:\t" << req_item_.path << "\tdistance:\t" << rust_5E(n.distance) << "\tanswer_fasta_path\t" << d.path << "\t"
+                << d.fasta_id << " \t answer_seq_len:\t " << d.len;
+        }
+        return nb_match;
+    }
+    const ItemDict &get_request_id() const { return req_item_; }
+private:
+    size_t rank_;
+    ItemDict req_item_;
+    const std::vector<Neighbour> &neighbours_;
+};
+
+// bindash.rs:93-99 compute_distance: j = 1 - d (f32); frac = 2j/(1+j) (f32); 1.0f64 - frac.powf(1/k as f32) as f64
+inline double bindash_compute_distance(float hamming_distance, size_t kmer_size)
+{
+    const float j = 1.0f - hamming_distance;
+    const float frac = 2.0f * j / (1.0f + j);
+    return 1.0 - (double)std::pow(frac, 1.0f / (float)kmer_size);
+}
 
 // hnsw_rs::Hnsw<T, DistHamming>
 template <class T>

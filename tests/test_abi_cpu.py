@@ -75,3 +75,14 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 for pat in (r"#\s*include[^\n]*oracle", r"import\s+oracle", r"from\s+oracle", r"libgs_oracle", r"oracle_lib", r"dlopen[^\n]*oracle"):
                     assert not re.search(pat, txt), (os.path.join(dirpath, f), pat)
+
+
+def test_fasta_scan_capsid_filter_uses_the_whole_header_line():
+    """needletail's id() is the whole header line: dnafiles.rs:62-67 drops a record whose DESCRIPTION says capsid (host-only code)"""
+    import gsearch_amd as G
+    txt = (b">NC_0123.1 Foo virus capsid protein\nACGT\nAC\n>NC_2 major Capsid (upper case is kept)\nGG\n>x_capsid_y\nTT\n"
+           b">NC_3 tail fibre\r\nACGTA\r\n>NC_4 ends with capsid\r\nCC\r\n>last\nA")
+    recs = G.fasta_scan(txt)
+    assert [r[0] for r in recs] == ["NC_2", "NC_3", "last"]
+    assert [txt[b:e] for _, b, e in recs] == [b"GG\n", b"ACGTA\r\n", b"A"]
+    assert [r[0] for r in G.fasta_scan(txt, skip_capsid=False)] == ["NC_0123.1", "NC_2", "x_capsid_y", "NC_3", "NC_4", "last"]

@@ -644,3 +644,69 @@ def test_tiny_query_batches(gpu_ctx, monkeypatch, mode):
         got = hn.search_arrays(q[lo:hi], 5, 300)
         for a, b in zip(got, want):
             assert np.array_equal(a, b[lo:hi])
+
+
+def test_config5_distance_leg_u64_m24000(gpu_ctx, monkeypatch):
+    """BASELINE configs[4] beyond the sketch: DistHamming and the HNSW build/search on u64 signatures of m = 24000 (192 kB rows;
+    the EW=2 tile path, the 8-byte-key join table at full width, row-gather traversal) against the oracle, bit for bit."""
+    import gsearch_amd as G
+    m, dtype = 24000, np.uint64
+    db = H.synth_sig_db(20, 110, m, 505, dtype=dtype, jlo=0.05, jhi=0.95)       # 2200 rows, 422 MB
+    q = H.queries_from(db, 96, 12, frac=0.3)
+    dh = G.DistHamming()
+    assert np.array_equal(dh.eval_qxc(q[:70], db[:600]), O.hamming_qxc(q[:70], db[:600], nthreads=os.cpu_count()))
+    rng = np.random.default_rng(4)
+    ia, ib = rng.integers(0, len(q), 300), rng.integers(0, len(db), 300)
+    assert np.array_equal(dh.eval_pairs(q, db, ia, ib), O.hamming_pairs(q, db, ia, ib))
+    M, efc, B = 16, 64, 128
+    oix = O.Index(dtype, m, M, efc, scale_modify=0.25, seed=31)
+    oix.parallel_insert(db, batch=B)
+    og = oix.export()
+    want = oix.parallel_search(q, 50, 200, nthreads=os.cpu_count())
+    for mode, impl in (("gather", None), ("dense", "join"), ("dense", "tile")):
+        monkeypatch.setenv("GS_DIST_MODE", mode)
+        if impl:
+            monkeypatch.setenv("GS_DENSE_IMPL", impl)
+        hn = G.Hnsw.new(M, 10000, 16, efc, dh, dtype=dtype, seed=31, insert_batch=B)
+        hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+        hn.parallel_insert(db)
+        g = hn.export_graph()
+        assert g["entry"] == og["entry"] and np.array_equal(g["levels"], og["levels"]) and np.array_equal(g["deg0"], og["deg0"]), (mode, impl)
+        for i in range(len(db)):
+            d = int(og["deg0"][i])
+            assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]) and np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d]), (mode, impl, i)
+        got = hn.search_arrays(q, 50, 200)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (mode, impl)
+        hn.close()
+
+
+def test_baseline_parameter_build_and_search(gpu_ctx):
+    """one build at BASELINE parameters - s = 18000 f32, M = 128, efc = 1600, level scale 0.25, insert_batch = 256, n = 4096
+    sketch-level rows (SURVEY 8d generator) - device graph == oracle graph, then the request search ef = 5000, n = 50 == oracle"""
+    import gsearch_amd as G
+    m, M, efc, B, n = 18000, 128, 1600, 256, 4096
+    db = H.synth_sig_db(41, 100, m, 2024, jlo=0.3, jhi=0.99)[:n]
+    oix = O.Index(np.float32, m, M, efc, scale_modify=0.25, seed=18000)
+    oix.parallel_insert(db, batch=B)
+    hn = G.Hnsw.new(M, 1_500_000, 16, efc, G.DistHamming(), seed=18000, insert_batch=B)
+    hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+    hn.parallel_insert(db)
+    g, og = hn.export_graph(), oix.export()
+    assert g["entry"] == og["entry"] and g["n_upper"] == og["n_upper"]
+    for key in ("levels", "upidx", "deg0", "degU"):
+        assert np.array_equal(g[key], og[key]), key
+    assert og["deg0"].max() > 64 and og["deg0"].min() >= 1            # a real graph: the heuristic keeps tens of neighbours per node
+    for i in range(n):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]), ("nbr0", i)
+        assert np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d]), ("cnt0", i)
+    for u in range(og["n_upper"]):
+        for L in range(og["degU"].shape[1]):
+            d = int(og["degU"][u, L])
+            assert np.array_equal(g["nbrU"][u, L, :d], og["nbrU"][u, L, :d]), ("nbrU", u, L)
+    q = H.queries_from(db, 64, 6, frac=0.2)
+    got = hn.search_arrays(q, 50, 5000)
+    want = oix.parallel_search(q, 50, 5000, nthreads=os.cpu_count())
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
