@@ -83,6 +83,12 @@ SYMBOLS = {
     "gs_index_load": (_i, [_vp, C.c_char_p, C.POINTER(_vp)]),
     "gs_index_insert_evals": (_u64, [_vp]),
     "gs_index_search_stats": (_i, [_vp, _vp, _i]),
+    "gs_comm_unique_id": (_i, [_vp]),
+    "gs_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "gs_comm_destroy": (None, [_vp]),
+    "gs_comm_rank": (_i, [_vp]),
+    "gs_comm_size": (_i, [_vp]),
+    "gs_comm_allgather_topk_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "gs_synth_dna_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _vp]),
     "gs_synth_dna_family_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _u64, C.c_double, C.c_double, _vp]),
     "gs_synth_sigs_dev": (_i, [_vp, _i, _u32, _u64, _u64, _u64, _u64, C.c_double, C.c_double, _vp]),

@@ -109,6 +109,38 @@ class Context:
         check(self.L.gs_dev_memset(self.h, ptr, byte, nbytes))
 
 
+class Comm:
+    """RCCL communicator of the path's one exchange step (include/gsearch_amd.h gs_comm_*): all-gather of the per-rank top-k blocks."""
+
+    def __init__(self, ctx, n_ranks, rank, unique_id):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(self.L.gs_comm_create(ctx.h, int(n_ranks), int(rank), buf, C.byref(h)))
+        self.h, self.n_ranks, self.rank = h, int(n_ranks), int(rank)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(_lib.load().gs_comm_unique_id(buf))
+        return buf.raw
+
+    def allgather_topk_dev(self, ids_dev, dist_dev, nq_local, knbn, all_ids_dev, all_dist_dev):
+        check(self.L.gs_comm_allgather_topk_dev(self.h, ids_dev, dist_dev, nq_local, knbn, all_ids_dev, all_dist_dev))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gs_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if not _exiting[0]:
+                self.close()
+        except Exception:
+            pass
+
+
 _default_ctx = None
 
 
@@ -305,10 +337,16 @@ class SuperHash2Sketch(_SeqSketcher):
     ALGO_NAME = "super2"
 
 
+class HyperLogLogSketch(_SeqSketcher):
+    """kmerutils HyperLogLogSketch<Kmer, u16>: SetSketch registers with SetSketchParams::default() + set_m(sketch_size)
+    (dnasketch.rs:541-574, aasketch.rs:481-500)"""
+    ALGO_NAME = "hll"
+
+
 def sketcher_for(params, ctx=None):
     """(algo) dispatch of dna_process_tohnsw (dnasketch.rs:493-644)."""
     table = {ALGO["optdens"]: OptDensHashSketch, ALGO["revoptdens"]: RevOptDensHashSketch, ALGO["prob"]: ProbHash3aSketch,
-             ALGO["super"]: SuperHashSketch, ALGO["super2"]: SuperHash2Sketch}
+             ALGO["super"]: SuperHashSketch, ALGO["super2"]: SuperHash2Sketch, ALGO["hll"]: HyperLogLogSketch}
     return table[params.c.algo](params, ctx)
 
 

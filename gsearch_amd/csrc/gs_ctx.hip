@@ -59,6 +59,7 @@ void gs_ctx_destroy(gs_ctx *c)
 int gs_ctx_release_scratch(gs_ctx *c)
 {
     GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     delete (gs::ScratchPool *)c->scratch_pool;
@@ -68,6 +69,7 @@ int gs_ctx_release_scratch(gs_ctx *c)
 int gs_ctx_sync(gs_ctx *c)
 {
     GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GS_OK;
 }
@@ -83,6 +85,7 @@ int gs_ctx_device_info(gs_ctx *c, int *n_cu, uint64_t *hbm, char *name, size_t c
 int gs_ctx_timer_start(gs_ctx *c)
 {
     GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipEventRecord(c->t0, c->stream));
     return GS_OK;
 }
@@ -103,6 +106,7 @@ int gs_ctx_profile(gs_ctx *c, int enable)
 int gs_ctx_profile_read(gs_ctx *c, int family, double *total_ms, uint64_t *launches, int reset)
 {
     GS_REQUIRE(c && family >= 0 && family < gs::FAM_COUNT, GS_ERR_INVALID, "bad family");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     gs::ProfSlot &s = c->prof[family];
     for (auto &p : s.pending) {
@@ -135,6 +139,7 @@ int gs_dev_free(gs_ctx *c, void *p)
 int gs_dev_upload(gs_ctx *c, void *dst, const void *src, size_t bytes)
 {
     GS_REQUIRE(c && (bytes == 0 || (dst && src)), GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
     if (bytes) {
         GS_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -144,6 +149,7 @@ int gs_dev_upload(gs_ctx *c, void *dst, const void *src, size_t bytes)
 int gs_dev_download(gs_ctx *c, void *dst, const void *src, size_t bytes)
 {
     GS_REQUIRE(c && (bytes == 0 || (dst && src)), GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
     if (bytes) {
         GS_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -153,6 +159,7 @@ int gs_dev_download(gs_ctx *c, void *dst, const void *src, size_t bytes)
 int gs_dev_memset(gs_ctx *c, void *dst, int byte, size_t bytes)
 {
     GS_REQUIRE(c && (bytes == 0 || dst), GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
     if (bytes) GS_HIP_CHECK(hipMemsetAsync(dst, byte, bytes, c->stream));
     return GS_OK;
 }
@@ -163,7 +170,7 @@ int gs_check_params(const gs_sketch_params *p)
     GS_REQUIRE(p, GS_ERR_INVALID, "null params");
     GS_REQUIRE(p->sketch_size >= 2, GS_ERR_INVALID, "sketch_size must be >= 2");
     GS_REQUIRE(p->algo <= GS_ALGO_REVOPTDENS, GS_ERR_INVALID, "unknown sketch algo %u", p->algo);
-    GS_REQUIRE(p->algo != GS_ALGO_HLL, GS_ERR_UNSUPPORTED, "hll (SetSketch) is outside the accelerated path");
+    GS_REQUIRE(p->algo != GS_ALGO_HLL || p->sketch_size <= 40000, GS_ERR_UNSUPPORTED, "hll (SetSketch): sketch_size > 40000 does not fit the LDS register table");
     if (p->data_t == GS_DATA_DNA) {
         GS_REQUIRE(p->k >= 1 && p->k <= 32, GS_ERR_INVALID, "DNA kmer size must be in 1..32");
         GS_REQUIRE(p->k != 15, GS_ERR_INVALID, "kmer size 15 is rejected (dnarequest.rs:451-454)");
@@ -318,6 +325,7 @@ extern "C" {
 int gs_synth_dna_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_t len, void *seq_dev)
 {
     GS_REQUIRE(c && seq_dev, GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
     uint64_t wp = (len + 31) / 32;
     if (ng * wp == 0) return GS_OK;
     hipLaunchKernelGGL(gs::k_synth_dna, dim3(c->n_cu * 8), dim3(256), 0, c->stream, seed, g0, ng, wp, len, (uint64_t *)seq_dev);
@@ -328,6 +336,7 @@ int gs_synth_dna_family_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, 
                             void *seq_dev)
 {
     GS_REQUIRE(c && seq_dev && n_roots > 0 && mu_lo >= 0 && mu_hi >= mu_lo && mu_hi < 1.0, GS_ERR_INVALID, "bad argument");
+    GS_CTX_LOCK(c);
     uint64_t wp = (len + 31) / 32;
     if (ng * wp == 0) return GS_OK;
     hipLaunchKernelGGL(gs::k_synth_family, dim3(c->n_cu * 8), dim3(256), 0, c->stream, seed, g0, ng, wp, len, n_roots, mu_lo, mu_hi, (uint64_t *)seq_dev);
@@ -338,6 +347,7 @@ int gs_synth_sigs_dev(gs_ctx *c, int kind, uint32_t m, uint64_t seed, uint64_t r
                       double jlo, double jhi, void *out)
 {
     GS_REQUIRE(c && out && n_roots > 0, GS_ERR_INVALID, "bad argument");
+    GS_CTX_LOCK(c);
     if (nrows == 0) return GS_OK;
     dim3 g(c->n_cu * 8), b(256);
     if (kind == GS_KIND_F32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_F32>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);

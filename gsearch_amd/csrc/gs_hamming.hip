@@ -208,7 +208,56 @@ int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
+static int hamming_qxc_dev_native(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc, float *out);
+// u16 signatures (hll, SPEC 3.4) run through the u32 kernels: a zero-extended u16 compares equal exactly when the u16 does, so the
+// mismatch counts - and everything built on them - are identical; rows are widened once when they enter device memory.
+__global__ void k_widen_u16(const uint16_t *__restrict__ src, uint64_t src_pitch_elems, uint64_t nrows, uint32_t m, uint8_t *__restrict__ dst, uint64_t dst_stride_bytes)
+{
+    const uint64_t total = nrows * m;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / m, s = i % m;
+        ((uint32_t *)(dst + r * dst_stride_bytes))[s] = src[r * src_pitch_elems + s];
+    }
+}
+__global__ void k_narrow_u16(const uint8_t *__restrict__ src, uint64_t src_stride_bytes, uint64_t nrows, uint32_t m, uint16_t *__restrict__ dst)
+{
+    const uint64_t total = nrows * m;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / m, s = i % m;
+        dst[i] = (uint16_t)((const uint32_t *)(src + r * src_stride_bytes))[s];
+    }
+}
+int widen_u16_rows(gs_ctx *c, const void *src_dev, uint64_t nrows, uint32_t m, void *dst_dev, uint64_t dst_stride_bytes)
+{
+    if (nrows == 0) return GS_OK;
+    hipLaunchKernelGGL(k_widen_u16, dim3((uint32_t)std::min<uint64_t>((nrows * m + 255) / 256, (uint64_t)c->n_cu * 16)), dim3(256), 0, c->stream,
+                       (const uint16_t *)src_dev, (uint64_t)m, nrows, m, (uint8_t *)dst_dev, dst_stride_bytes);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+int narrow_u16_rows(gs_ctx *c, const void *src_dev, uint64_t src_stride_bytes, uint64_t nrows, uint32_t m, void *dst_dev)
+{
+    if (nrows == 0) return GS_OK;
+    hipLaunchKernelGGL(k_narrow_u16, dim3((uint32_t)std::min<uint64_t>((nrows * m + 255) / 256, (uint64_t)c->n_cu * 16)), dim3(256), 0, c->stream,
+                       (const uint8_t *)src_dev, src_stride_bytes, nrows, m, (uint16_t *)dst_dev);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
 static int hamming_qxc_dev(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc, float *out)
+{
+    if (kind == GS_KIND_U16) {
+        PoolBuf wq(c, 30), wc(c, 31);
+        int rc;
+        if ((rc = wq.alloc((size_t)4 * m * nq))) return rc;
+        if ((rc = wc.alloc((size_t)4 * m * nc))) return rc;
+        if ((rc = widen_u16_rows(c, Q, nq, m, wq.p, (uint64_t)4 * m))) return rc;
+        if ((rc = widen_u16_rows(c, C, nc, m, wc.p, (uint64_t)4 * m))) return rc;
+        return hamming_qxc_strided(c, GS_KIND_U32, m, wq.p, nq, (uint64_t)4 * m, wc.p, nc, (uint64_t)4 * m, out, nullptr, nullptr, nc);
+    }
+    return hamming_qxc_dev_native(c, kind, m, Q, nq, C, nc, out);
+}
+static int hamming_qxc_dev_native(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc, float *out)
 {
     const uint64_t row = kind_bytes(kind) * (uint64_t)m;
     return hamming_qxc_strided(c, kind, m, Q, nq, row, C, nc, row, out, nullptr, nullptr, nc);
@@ -220,6 +269,8 @@ extern "C" {
 
 int gs_hamming_qxc_dev(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, const void *C, uint64_t nc, float *out)
 {
+    GS_REQUIRE(c, GS_ERR_INVALID, "null context");
+    GS_CTX_LOCK(c);
     return gs::hamming_qxc_dev(c, kind, m, Q, nq, C, nc, out);
 }
 
@@ -228,6 +279,7 @@ int gs_hamming_qxc(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, 
     GS_REQUIRE(c && m > 0, GS_ERR_INVALID, "bad argument");
     if (nq == 0 || nc == 0) return GS_OK;
     GS_REQUIRE(Q && C && out, GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const size_t row = gs::kind_bytes(kind) * (size_t)m;
     gs::DevBuf dq, dc, dout;
@@ -247,10 +299,11 @@ int gs_hamming_pairs(gs_ctx *c, int kind, uint32_t m, const void *A, uint64_t na
                      const uint64_t *ib, uint64_t npairs, float *out)
 {
     GS_REQUIRE(c && m > 0, GS_ERR_INVALID, "bad argument");
-    GS_REQUIRE(kind == GS_KIND_F32 || kind == GS_KIND_U32 || kind == GS_KIND_U64, GS_ERR_UNSUPPORTED, "DistHamming kind %d not on the device path", kind);
+    GS_REQUIRE(kind == GS_KIND_F32 || kind == GS_KIND_U32 || kind == GS_KIND_U64 || kind == GS_KIND_U16, GS_ERR_UNSUPPORTED, "DistHamming kind %d not on the device path", kind);
     if (npairs == 0) return GS_OK;
     GS_REQUIRE(A && B && ia && ib && out, GS_ERR_INVALID, "null argument");
     for (uint64_t p = 0; p < npairs; p++) GS_REQUIRE(ia[p] < na && ib[p] < nb, GS_ERR_INVALID, "pair %llu out of range", (unsigned long long)p);
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const size_t row = gs::kind_bytes(kind) * (size_t)m;
     gs::DevBuf da, db, dia, dib, dout;
@@ -264,6 +317,15 @@ int gs_hamming_pairs(gs_ctx *c, int kind, uint32_t m, const void *A, uint64_t na
     GS_HIP_CHECK(hipMemcpyAsync(db.p, B, row * nb, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dia.p, ia, 8 * npairs, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dib.p, ib, 8 * npairs, hipMemcpyHostToDevice, c->stream));
+    gs::DevBuf wa, wb;
+    if (kind == GS_KIND_U16) {                                   // widen once, then the u32 kernel (see k_widen_u16)
+        if ((rc = wa.alloc((size_t)4 * m * na))) return rc;
+        if ((rc = wb.alloc((size_t)4 * m * nb))) return rc;
+        if ((rc = gs::widen_u16_rows(c, da.p, na, m, wa.p, (uint64_t)4 * m))) return rc;
+        if ((rc = gs::widen_u16_rows(c, db.p, nb, m, wb.p, (uint64_t)4 * m))) return rc;
+        std::swap(da.p, wa.p); std::swap(da.bytes, wa.bytes); std::swap(db.p, wb.p); std::swap(db.bytes, wb.bytes);
+        kind = GS_KIND_U32;
+    }
     uint32_t blocks = (uint32_t)((npairs + 3) / 4);
     if (blocks > (uint32_t)c->n_cu * 8) blocks = (uint32_t)c->n_cu * 8;
     {

@@ -820,6 +820,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
     }
 }
 
+
 __device__ __forceinline__ SearchLds carve_lds(uint8_t *base, uint32_t ef, uint32_t maxdeg)
 {
     SearchLds S;
@@ -1119,7 +1120,8 @@ __global__ __launch_bounds__(LM_T) void k_link_merge(GraphDev g, uint32_t inbox_
 struct gs_index {
     gs_ctx *ctx = nullptr;
     gs_index_params prm{};
-    size_t esz = 4, rowbytes = 0; uint64_t stride = 0; uint32_t nchunks = 0;
+    size_t esz = 4, rowbytes = 0; uint64_t stride = 0; uint32_t nchunks = 0;     // INTERNAL element size / row bytes
+    int ikind = GS_KIND_F32; size_t user_rowbytes = 0;      // u16 signatures (hll) are held zero-extended to u32 (gs_hamming.hip k_widen_u16)
     uint64_t n = 0, cap = 0; int64_t entry = -1; int top = -1;
     uint64_t n_upper = 0, cap_upper = 0;
     gs::DevBuf data, levels, deg0, nbr0, cnt0, upidx, degU, nbrU, cntU;
@@ -1202,6 +1204,39 @@ static int upload_rows(gs_ctx *c, void *dst, uint64_t stride, const void *src, s
     return GS_OK;
 }
 
+// rows as the caller holds them (u16 for hll) -> internal zero-padded strided rows; nrows rows from host or device memory
+static int upload_user_rows(gs_index *ix, void *dst, const void *src, uint64_t nrows, hipMemcpyKind kind)
+{
+    gs_ctx *c = ix->ctx;
+    if (ix->prm.kind != GS_KIND_U16) return upload_rows(c, dst, ix->stride, src, ix->rowbytes, nrows, kind);
+    if (nrows == 0) return GS_OK;
+    GS_HIP_CHECK(hipMemsetAsync(dst, 0, ix->stride * nrows, c->stream));
+    const void *dev = src;
+    PoolBuf stage(c, 39);
+    if (kind == hipMemcpyHostToDevice) {
+        int rc = stage.alloc(ix->user_rowbytes * nrows); if (rc) return rc;
+        GS_HIP_CHECK(hipMemcpyAsync(stage.p, src, ix->user_rowbytes * nrows, hipMemcpyHostToDevice, c->stream));
+        dev = stage.p;
+    }
+    return widen_u16_rows(c, dev, nrows, ix->prm.m, dst, ix->stride);
+}
+// internal rows [first, first+n) -> dense rows as the caller holds them, in host memory
+static int download_user_rows(gs_index *ix, uint64_t first, uint64_t n, void *out_host)
+{
+    gs_ctx *c = ix->ctx;
+    if (n == 0) return GS_OK;
+    if (ix->prm.kind != GS_KIND_U16) {
+        GS_HIP_CHECK(hipMemcpy2DAsync(out_host, ix->rowbytes, ix->data.as<uint8_t>() + first * ix->stride, ix->stride, ix->rowbytes, n, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        PoolBuf stage(c, 39);
+        int rc = stage.alloc(ix->user_rowbytes * n); if (rc) return rc;
+        if ((rc = narrow_u16_rows(c, ix->data.as<uint8_t>() + first * ix->stride, ix->stride, n, ix->prm.m, stage.p))) return rc;
+        GS_HIP_CHECK(hipMemcpyAsync(out_host, stage.p, ix->user_rowbytes * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
 // ---- distance-evaluation strategy -----------------------------------------------------
 // gather: every evaluation streams one candidate row from HBM (72 kB at s=18000) — right when a traversal touches a
 //         small part of the graph;
@@ -1231,7 +1266,7 @@ static bool dense_pays(const gs_index *ix, double frac, uint64_t nq)
     const double gather = evals * (double)ix->rowbytes * std::max(q / 5.5e12, 1.0 / 8.0e10);
     double dense;
     if (use_join(ix)) dense = n * (double)ix->rowbytes / (nq <= 512 ? 3.5e12 : 1.0e12) * std::ceil(q / (double)match_join_max_queries()) + 3e-3;
-    else dense = std::ceil(q / 128.0) * 128.0 * n * (double)ix->prm.m / (ix->prm.kind == GS_KIND_U64 ? 1.4e13 : 1.6e13);       // 128-query tiles
+    else dense = std::ceil(q / 128.0) * 128.0 * n * (double)ix->prm.m / (ix->ikind == GS_KIND_U64 ? 1.4e13 : 1.6e13);       // 128-query tiles
     dense += evals * 75e-9 * std::max(1.0, q / 768.0);
     return dense < gather;
 }
@@ -1251,7 +1286,7 @@ static int ensure_cols(gs_index *ix, uint64_t upto)
         ix->cols_cap = ix->cap; ix->cols_n = 0;
     }
     if (ix->cols_n < upto) {
-        if ((rc = rows_to_cols(c, ix->prm.kind, ix->prm.m, ix->data.as<uint8_t>() + ix->cols_n * ix->stride, ix->stride, upto - ix->cols_n, ix->cols.p, ix->cols_cap, ix->cols_n))) return rc;
+        if ((rc = rows_to_cols(c, ix->ikind, ix->prm.m, ix->data.as<uint8_t>() + ix->cols_n * ix->stride, ix->stride, upto - ix->cols_n, ix->cols.p, ix->cols_cap, ix->cols_n))) return rc;
         ix->cols_n = upto;
     }
     return GS_OK;
@@ -1270,17 +1305,17 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
     gs_ctx *c = ix->ctx;
     int rc;
     if (!use_join(ix))
-        return hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows, nq, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16, ld);
+        return hamming_qxc_strided(c, ix->ikind, ix->prm.m, qrows, nq, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16, ld);
     if ((rc = ensure_cols(ix, n))) return rc;
     if ((rc = ensure_stats(ix))) return rc;
     const uint64_t jq = match_join_max_queries();
     for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
         const uint64_t nb = std::min<uint64_t>(jq, nq - q0);
         int declined = 0;
-        if ((rc = match_join_counts(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch,
+        if ((rc = match_join_counts(c, ix->ikind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch,
                                     &declined, ix->stats.as<unsigned long long>()))) return rc;
         if (declined &&      // too many matches to record one by one (redundant queries against a redundant database): fixed-cost compare kernel
-            (rc = hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, qrows + q0 * ix->stride, nb, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16 + q0 * ld, ld))) return rc;
+            (rc = hamming_qxc_strided(c, ix->ikind, ix->prm.m, qrows + q0 * ix->stride, nb, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16 + q0 * ld, ld))) return rc;
     }
     return GS_OK;
 }
@@ -1303,7 +1338,10 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
     const bool vlds = dense_vis_in_lds(ix, knbn, maxdeg);
     const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, vlds);
-    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024 - 1024) / lds));
+    // two 8-wave workgroups per CU: the kernel needs 127 VGPRs per lane (16 wave slots); a build capped at 80 VGPRs fits a third but
+    // spills ~30 registers and was measured slower or equal at 300 k nodes (NOTES.md)
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024 - 1024) / lds));
+    if (getenv("GS_DENSE_PER_CU")) per_cu = std::max(1, std::min((int)per_cu, atoi(getenv("GS_DENSE_PER_CU"))));
     // per-workgroup global scratch: visited bitmap (vlds = false) or the fine histogram bins (vlds = true)
     const uint32_t scratch_words = vlds ? dense_nblocks(ix->prm.m) * (HB / 2) : (uint32_t)((ix->n + 31) / 32);
     const uint32_t capC = 2 * efs + 2 * (uint32_t)DCN + maxdeg + 64;
@@ -1366,8 +1404,8 @@ static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq,
         hipLaunchKernelGGL(kern, dim3(grid), dim3(ST), lds, c->stream, d, q_padded_dev, nq, knbn, ef, mat, mat_ld,       \
                            ix->visited.as<uint32_t>(), vis_words, ix->counter.as<unsigned long long>(), ids, dist, count, evals); \
     } while (0)
-    if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_SEARCH(GS_KIND_F32);
-    else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_SEARCH(GS_KIND_U32);
+    if (ix->ikind == GS_KIND_F32) GS_LAUNCH_SEARCH(GS_KIND_F32);
+    else if (ix->ikind == GS_KIND_U32) GS_LAUNCH_SEARCH(GS_KIND_U32);
     else GS_LAUNCH_SEARCH(GS_KIND_U64);
 #undef GS_LAUNCH_SEARCH
     GS_HIP_CHECK(hipGetLastError());
@@ -1432,9 +1470,16 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     }
     const uint64_t ld = round_up(ix->n, 8);
     const bool join = use_join(ix);
-    uint64_t QB = ((uint64_t)4 << 30) / (2 * ld);
+    // one traversal launch should cover the whole request (every launch ends with a tail in which most CUs idle while the last queries
+    // finish), so the count matrix is sized for all queries when HBM allows: a quarter of the free memory, at most 32 GB (10 000 queries
+    // x 300 k nodes x 2 B = 6 GB); the join fills it in chunks of its own maximum inside dense_counts
+    uint64_t budget = (uint64_t)4 << 30;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::max<uint64_t>(budget, std::min<uint64_t>((uint64_t)32 << 30, (uint64_t)fr / 4 + ix->mat.bytes));
+    }
+    uint64_t QB = budget / (2 * ld);
     QB = std::max<uint64_t>(128, QB / 128 * 128);
-    if (join) QB = std::min<uint64_t>(QB, match_join_max_queries());
     if (getenv("GS_SEARCH_QB")) QB = std::min<uint64_t>(QB, (uint64_t)std::max(1, atoi(getenv("GS_SEARCH_QB"))));
     QB = std::min<uint64_t>(QB, rest);
     if ((rc = ix->mat.ensure((size_t)2 * QB * ld))) return rc;
@@ -1455,7 +1500,7 @@ extern "C" {
 int gs_index_create(gs_ctx *c, const gs_index_params *p, gs_index **out)
 {
     GS_REQUIRE(c && p && out, GS_ERR_INVALID, "null argument");
-    GS_REQUIRE(p->kind == GS_KIND_F32 || p->kind == GS_KIND_U32 || p->kind == GS_KIND_U64, GS_ERR_UNSUPPORTED, "signature kind %d not supported by the index", p->kind);
+    GS_REQUIRE(p->kind == GS_KIND_F32 || p->kind == GS_KIND_U32 || p->kind == GS_KIND_U64 || p->kind == GS_KIND_U16, GS_ERR_UNSUPPORTED, "signature kind %d not supported by the index", p->kind);
     GS_REQUIRE(p->m >= 1, GS_ERR_INVALID, "m must be positive");
     GS_REQUIRE(p->max_nb_conn >= 2 && p->max_nb_conn <= 255, GS_ERR_INVALID, "max_nb_conn must be in 2..255 (gsearch.rs:268)");
     GS_REQUIRE(p->max_layer >= 1 && p->max_layer <= 16, GS_ERR_INVALID, "max_layer must be in 1..16");
@@ -1463,8 +1508,10 @@ int gs_index_create(gs_ctx *c, const gs_index_params *p, gs_index **out)
     gs_index *ix = new gs_index();
     ix->ctx = c; ix->prm = *p;
     if (ix->prm.insert_batch == 0) ix->prm.insert_batch = 64;
-    ix->esz = gs::kind_bytes(p->kind);
+    ix->ikind = p->kind == GS_KIND_U16 ? GS_KIND_U32 : p->kind;
+    ix->esz = gs::kind_bytes(ix->ikind);
     ix->rowbytes = ix->esz * p->m;
+    ix->user_rowbytes = gs::kind_bytes(p->kind) * (size_t)p->m;
     ix->stride = gs::round_up(ix->rowbytes, 256);
     ix->nchunks = (uint32_t)((ix->rowbytes + 15) / 16);
     *out = ix;
@@ -1473,6 +1520,7 @@ int gs_index_create(gs_ctx *c, const gs_index_params *p, gs_index **out)
 void gs_index_destroy(gs_index *ix)
 {
     if (!ix) return;
+    GS_CTX_LOCK(ix->ctx);
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     delete ix;
@@ -1482,6 +1530,7 @@ int gs_index_search_stats(gs_index *ix, uint64_t out[8], int reset)
 {
     GS_REQUIRE(ix && out, GS_ERR_INVALID, "null argument");
     gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (ix->stats.p) {
         GS_HIP_CHECK(hipSetDevice(c->device));
@@ -1511,6 +1560,7 @@ int gs_index_import(gs_index *ix, const void *sigs, uint64_t n, const uint8_t *l
     GS_REQUIRE(entry >= 0 && (uint64_t)entry < n, GS_ERR_INVALID, "entry point out of range");
     GS_REQUIRE(n_upper == 0 || (degU && nbrU && cntU), GS_ERR_INVALID, "null upper-layer arrays");
     gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
     int top = 0;
@@ -1524,7 +1574,7 @@ int gs_index_import(gs_index *ix, const void *sigs, uint64_t n, const uint8_t *l
     GS_REQUIRE(levels[entry] == top, GS_ERR_INVALID, "entry point is not on the top layer");
     int rc = gs::index_reserve(ix, n, n_upper);
     if (rc) return rc;
-    if ((rc = gs::upload_rows(c, ix->data.p, ix->stride, sigs, ix->rowbytes, n, hipMemcpyHostToDevice))) return rc;
+    if ((rc = gs::upload_user_rows(ix, ix->data.p, sigs, n, hipMemcpyHostToDevice))) return rc;
     GS_HIP_CHECK(hipMemcpyAsync(ix->levels.p, levels, n, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(ix->deg0.p, deg0, 4 * n, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(ix->nbr0.p, nbr0, (size_t)8 * M * n, hipMemcpyHostToDevice, c->stream));
@@ -1545,6 +1595,7 @@ int gs_index_export(gs_index *ix, uint8_t *levels, int64_t *entry, uint32_t *deg
 {
     GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
     gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
     const uint64_t n = ix->n, U = ix->n_upper;
@@ -1570,10 +1621,8 @@ int gs_index_get_data(gs_index *ix, uint64_t first, uint64_t n, void *out)
 {
     GS_REQUIRE(ix && out && first + n <= ix->n, GS_ERR_INVALID, "bad range");
     if (n == 0) return GS_OK;
-    gs_ctx *c = ix->ctx;
-    GS_HIP_CHECK(hipMemcpy2DAsync(out, ix->rowbytes, ix->data.as<uint8_t>() + first * ix->stride, ix->stride, ix->rowbytes, n, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return GS_OK;
+    GS_CTX_LOCK(ix->ctx);
+    return gs::download_user_rows(ix, first, n, out);
 }
 
 static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
@@ -1585,11 +1634,12 @@ static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_
     GS_REQUIRE(queries && ids && dist, GS_ERR_INVALID, "null argument");
     GS_REQUIRE(ix->n > 0, GS_ERR_STATE, "search on an empty index");
     gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     gs::PoolBuf dq(c, 32), dids(c, 33), ddist(c, 34), dcount(c, 35), devals(c, 36);
     int rc;
     if ((rc = dq.alloc(ix->stride * nq))) return rc;
-    if ((rc = gs::upload_rows(c, dq.p, ix->stride, queries, ix->rowbytes, nq, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
+    if ((rc = gs::upload_user_rows(ix, dq.p, queries, nq, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
     if (on_dev) {
         if ((rc = gs::search_dev(ix, dq.p, nq, knbn, ef, ids, dist, count, evals))) return rc;
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1638,6 +1688,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     if (n == 0) return GS_OK;
     GS_REQUIRE(sigs, GS_ERR_INVALID, "null signatures");
     gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer, maxdeg = 2 * M, efc = ix->prm.ef_construction;
     const uint32_t B = std::min<uint32_t>(std::min<uint32_t>(ix->prm.insert_batch, 256u), gs::ST);
     GS_REQUIRE(!ix->prm.keep_pruned, GS_ERR_UNSUPPORTED, "keep_pruned=true is not implemented on the device (gsearch sets false, dnasketch.rs:160)");
@@ -1653,8 +1704,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     int rc = gs::index_reserve(ix, ix->n + n, nup);
     if (rc) return rc;
     const uint64_t first = ix->n;
-    if ((rc = gs::upload_rows(c, ix->data.as<uint8_t>() + first * ix->stride, ix->stride, sigs, ix->rowbytes, n,
-                              on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
+    if ((rc = gs::upload_user_rows(ix, ix->data.as<uint8_t>() + first * ix->stride, sigs, n, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
     GS_HIP_CHECK(hipMemcpyAsync(ix->levels.as<uint8_t>() + first, lv.data(), n, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(ix->upidx.as<int32_t>() + first, up.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
     // scratch
@@ -1700,7 +1750,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         GS_HIP_CHECK(hipMemsetAsync(ix->plan_n.p, 0, (size_t)4 * nb * ML, c->stream));
         GS_HIP_CHECK(hipMemsetAsync(ix->ntouched.p, 0, 4, c->stream));
         const uint8_t *rows = ix->data.as<uint8_t>() + b0 * ix->stride;
-        if (nb > 1) { if ((rc = gs::hamming_qxc_strided(c, ix->prm.kind, ix->prm.m, rows, nb, ix->stride, rows, nb, ix->stride, nullptr, ix->cntmat.as<uint32_t>(), nullptr, nb))) return rc; }
+        if (nb > 1) { if ((rc = gs::hamming_qxc_strided(c, ix->ikind, ix->prm.m, rows, nb, ix->stride, rows, nb, ix->stride, nullptr, ix->cntmat.as<uint32_t>(), nullptr, nb))) return rc; }
         gs::IndexDev d = gs::index_dev(ix);
         d.n = b0; d.entry = ix->entry; d.top = ix->top;                  // the graph frozen at batch start
         const uint32_t vw = (uint32_t)((b0 + 31) / 32);
@@ -1748,8 +1798,8 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
                            ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, vis_in_lds, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
                            ix->evals_dev.as<unsigned long long>());                                                        \
     } while (0)
-            if (ix->prm.kind == GS_KIND_F32) GS_LAUNCH_PLAN(GS_KIND_F32);
-            else if (ix->prm.kind == GS_KIND_U32) GS_LAUNCH_PLAN(GS_KIND_U32);
+            if (ix->ikind == GS_KIND_F32) GS_LAUNCH_PLAN(GS_KIND_F32);
+            else if (ix->ikind == GS_KIND_U32) GS_LAUNCH_PLAN(GS_KIND_U32);
             else GS_LAUNCH_PLAN(GS_KIND_U64);
 #undef GS_LAUNCH_PLAN
         }
@@ -1781,6 +1831,7 @@ int gs_index_bruteforce_search(gs_index *ix, const void *queries, uint64_t nq, u
     if (nq == 0) return GS_OK;
     GS_REQUIRE(queries && ids && dist && ix->n > 0, GS_ERR_INVALID, "bad argument");
     gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     // dense copy of the data rows (the tile kernel takes unpadded rows), query blocks of 256
     const uint64_t n = ix->n;
@@ -1795,8 +1846,14 @@ int gs_index_bruteforce_search(gs_index *ix, const void *queries, uint64_t nq, u
     std::vector<uint64_t> keys(n);
     for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
         const uint64_t nb = std::min(QB, nq - q0);
+        if (ix->prm.kind == GS_KIND_U16) {                       // u16 rows from the host: stage, then zero-extend into the dense u32 block
+            gs::PoolBuf stage(c, 39);
+            if ((rc = stage.alloc(ix->user_rowbytes * nb))) return rc;
+            GS_HIP_CHECK(hipMemcpyAsync(stage.p, (const uint8_t *)queries + ix->user_rowbytes * q0, ix->user_rowbytes * nb, hipMemcpyHostToDevice, c->stream));
+            if ((rc = gs::widen_u16_rows(c, stage.p, nb, ix->prm.m, dq.p, ix->rowbytes))) return rc;
+        } else
         GS_HIP_CHECK(hipMemcpyAsync(dq.p, (const uint8_t *)queries + ix->rowbytes * q0, ix->rowbytes * nb, hipMemcpyHostToDevice, c->stream));
-        if ((rc = gs_hamming_qxc_dev(c, ix->prm.kind, ix->prm.m, dq.p, nb, dense.p, n, dd.as<float>()))) return rc;
+        if ((rc = gs_hamming_qxc_dev(c, ix->ikind, ix->prm.m, dq.p, nb, dense.p, n, dd.as<float>()))) return rc;
         GS_HIP_CHECK(hipMemcpyAsync(h.data(), dd.p, 4 * nb * n, hipMemcpyDeviceToHost, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         for (uint64_t i = 0; i < nb; i++) {
@@ -1821,6 +1878,7 @@ int gs_index_save(gs_index *ix, const char *path)
 {
     GS_REQUIRE(ix && path, GS_ERR_INVALID, "null argument");
     GS_REQUIRE(ix->n > 0, GS_ERR_STATE, "nothing to save");
+    GS_CTX_LOCK(ix->ctx);
     FILE *f = fopen(path, "wb");
     GS_REQUIRE(f, GS_ERR_IO, "cannot open %s for writing", path);
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
@@ -1830,11 +1888,11 @@ int gs_index_save(gs_index *ix, const char *path)
     uint64_t hdr[4] = {n, U, (uint64_t)ix->entry, (uint64_t)(int64_t)ix->top};
     bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&ix->prm, sizeof(ix->prm), 1, f) == 1 && fwrite(hdr, 8, 4, f) == 4;
     const uint64_t CH = 4096;
-    std::vector<uint8_t> buf(ix->rowbytes * CH);
+    std::vector<uint8_t> buf(ix->user_rowbytes * CH);
     for (uint64_t r0 = 0; ok && r0 < n; r0 += CH) {
         const uint64_t nr = std::min(CH, n - r0);
         if ((rc = gs_index_get_data(ix, r0, nr, buf.data()))) break;
-        ok = fwrite(buf.data(), ix->rowbytes, nr, f) == nr;
+        ok = fwrite(buf.data(), ix->user_rowbytes, nr, f) == nr;
     }
     if (ok && rc == GS_OK) {
         std::vector<uint8_t> lv(n); std::vector<uint32_t> d0(n), n0(n * 2 * M), c0(n * 2 * M); std::vector<int32_t> up(n);

@@ -141,6 +141,7 @@ int gs_pack_fasta_dev(gs_ctx *c, const void *text_dev, uint64_t n_bytes, const u
     GS_REQUIRE(c && rec_start_out && rec_len_out, GS_ERR_INVALID, "null argument");
     if (n_rec == 0) return GS_OK;
     GS_REQUIRE(text_dev && seq_begin && seq_end && packed_dev, GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     std::vector<uint64_t> cb, ce, first_chunk(n_rec + 1);
     for (uint64_t r = 0; r < n_rec; r++) {

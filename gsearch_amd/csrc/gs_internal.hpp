@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/gsearch_amd.h"
@@ -49,7 +50,13 @@ struct gs_ctx {
     bool profile = false;
     gs::ProfSlot prof[gs::FAM_COUNT];
     void *scratch_pool = nullptr;      // gs::ScratchPool: grow-only device buffers reused by the calls of this context
+    // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
+    // and parallel_search through &self from many threads (dnasketch.rs:252,305,322): every entry point that touches the stream or the
+    // pool takes this lock, so concurrent calls on one context are safe (they queue on the GPU anyway); recursive because entry
+    // points call one another (save -> export / get_data, bruteforce -> hamming).
+    std::recursive_mutex mu;
 };
+#define GS_CTX_LOCK(c) std::lock_guard<std::recursive_mutex> gs_ctx_lock_((c)->mu)
 
 namespace gs {
 
@@ -76,6 +83,9 @@ struct ProfScope {   // brackets one kernel launch with events when profiling is
 // 32-bit mismatch counts (out_cnt), 16-bit mismatch counts (out_cnt16); ld_out = output row pitch in elements (0 -> nc).
 int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, uint64_t strideQ_bytes, const void *C, uint64_t nc,
                         uint64_t strideC_bytes, float *out, uint32_t *out_cnt, uint16_t *out_cnt16, uint64_t ld_out);
+
+int widen_u16_rows(gs_ctx *c, const void *src_dev, uint64_t nrows, uint32_t m, void *dst_dev, uint64_t dst_stride_bytes);
+int narrow_u16_rows(gs_ctx *c, const void *src_dev, uint64_t src_stride_bytes, uint64_t nrows, uint32_t m, void *dst_dev);
 
 struct DevBuf;
 // match-join form of the dense count matrix (gs_join.hip): counts of nq strided query rows against the first n nodes of the

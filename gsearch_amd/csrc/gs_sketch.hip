@@ -878,6 +878,203 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
 }
 
 // everything on the device; scratch owned by the call (freed after the stream drains)
+
+// ======================================================================================================
+// hll = SetSketch1 with u16 registers (SPEC 3.4; kmerutils HyperLogLogSketch<Kmer,u16> over probminhash's SetSketcher,
+// /root/reference/src/dna/dnasketch.rs:541-574, src/aa/aasketch.rs:481-500). Registers are per-slot MAXIMA over (element, j) of
+// k_j = trunc(1 - log_b x_j): order free, so the sequential lower-bound pruning of the paper becomes two passes per genome inside
+// one workgroup (register table in LDS, ds_max_u32):
+//   pass A  level j = 0 of every k-mer (one exponential draw, one uniform slot) under the workgroup's RUNNING minimum register as a
+//           filter - a conservative integer threshold on the 52 uniform bits decides without evaluating a logarithm for all but a
+//           few percent of the k-mers (U > a*m*b^-(K-2) implies k_0 < K because -ln(1-U) >= U; table ucut[K] from the host);
+//   pass B  with the exact minimum K_low of pass A as the bound every k-mer is hashed again, the ~3 % whose first point beats K_low
+//           walk on (j = 1, 2, ...: exponential spacings through a lazily materialised Fisher-Yates permutation) until k_j <= K_low.
+// The permutation of a walking lane is a short list of displaced positions in registers (walks are a few steps once K_low is
+// realistic); a genome whose walks outgrow it - few k-mers per register, K_low ~ 0, walks of ~m steps - is flagged and redone by
+// the COLD instantiation, whose lanes keep stamped perm arrays in global scratch (same scheme as k_smh_cold_wg).
+// ======================================================================================================
+constexpr int HL_T = 512;          // lanes per workgroup
+constexpr int HL_JR = 12;          // displaced positions a warm lane can remember
+constexpr int HL_CT = 256;         // lanes per workgroup of the cold instantiation
+struct HllShared { uint32_t *tab; volatile uint32_t *ctl; };   // ctl: [0] klow, [1] work item, [2] scratch min, [3] overflow flag, [4,5] ucut[klow]
+template <bool COLD>
+struct HllEmit {
+    HllShared S; uint32_t m; uint64_t zone_m; double inv_lnb, am;
+    uint32_t *q, *perm; uint32_t *stamp; bool walk;
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const
+    {
+        Rng g; g.seed(elem_hash<ALGO_HLL, 64>(v));
+        const uint64_t u52 = g.next64() >> 12;
+        const uint64_t cut = ((uint64_t)S.ctl[5] << 32) | S.ctl[4];
+        if (u52 > cut) return;                                    // its first point cannot reach the lower bound: nor can any later one
+        const uint32_t klow = S.ctl[0];
+        double x = -spec_ln(1.0 - (double)u52 * 0x1.0p-52) / am;
+        uint32_t k = hll_k(x, inv_lnb);
+        if (k <= klow) return;
+        uint32_t t = (uint32_t)rng_uint(g, (uint64_t)m, zone_m);
+        atomicMax(&S.tab[t], k);                                  // j = 0: p[0] after swap(p[0], p[t]) is t
+        if (!walk) return;
+        // j >= 1: lazily materialised permutation. Position 0 now holds t and position t holds 0.
+        uint32_t tpos[HL_JR], tval[HL_JR]; uint32_t nt = 0;
+        const uint32_t st = COLD ? (*stamp)++ : 0, l = threadIdx.x;
+        if (COLD) { q[(uint64_t)0 * HL_CT + l] = st; perm[(uint64_t)0 * HL_CT + l] = t; q[(uint64_t)t * HL_CT + l] = st; perm[(uint64_t)t * HL_CT + l] = 0; }
+        else if (t != 0) { tpos[0] = t; tval[0] = 0; nt = 1; }
+        for (uint32_t j = 1; j < m; j++) {
+            const double te = -spec_ln(1.0 - g.u64f());
+            const double den = GS_HLL_A * (double)(m - j);
+            x = x + te / den;
+            k = hll_k(x, inv_lnb);
+            if (k <= klow) break;
+            const uint64_t range = (uint64_t)(m - j);
+            t = j + (uint32_t)rng_uint(g, range, uint_zone(range));
+            uint32_t sl;
+            if (COLD) {
+                const uint64_t ij = (uint64_t)j * HL_CT + l, it = (uint64_t)t * HL_CT + l;
+                if (q[ij] != st) { q[ij] = st; perm[ij] = j; }
+                if (q[it] != st) { q[it] = st; perm[it] = t; }
+                const uint32_t tmp = perm[ij]; perm[ij] = perm[it]; perm[it] = tmp;
+                sl = perm[ij];
+            } else {
+                uint32_t pj = j, pt = t; int hit = -1;
+#pragma unroll
+                for (int i = 0; i < HL_JR; i++) if ((uint32_t)i < nt) { if (tpos[i] == j) pj = tval[i]; if (tpos[i] == t) { pt = tval[i]; hit = i; } }
+                if (t != j) {
+                    if (hit >= 0) {
+#pragma unroll
+                        for (int i = 0; i < HL_JR; i++) if (i == hit) tval[i] = pj;
+                    } else {
+                        if (nt == HL_JR) { S.ctl[3] = 1; return; }       // outgrown: the genome is redone by the cold instantiation
+#pragma unroll
+                        for (int i = 0; i < HL_JR; i++) if ((uint32_t)i == nt) { tpos[i] = t; tval[i] = pj; }
+                        nt++;
+                    }
+                }
+                sl = (t != j) ? pt : pj;
+            }
+            atomicMax(&S.tab[sl], k);
+        }
+    }
+};
+template <bool AA, bool COLD>
+__global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
+        const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off,
+        const uint64_t *__restrict__ gen_units, const uint32_t *__restrict__ list, uint32_t n_items, uint32_t k, uint32_t m, double inv_lnb,
+        const uint64_t *__restrict__ ucut, uint32_t *__restrict__ lane_q, uint32_t *__restrict__ lane_perm, unsigned long long *__restrict__ counter,
+        uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_hll[];
+    HllShared S; S.tab = (uint32_t *)s_hll; S.ctl = (volatile uint32_t *)(S.tab + m);
+    const uint32_t T = COLD ? HL_CT : HL_T;
+    uint32_t *q = COLD ? lane_q + (uint64_t)blockIdx.x * m * HL_CT : nullptr, *perm = COLD ? lane_perm + (uint64_t)blockIdx.x * m * HL_CT : nullptr;
+    uint32_t stamp = 0;
+    const uint64_t zone_m = uint_zone(m);
+    const double am = GS_HLL_A * (double)m;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) S.ctl[1] = (uint32_t)atomicAdd(counter, 1ull);
+        __syncthreads();
+        const uint32_t c = S.ctl[1];
+        if (c >= n_items) break;
+        const uint64_t g = list ? list[c] : c;
+        for (uint32_t i = threadIdx.x; i < m; i += T) S.tab[i] = 0;
+        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[3] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; }
+        __syncthreads();
+        const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
+        const uint32_t nchunks = (uint32_t)std::max<uint64_t>(1, units / ((uint64_t)T * 8));
+        for (int pass = 0; pass < 2; pass++) {
+            HllEmit<COLD> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1};
+            for (uint32_t ch = 0; ch < nchunks; ch++) {
+                walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, ch, nchunks, emit);
+                if (pass == 0 || ch + 1 == nchunks) {
+                    // refresh the lower bound: minimum register (pass A: running, between chunks; after pass A: exact)
+                    __syncthreads();
+                    if (threadIdx.x == 0) S.ctl[2] = 0xFFFFFFFFu;
+                    __syncthreads();
+                    uint32_t lo = 0xFFFFFFFFu;
+                    for (uint32_t i = threadIdx.x; i < m; i += T) lo = min(lo, S.tab[i]);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_down((int)lo, o));
+                    if ((threadIdx.x & 63) == 0) atomicMin((uint32_t *)&S.ctl[2], lo);
+                    __syncthreads();
+                    if (threadIdx.x == 0) { const uint32_t kl = S.ctl[2]; const uint64_t cu = ucut[kl]; S.ctl[0] = kl; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); }
+                    __syncthreads();
+                }
+                if (!COLD && S.ctl[3]) break;
+            }
+            if (!COLD && S.ctl[3]) break;
+        }
+        __syncthreads();
+        if (!COLD && S.ctl[3]) { if (threadIdx.x == 0) cold_flag[g] = 1; continue; }
+        for (uint32_t i = threadIdx.x; i < m; i += T) sig[g * (uint64_t)m + i] = (uint16_t)S.tab[i];
+    }
+}
+
+static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len,
+                   const uint64_t *rec_upre, const uint64_t *genome_rec_off, const uint64_t *gen_units, uint64_t n_genomes, uint16_t *sig_out)
+{
+    const uint32_t m = p->sketch_size;
+    const bool aa = p->data_t == GS_DATA_AA;
+    const double inv_lnb = 1.0 / spec_ln(GS_HLL_B);
+    // conservative skip thresholds on the 52 uniform bits, one per possible lower bound K (see the kernel comment)
+    std::vector<uint64_t> ucut((size_t)GS_HLL_Q + 2);
+    for (uint32_t K = 0; K <= GS_HLL_Q + 1; K++) {
+        double f = K < 2 ? 1.0 : GS_HLL_A * (double)m * pow(GS_HLL_B, -(double)(K - 2));
+        if (!(f < 1.0)) f = 1.0;
+        ucut[K] = (uint64_t)floor(f * 0x1.0p52);                  // u52 < 2^52 always: f = 1 never skips
+    }
+    PoolBuf dcut(c, 24), cold(c, 25), cnt(c, 38);
+    int rc;
+    if ((rc = dcut.alloc(8 * ucut.size()))) return rc;
+    if ((rc = cold.alloc(n_genomes))) return rc;
+    if ((rc = cnt.alloc(64))) return rc;
+    GS_HIP_CHECK(hipMemcpyAsync(dcut.p, ucut.data(), 8 * ucut.size(), hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemsetAsync(cold.p, 0, n_genomes, c->stream));
+    GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 8, c->stream));
+    const size_t lds = 4 * ((size_t)m + 8);
+    const uint32_t wgs = (uint32_t)std::min<uint64_t>(n_genomes, (uint64_t)c->n_cu * 2);
+    {
+        ProfScope ps(c, FAM_SKETCH);
+#define GS_LAUNCH_HLL(AAV)                                                                                                     \
+    do {                                                                                                                       \
+        auto kern = k_sketch_hll<AAV, false>;                                                                                  \
+        if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(HL_T), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, (const uint32_t *)nullptr, \
+                           (uint32_t)n_genomes, p->k, m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out); \
+    } while (0)
+        if (aa) GS_LAUNCH_HLL(true); else GS_LAUNCH_HLL(false);
+#undef GS_LAUNCH_HLL
+    }
+    GS_HIP_CHECK(hipGetLastError());
+    std::vector<uint8_t> h(n_genomes);
+    GS_HIP_CHECK(hipMemcpyAsync(h.data(), cold.p, n_genomes, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> list;
+    for (uint64_t g = 0; g < n_genomes; g++) if (h[g]) list.push_back((uint32_t)g);
+    if (list.empty()) return GS_OK;
+    // cold genomes (few k-mers per register): exact walks with the permutation in per-lane global scratch
+    const uint32_t nc = (uint32_t)list.size();
+    const uint32_t cw = std::min<uint32_t>(nc, (uint32_t)c->n_cu);
+    PoolBuf dl(c, 26), lq(c, 27), lp(c, 37);
+    if ((rc = dl.alloc(4 * (size_t)nc))) return rc;
+    if ((rc = lq.alloc((size_t)4 * cw * m * HL_CT))) return rc;
+    if ((rc = lp.alloc((size_t)4 * cw * m * HL_CT))) return rc;
+    GS_HIP_CHECK(hipMemcpyAsync(dl.p, list.data(), 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemsetAsync(lq.p, 0xFF, (size_t)4 * cw * m * HL_CT, c->stream));
+    GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 8, c->stream));
+#define GS_LAUNCH_HLLC(AAV)                                                                                                    \
+    do {                                                                                                                       \
+        auto kern = k_sketch_hll<AAV, true>;                                                                                   \
+        if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(cw), dim3(HL_CT), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, p->k, m, \
+                           inv_lnb, dcut.as<uint64_t>(), lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out); \
+    } while (0)
+    if (aa) GS_LAUNCH_HLLC(true); else GS_LAUNCH_HLLC(false);
+#undef GS_LAUNCH_HLLC
+    GS_HIP_CHECK(hipGetLastError());
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
 static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint64_t seq_bytes, const uint64_t *rec_start,
                            const uint64_t *rec_len, uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out)
 {
@@ -886,6 +1083,7 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
     GS_REQUIRE(c && (n_genomes == 0 || (seq && rec_start && rec_len && genome_rec_off && sig_out)), GS_ERR_INVALID, "null argument");
     if (n_genomes == 0) return GS_OK;
     GS_REQUIRE(n_genomes < ((uint64_t)1 << 31), GS_ERR_INVALID, "too many genomes in one batch");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const uint32_t m = p->sketch_size;
     if (p->algo == GS_ALGO_OPTDENS || p->algo == GS_ALGO_REVOPTDENS) {
@@ -918,6 +1116,18 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
         if (p->algo == GS_ALGO_SUPER) rc = run_smh<ALGO_SUPER, 64, uint32_t>(c, p, sq, rec_start, rec_len, up, genome_rec_off, gu, n_genomes, avg_units, sig_out);
         else if (vb == 32) rc = run_smh<ALGO_SUPER2, 32, uint32_t>(c, p, sq, rec_start, rec_len, up, genome_rec_off, gu, n_genomes, avg_units, sig_out);
         else rc = run_smh<ALGO_SUPER2, 64, uint64_t>(c, p, sq, rec_start, rec_len, up, genome_rec_off, gu, n_genomes, avg_units, sig_out);
+        if (rc) return rc;
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return GS_OK;
+    }
+    if (p->algo == GS_ALGO_HLL) {
+        PoolBuf upre(c, 20), gunits(c, 21);
+        rc = upre.alloc(8 * (n_rec + 1)); if (rc) return rc;
+        rc = gunits.alloc(8 * n_genomes); if (rc) return rc;
+        hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 3) / 4)), dim3(256), 0, c->stream, rec_start, rec_len,
+                           genome_rec_off, n_genomes, p->k, upre.as<uint64_t>(), gunits.as<uint64_t>());
+        GS_HIP_CHECK(hipGetLastError());
+        rc = run_hll(c, p, (const uint8_t *)seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), n_genomes, (uint16_t *)sig_out);
         if (rc) return rc;
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         return GS_OK;
@@ -955,6 +1165,7 @@ int gs_sketch_batch(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint6
     for (uint64_t r = 0; r < n_rec; r++)
         GS_REQUIRE(rec_start[r] + rec_len[r] <= sym_cap, GS_ERR_INVALID, "record %llu exceeds the sequence buffer", (unsigned long long)r);
     GS_REQUIRE(genome_rec_off[n_genomes] <= n_rec, GS_ERR_INVALID, "genome_rec_off exceeds n_rec");
+    GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     gs::DevBuf dseq, drs, drl, dgo, dsig;
     const uint64_t padded = gs::round_up(seq_bytes, 32) + 32;

@@ -25,6 +25,7 @@ template <int ALGO, int VBITS>
 GS_HD uint64_t elem_hash(uint64_t v)
 {
     if (ALGO == ALGO_PROB3A) return v;
+    if (ALGO == ALGO_HLL) return fx64(v);
     if (ALGO == ALGO_SUPER2 && VBITS == 32) return fx32_w32((uint32_t)v);
     return fx64(v);
 }
@@ -103,6 +104,41 @@ GS_HD void oph_draw(uint64_t h, uint32_t m, uint64_t zone, uint32_t &r23, uint32
     uint64_t o1;
     two_draw(h, m, zone, o1, bin);
     r23 = (uint32_t)(o1 >> 41);
+}
+
+// ---- SPEC 2 LN / TEXP, SPEC 3.4 hll (SetSketch1): natural logarithm from IEEE + - * / only (no fma contraction: the library is
+// built with -ffp-contract=off), so the host oracle and the device evaluate the same instruction sequence
+GS_HD double spec_ln(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t bits = (uint64_t)__double_as_longlong(x);
+#else
+    uint64_t bits; __builtin_memcpy(&bits, &x, 8);
+#endif
+    long long e = (long long)((bits >> 52) & 0x7FF) - 1023;
+    const uint64_t mb = (bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double t = __longlong_as_double((long long)mb);
+#else
+    double t; __builtin_memcpy(&t, &mb, 8);
+#endif
+    if (t > 1.4142135623730951) { t = t * 0.5; e += 1; }
+    const double s = (t - 1.0) / (t + 1.0), z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0; p = p * z + 1.0 / 19.0; p = p * z + 1.0 / 17.0; p = p * z + 1.0 / 15.0; p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0; p = p * z + 1.0 / 9.0; p = p * z + 1.0 / 7.0; p = p * z + 1.0 / 5.0; p = p * z + 1.0 / 3.0; p = p * z + 1.0;
+    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+}
+#define GS_HLL_B 1.001
+#define GS_HLL_A 20.0
+#define GS_HLL_Q 65534u
+GS_HD uint32_t hll_k(double x, double inv_lnb)
+{
+    if (!(x > 0.0)) return GS_HLL_Q + 1;
+    const double y = 1.0 - spec_ln(x) * inv_lnb;
+    if (y < 0.0) return 0;
+    if (y >= (double)(GS_HLL_Q + 1)) return GS_HLL_Q + 1;
+    return (uint32_t)y;
 }
 
 }  // namespace gs

@@ -39,6 +39,8 @@ const char *gs_version(void);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Context: one per (process, GPU). Owns a HIP stream; every call on a context is enqueued on it.   */
+/* Every entry point that takes a context (or an index made on one) may be called concurrently from */
+/* several host threads: the context serialises them internally (one stream, one scratch pool).     */
 /* `stream` may be NULL (the context creates its own) or an existing hipStream_t to adopt.          */
 typedef struct gs_ctx gs_ctx;
 int   gs_ctx_create(gs_ctx **out, int device_id, void *stream);
@@ -70,7 +72,7 @@ int   gs_dev_memset(gs_ctx *, void *dst_dev, int byte, size_t bytes);
 /* mirrors kmerutils::sketcharg::SeqSketcherParams{kmer_size, sketch_size, algo, data_t}            */
 typedef struct { uint32_t k, sketch_size, algo, data_t; } gs_sketch_params;
 
-int    gs_check_params(const gs_sketch_params *);       /* k=15, k>32 (DNA) / k>12 (AA), hll -> error */
+int    gs_check_params(const gs_sketch_params *);       /* k=15, k>32 (DNA) / k>12 (AA) -> error */
 int    gs_sig_kind(const gs_sketch_params *);           /* GS_KIND_* */
 size_t gs_sig_elem_bytes(const gs_sketch_params *);
 int    gs_value_bits(const gs_sketch_params *);         /* width of Kmer::Val: 32 or 64 */
@@ -83,7 +85,8 @@ int    gs_value_bits(const gs_sketch_params *);         /* width of Kmer::Val: 3
  *   record r   = bases/residues [rec_start[r], rec_start[r]+rec_len[r]); k-mers never span records.
  *   genome g   = records [genome_rec_off[g], genome_rec_off[g+1]).  `--block` mode = one record/genome.
  *   sig_out    n_genomes x sketch_size elements of gs_sig_kind(), caller owned.
- * Re-entrant per context (the reference clones the sketcher into every worker, dnasketch.rs:305).
+ * Thread-safe: callable concurrently from many host threads on ONE context, like the reference's &self sketcher cloned into
+ * --nbthreads workers (dnasketch.rs:252,305,322); calls on one context queue on its stream, contexts run side by side.
  */
 int gs_sketch_batch(gs_ctx *, const gs_sketch_params *, const void *seq, uint64_t seq_bytes,
                     const uint64_t *rec_start, const uint64_t *rec_len, uint64_t n_rec,
@@ -175,6 +178,22 @@ uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluation
  * out[0] memory-side atomics sent by the match-join, out[1] candidates popped by the dense traversal, out[2] pops that accepted
  * at least one neighbour, out[3] traversal workgroups in flight (last launch), out[4] bytes of adjacency a pop loads, out[5..7] 0 */
 int      gs_index_search_stats(gs_index *, uint64_t out[8], int reset);
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Multi-GPU: one process per GPU, query batches sharded, DB + graph replicated. The path has ONE exchange step - the
+ * all-gather of the per-rank top-k blocks - and this is it, over RCCL / xGMI, for hosts that are not Python (the reference's host is
+ * Rust; conceptual ancestor: the per-shard loop of scripts/multiple_search.sh:71-107). Bootstrap like NCCL: one rank calls
+ * gs_comm_unique_id and hands the 128 bytes to the others by its own means (file, socket, MPI); every rank then calls gs_comm_create. */
+typedef struct gs_comm gs_comm;
+int  gs_comm_unique_id(void *id_out_128);
+int  gs_comm_create(gs_ctx *, int n_ranks, int rank, const void *id_128, gs_comm **out);
+void gs_comm_destroy(gs_comm *);
+int  gs_comm_rank(const gs_comm *);
+int  gs_comm_size(const gs_comm *);
+/* ids_dev / dist_dev: this rank's nq_local x knbn block (device memory); all_*_dev: n_ranks x nq_local x knbn, rank order.
+ * One ncclAllGather of the packed block (12 bytes per neighbour). Same nq_local and knbn on every rank. */
+int  gs_comm_allgather_topk_dev(gs_comm *, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint32_t knbn,
+                                uint64_t *all_ids_dev, float *all_dist_dev);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Synthetic inputs generated in HBM (bench / tests): counter-based, reproducible on the host.      */

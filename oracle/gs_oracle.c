@@ -38,6 +38,7 @@ static inline uint64_t elem_hash(uint32_t algo, int vbits, uint64_t v)
 {
     switch (algo) {
     case GO_ALGO_PROB3A: return v;
+    case GO_ALGO_HLL:    return fx64(v);
     case GO_ALGO_SUPER2: return vbits == 32 ? fx32(v, 32) : fx64(v);
     default:             return fx64(v);
     }
@@ -99,7 +100,8 @@ float go_test_u32f(uint64_t seed) { rng_t g; rng_seed(&g, seed); return (float)r
 int go_check_params(const go_params *p)
 {
     if (!p || p->sketch_size < 2) return -1;
-    if (p->algo > GO_ALGO_REVOPTDENS || p->algo == GO_ALGO_HLL) return -2;
+    if (p->algo > GO_ALGO_REVOPTDENS) return -2;
+    if (p->algo == GO_ALGO_HLL && p->sketch_size > 65535u * 16u) return -1;
     if (p->data_t == GO_DATA_DNA) {
         if (p->k < 1 || p->k > 32 || p->k == 15) return -3;   /* dnarequest.rs:451-454, README.md:676 */
     } else if (p->data_t == GO_DATA_AA) {
@@ -413,6 +415,73 @@ static void prob_sketch(const go_params *p, int vbits, vec64_t *vals, void *sig)
     free(sg);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* SPEC 2 LN / TEXP and SPEC 3.4: hll = SetSketch1 with u16 registers                           */
+/* (probminhash::setsketcher::SetSketcher behind kmerutils' HyperLogLogSketch<Kmer,u16>;        */
+/*  parameters from SetSketchParams::default() + set_m: dnasketch.rs:541-574)                   */
+/* ------------------------------------------------------------------------------------------ */
+static double spec_ln(double x)
+{
+    uint64_t bits; memcpy(&bits, &x, 8);
+    int64_t e = (int64_t)((bits >> 52) & 0x7FF) - 1023;
+    uint64_t mb = (bits & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+    double t; memcpy(&t, &mb, 8);
+    if (t > 1.4142135623730951) { t = t * 0.5; e += 1; }
+    const double s = (t - 1.0) / (t + 1.0), z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0; p = p * z + 1.0 / 19.0; p = p * z + 1.0 / 17.0; p = p * z + 1.0 / 15.0; p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0; p = p * z + 1.0 / 9.0; p = p * z + 1.0 / 7.0; p = p * z + 1.0 / 5.0; p = p * z + 1.0 / 3.0; p = p * z + 1.0;
+    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+}
+double go_test_ln(double x) { return spec_ln(x); }
+#define HLL_B 1.001
+#define HLL_A 20.0
+#define HLL_Q 65534u
+static inline uint32_t hll_k(double x, double inv_lnb)
+{
+    if (!(x > 0.0)) return HLL_Q + 1;
+    const double y = 1.0 - spec_ln(x) * inv_lnb;
+    if (y < 0.0) return 0;
+    if (y >= (double)(HLL_Q + 1)) return HLL_Q + 1;
+    return (uint32_t)y;
+}
+typedef struct {
+    const go_params *p; uint32_t m; double inv_lnb;
+    uint32_t *K; uint32_t klow, nmod;            /* klow: lower bound of the registers (pruning only), refreshed every m modifications */
+    int64_t *q; uint32_t *perm; int64_t item;
+} hll_t;
+static void hll_emit(void *ctx, uint64_t v)
+{
+    hll_t *h = (hll_t *)ctx;
+    const uint32_t m = h->m;
+    rng_t g;
+    rng_seed(&g, elem_hash(GO_ALGO_HLL, 64, v));
+    const int64_t it = h->item++;
+    double x = 0.0;
+    for (uint32_t j = 0; j < m; j++) {
+        const double u = rng_u64f(&g);
+        const double te = -spec_ln(1.0 - u);
+        const double den = HLL_A * (double)(m - j);
+        x = x + te / den;
+        const uint32_t k = hll_k(x, h->inv_lnb);
+        if (k <= h->klow) break;
+        const uint32_t t = j + (uint32_t)rng_uint(&g, (uint64_t)(m - j));
+        if (h->q[j] != it) { h->q[j] = it; h->perm[j] = j; }
+        if (h->q[t] != it) { h->q[t] = it; h->perm[t] = t; }
+        const uint32_t tmp = h->perm[j]; h->perm[j] = h->perm[t]; h->perm[t] = tmp;
+        const uint32_t sl = h->perm[j];
+        if (k > h->K[sl]) {
+            h->K[sl] = k;
+            if (++h->nmod >= m) {                 /* the paper's lower-bound refresh */
+                uint32_t lo = h->K[0];
+                for (uint32_t i = 1; i < m; i++) if (h->K[i] < lo) lo = h->K[i];
+                h->klow = lo; h->nmod = 0;
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* sketch driver == SeqSketcherT::sketch_compressedkmer_seqs, one call per genome              */
 /* (dnasketch.rs:336,357; dnarequest.rs:272,287; aasketch.rs:313,329; aarequest.rs:268,283)    */
@@ -432,6 +501,14 @@ static void sketch_one(const go_params *p, const uint8_t *seq, const uint64_t *r
         for (uint64_t r = 0; r < nrec; r++) for_each_kmer(p, seq, rs[r], rl[r], smh_emit, &s);
         smh_finish(&s, sig);
         smh_free(&s);
+    } else if (p->algo == GO_ALGO_HLL) {
+        hll_t h; memset(&h, 0, sizeof h);
+        h.p = p; h.m = m; h.inv_lnb = 1.0 / spec_ln(HLL_B);
+        h.K = (uint32_t *)calloc(m, 4); h.q = (int64_t *)malloc(8 * (size_t)m); h.perm = (uint32_t *)malloc(4 * (size_t)m);
+        for (uint32_t i = 0; i < m; i++) h.q[i] = -1;
+        for (uint64_t r = 0; r < nrec; r++) for_each_kmer(p, seq, rs[r], rl[r], hll_emit, &h);
+        for (uint32_t i = 0; i < m; i++) ((uint16_t *)sig)[i] = (uint16_t)h.K[i];
+        free(h.K); free(h.q); free(h.perm);
     } else {
         vec64_t vals = { 0, 0, 0 };
         for (uint64_t r = 0; r < nrec; r++) for_each_kmer(p, seq, rs[r], rl[r], vec_emit, &vals);

@@ -90,6 +90,7 @@ uint64_t go_test_fx(uint64_t v, int hasher_bits, int value_bits);
 uint64_t go_test_uint(uint64_t seed, uint64_t n);
 double   go_test_u64f(uint64_t seed);
 float    go_test_u32f(uint64_t seed);
+double   go_test_ln(double x);   /* SPEC 2 LN */
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,8 @@ def synth_sig_db(n_roots, per, m, seed, dtype=np.float32, jlo=0.3, jhi=0.99):
             return rng.integers(0, 1 << 23, shape).astype(np.float32) * np.float32(2.0 ** -23)
         if np.dtype(dtype) == np.uint32:
             return rng.integers(0, 1 << 32, shape, dtype=np.uint64).astype(np.uint32)
+        if np.dtype(dtype) == np.uint16:                          # SetSketch registers: a narrow band of values, so chance agreement happens
+            return rng.integers(18000, 18400, shape).astype(np.uint16)
         return rng.integers(0, 1 << 63, shape, dtype=np.uint64)
 
     roots = rnd((n_roots, m))

@@ -50,6 +50,8 @@ def lib():
         L.go_filter_aa.restype = C.c_uint64
         L.go_kmers.argtypes = [C.POINTER(Params), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64]
         L.go_kmers.restype = C.c_uint64
+        L.go_test_ln.argtypes = [C.c_double]
+        L.go_test_ln.restype = C.c_double
         L.go_sketch_batch.argtypes = [C.POINTER(Params), vp, u64p, u64p, u64p, C.c_uint64, vp, C.c_int]
         L.go_hamming_count.argtypes = [C.c_int, C.c_uint32, vp, vp]
         L.go_hamming_count.restype = C.c_uint32

@@ -33,8 +33,9 @@ def test_parameter_validation_mirrors_reference():
         with pytest.raises(G.GsError) as e:
             P(*args)
         assert e.value.code == -1
+    assert P(21, 18000, "hll").sig_dtype() == np.uint16                   # HyperLogLogSketch<Kmer, u16> (dnasketch.rs:541-574)
     with pytest.raises(G.GsError) as e:
-        P(21, 100, "hll")
+        P(21, 50000, "hll")                                                # register table beyond LDS: refused, not approximated
     assert e.value.code == -3
 
 

@@ -10,6 +10,9 @@ import oracle_lib as O
 G_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz")
 
 
+G2_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2_hll.npz")
+
+
 def _load():
     z = np.load(G_PATH)
     genomes = {}
@@ -22,6 +25,10 @@ def _load():
         if key.startswith("sig_"):
             _, data, k, m, algo = key.split("_")
             cases.append((data, int(k[1:]), int(m[1:]), algo, z[key]))
+    z2 = np.load(G2_PATH)                       # SetSketch signatures of the same genomes (make_golden_hll.py)
+    for key in z2.files:
+        _, data, k, m, algo = key.split("_")
+        cases.append((data, int(k[1:]), int(m[1:]), algo, z2[key]))
     return z, genomes, cases
 
 
@@ -31,7 +38,7 @@ def _bits(a):
 
 def test_oracle_reproduces_golden_sketches():
     z, genomes, cases = _load()
-    assert len(cases) == 36
+    assert len(cases) == 36 + 8
     for data, k, m, algo, want in cases:
         recs = [r for g in genomes[data] for r in g]
         goff = np.cumsum([0] + [len(g) for g in genomes[data]]).astype(np.uint64)

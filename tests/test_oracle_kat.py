@@ -89,3 +89,18 @@ def test_ani_matches_readme_table():
         j = 1.0 - d
         assert abs(O.ani(d, 21, 1) - (1.0 + np.log(2 * j / (1 + j)) / 21) * 100.0) < 1e-9
         assert abs(O.ani(d, 21, 2) - (2 * j / (1 + j)) ** (1.0 / 21) * 100.0) < 1e-9
+
+
+def test_spec_ln_against_libm():
+    """SPEC 2 LN: the + - * / only logarithm the SetSketch registers are computed with agrees with libm to a few ulp"""
+    import math
+    L = O.lib()
+    assert L.go_test_ln(1.0) == 0.0
+    xs = [2.0, 0.5, math.e, 1.4142135623730951, 1.4142135623730954, 1e-300, 1e300, 2.0 ** -52, 1 - 2.0 ** -53, 3.7e-9, 0.999, 1.001]
+    rng = np.random.default_rng(4)
+    xs += list(np.exp(rng.uniform(-40, 40, 2000)))
+    for x in xs:
+        got, ref = L.go_test_ln(float(x)), math.log(float(x))
+        assert abs(got - ref) <= 4e-16 * max(1.0, abs(ref)), (x, got, ref)
+    # log_b steps of the register formula: 1/LN(1.001) and one register value by hand: x = 1e-8 -> 1 - ln(1e-8)/ln(1.001) = 18430.9...
+    assert int(1.0 - L.go_test_ln(1e-8) / L.go_test_ln(1.001)) == 18430

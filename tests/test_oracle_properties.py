@@ -7,6 +7,7 @@ import helpers as H
 import oracle_lib as O
 
 ALGOS = ["optdens", "revoptdens", "super", "super2", "prob"]
+SET_ALGOS = ALGOS + ["hll"]
 
 
 def py_kmers_dna(s, k):
@@ -71,7 +72,8 @@ def test_parameter_dispatch_follows_reference_tables():
     assert O.sig_dtype(O.params(21, 100, "super2")) == np.uint64
     assert O.sig_dtype(O.params(6, 100, "super2", "aa")) == np.uint32
     assert O.sig_dtype(O.params(7, 100, "super2", "aa")) == np.uint64
-    for bad in (O.params(15, 100, "optdens"), O.params(33, 100, "optdens"), O.params(13, 100, "optdens", "aa"), O.params(21, 100, "hll")):
+    assert O.sig_dtype(O.params(21, 100, "hll")) == np.uint16 and O.sig_dtype(O.params(7, 100, "hll", "aa")) == np.uint16    # dnasketch.rs:562-584
+    for bad in (O.params(15, 100, "optdens"), O.params(33, 100, "optdens"), O.params(13, 100, "optdens", "aa")):
         with pytest.raises(ValueError):
             O.sketch_batch(bad, np.zeros(8, np.uint8), np.zeros(1, np.uint64), np.zeros(1, np.uint64), np.array([0, 1], np.uint64))
 
@@ -83,7 +85,7 @@ def _sketch(algo, k, m, genomes, data="dna"):
     return O.sketch_batch(O.params(k, m, algo, data), seq, rs, rl, goff)
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", SET_ALGOS)
 def test_identical_and_reverse_complement_invariance(algo):
     rng = np.random.default_rng(3)
     g = H.dna_ascii(H.rand_dna(rng, 20000))
@@ -121,6 +123,34 @@ def test_min_sketch_mergeability(algo):
     a, b = H.dna_ascii(H.rand_dna(rng, 30000)), H.dna_ascii(H.rand_dna(rng, 30000))
     S = _sketch(algo, 21, 256, [[a], [b], [a, b]])
     assert np.array_equal(np.minimum(S[0], S[1]), S[2])
+
+
+def test_hll_registers_merge_by_max_and_track_jaccard():
+    """SetSketch (SPEC 3.4): the registers of A u B are the slot-wise MAX of those of A and of B - exactly, for any split, which is what
+    lets the reference sketch 10 M-base blocks independently and merge (dnasketch.rs:553) - and the fraction of equal registers follows
+    the Jaccard index (b = 1.001: chance collisions of different maxima are rare)."""
+    rng = np.random.default_rng(15)
+    a, b = H.dna_ascii(H.rand_dna(rng, 40000)), H.dna_ascii(H.rand_dna(rng, 25000))
+    S = _sketch("hll", 21, 256, [[a], [b], [a, b], [b, a], [a[:100], a[80:]]])
+    assert S.dtype == np.uint16
+    assert np.array_equal(np.maximum(S[0], S[1]), S[2]) and np.array_equal(S[2], S[3])
+    assert np.array_equal(S[0], S[4])                                     # an overlap of k-1 keeps the k-mer set
+    assert (S[0] > 0).all() and S[0].max() < 65535
+    k, m = 21, 2000
+    fam = H.family(rng, 60000, [0.005, 0.03])
+    G3 = _sketch("hll", k, m, [[H.dna_ascii(g)] for g in fam])
+    seq, rs, rl = O.pack_dna([H.dna_ascii(g) for g in fam])
+    sets = [set(O.kmers(O.params(k, m, "optdens"), seq, rs[i], rl[i]).tolist()) for i in range(3)]
+    est = []
+    for i in (1, 2):
+        J = len(sets[0] & sets[i]) / len(sets[0] | sets[i])
+        e = 1.0 - O.hamming_qxc(G3[:1], G3[i:i + 1])[0, 0]
+        est.append(e)
+        assert abs(e - J) < 4 * np.sqrt(J * (1 - J) / m) + 0.02, (i, J, e)
+    assert est[0] > est[1]
+    # tiny input: registers hit by no point stay 0; no k-mer at all: all 0
+    T = _sketch("hll", 21, 4096, [[H.dna_ascii(H.rand_dna(rng, 60))], [b"ACG"]])
+    assert (T[1] == 0).all() and 0 < (T[0] > 0).sum() <= 4096
 
 
 def test_prob_signature_is_subset_of_kmers_and_weight_sensitive():

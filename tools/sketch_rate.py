@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k-mers/s of gs_sketch_batch_dev for any DNA algorithm on synthetic genomes generated in HBM.
-usage: sketch_rate.py <algo: optdens|revoptdens|prob|super|super2> [n_genomes] [len] [k] [m] [dna|aa] [record_len]
+usage: sketch_rate.py <algo: optdens|revoptdens|prob|super|super2|hll> [n_genomes] [len] [k] [m] [dna|aa] [record_len]
 (record_len: split every genome into records of that many symbols - k-mers never span records, dnasketch.rs:348-363)"""
 import ctypes as C, os, sys, time
 import numpy as np
