@@ -231,7 +231,7 @@ def run_sketch(args, D):
             ref = O.sketch_batch(op, pk, np.zeros(1, np.uint64), np.array([L], np.uint64), np.array([0, 1], np.uint64))
             ok &= bool(np.array_equal(ref.view(np.uint32)[0], sig_dev.view(np.uint32)[g]))
         out["parity_checked"] = {"genomes": chk, "bit_exact_vs_oracle": ok}
-        out["cpu_baseline"] = cpu_sketch_baseline(O, op, args, kmers_per_genome, words, os.cpu_count() or 1) if D.world == 1 else None
+        out["cpu_baseline"] = cpu_sketch_baseline(O, op, args, kmers_per_genome, words, os.cpu_count() or 1) if (D.world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out))
     for p in (d_seq, d_sig, d_rs, d_rl, d_goff):
         ctx.free(p)
@@ -364,7 +364,7 @@ def run_request(args, D):
         out.update(request_accounting(args, ctx, hn, lib, chk, torch, D, dict(
             srch=(srch_ms, srch_n), tile=(tile_ms, tile_n), sk=(sk_ms, sk_n), stats=st, evals_total=evals_total, d_qsig=d_qsig, ids_t=ids_t,
             dist_t=dist_t, cnt_t=cnt_t)))
-        if D.world > 1:                                        # parity sample and CPU baseline: rank 0 at N=1 only
+        if D.world > 1 or args.no_cpu_baseline:                # parity sample and CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = None
         else:
             out.update(request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, nsteps_q, gbytes, words))
@@ -530,6 +530,7 @@ def main():
     ap.add_argument("--build-chunk", type=int, default=8192)
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle parity sample + CPU baseline leg (profiling passes: ~2 min of host work per run)")
     ap.add_argument("--selftest-launch", action="store_true", help="GPU-free check of the N-rank launch + single all-gather (gloo, stub searcher)")
     args = ap.parse_args()
     from gsearch_amd import sharding as S

@@ -61,6 +61,12 @@ SYMBOLS = {
     "gs_sketch_batch_dev": (_i, [_vp, _PP, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp]),
     "gs_fasta_scan": (_i, [_vp, _u64, _i, _u64, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "gs_pack_fasta_dev": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp]),
+    "gs_filter_aa_dev": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp]),
+    "gs_is_fasta_file": (_i, [C.c_char_p, _i]),
+    "gs_read_fasta_file": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_u64)]),
+    "gs_host_free": (None, [_vp]),
+    "gs_list_fasta_files": (_i, [C.c_char_p, _i, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
+    "gs_sketch_files": (_i, [_vp, _PP, C.POINTER(C.c_char_p), _u64, _i, _u32, _u32, _vp, _vp, _vp, _vp]),
     "gs_pack_dna": (_u64, [_vp, _u64, _vp, _u64]),
     "gs_filter_aa": (_u64, [_vp, _u64, _vp]),
     "gs_hamming_qxc": (_i, [_vp, _i, _u32, _vp, _u64, _vp, _u64, _vp]),
@@ -81,6 +87,8 @@ SYMBOLS = {
     "gs_index_get_data": (_i, [_vp, _u64, _u64, _vp]),
     "gs_index_save": (_i, [_vp, C.c_char_p]),
     "gs_index_load": (_i, [_vp, C.c_char_p, C.POINTER(_vp)]),
+    "gs_index_dump_hnswrs": (_i, [_vp, C.c_char_p]),
+    "gs_index_load_hnswrs": (_i, [_vp, C.c_char_p, C.POINTER(IndexParams), C.POINTER(_vp)]),
     "gs_index_insert_evals": (_u64, [_vp]),
     "gs_index_search_stats": (_i, [_vp, _vp, _i]),
     "gs_comm_unique_id": (_i, [_vp]),

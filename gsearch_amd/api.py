@@ -251,6 +251,18 @@ class _SeqSketcher:
         seq, rs, rl = self._pack(list(vseq))
         return [row for row in self.sketch_packed(seq, rs, rl, np.arange(len(rs) + 1, dtype=np.uint64))]
 
+    def sketch_files(self, paths, block=False, pio=0, threads=0):
+        """the reader side of sketchandstore_dir_compressedkmer (dnasketch.rs:240-300) for a list of FASTA files (plain / gz / bz2 / xz):
+        host threads read + decode + scan groups of `pio` files while the previous group crosses PCIe and the one before is packed and
+        sketched. -> ((n_files, m) signatures, records kept per file, symbols sketched per file, stats dict)"""
+        paths = [str(x).encode() for x in paths]
+        n = len(paths)
+        arr = (C.c_char_p * max(n, 1))(*paths)
+        out = np.zeros((n, self.params.c.sketch_size), dtype=self.sig_dtype())
+        nrec, nsym, st = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(4, np.float64)
+        check(self.ctx.L.gs_sketch_files(self.ctx.h, C.byref(self.params.c), arr, n, int(bool(block)), int(pio), int(threads), _p(out), _p(nrec), _p(nsym), _p(st)))
+        return out, nrec[:n], nsym[:n], {"host_read_decode_scan_s": st[0], "pcie_wait_s": st[1], "device_s": st[2], "wall_s": st[3]}
+
     def sketch_genomes(self, genomes):
         """Batch form used by the drivers: genomes = list of lists of records -> (n_genomes, m) array."""
         recs, goff = [], [0]
@@ -259,6 +271,33 @@ class _SeqSketcher:
             goff.append(len(recs))
         seq, rs, rl = self._pack(recs)
         return self.sketch_packed(seq, rs, rl, np.array(goff, dtype=np.uint64))
+
+
+def is_fasta_file(path, data_t="dna"):
+    """files.rs:117-146 is_fasta_dna_file / is_fasta_aa_file"""
+    return bool(_lib.load().gs_is_fasta_file(str(path).encode(), DATA[data_t] if isinstance(data_t, str) else int(data_t)))
+
+
+def read_fasta_file(path):
+    """file_to_buffer + needletail's transparent gz / bz2 / xz decoding (files.rs:220-250): the decompressed text as bytes"""
+    L = _lib.load()
+    p, n = C.c_void_p(), C.c_uint64()
+    check(L.gs_read_fasta_file(str(path).encode(), C.byref(p), C.byref(n)))
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        L.gs_host_free(p)
+
+
+def list_fasta_files(directory, data_t="dna"):
+    """recursive directory walk of process_dir (files.rs:148-215): accepted files in name order"""
+    L = _lib.load()
+    dt = DATA[data_t] if isinstance(data_t, str) else int(data_t)
+    n, nb = C.c_uint64(), C.c_uint64()
+    check(L.gs_list_fasta_files(str(directory).encode(), dt, None, 0, C.byref(n), C.byref(nb)))
+    buf = C.create_string_buffer(max(nb.value, 1))
+    check(L.gs_list_fasta_files(str(directory).encode(), dt, buf, nb.value, C.byref(n), C.byref(nb)))
+    return [x.decode() for x in buf.raw[:nb.value].split(b"\0") if x]
 
 
 def fasta_scan(text, skip_capsid=True):
@@ -445,6 +484,8 @@ class Hnsw:
 
     def set_extend_candidates(self, flag):
         self._frozen_check()
+        if flag and self.prm.ef_construction <= 2 * self.prm.max_nb_conn:      # refused here, before any sketching is done (gs_index_create repeats it)
+            raise GsError(_lib.GS_ERR_UNSUPPORTED, "extend_candidates with ef_construction <= 2*max_nb_conn is not implemented on the device")
         self.prm.extend_candidates = int(bool(flag))
 
     def set_keeping_pruned(self, flag):
@@ -574,6 +615,24 @@ class Hnsw:
         pops = int(out[1])
         return {"join_atomics": int(out[0]), "pops": pops, "accepting_pops": int(out[2]), "wg_in_flight": int(out[3]),
                 "adj_bytes": pops * int(out[4])}
+
+    def file_dump_hnswrs(self, basename):
+        """Hnsw::file_dump(dir, "hnswdump") in hnsw_rs' own format: <basename>.hnsw.graph + <basename>.hnsw.data (dumpload.rs:26-31)"""
+        check(self.ctx.L.gs_index_dump_hnswrs(self.h, str(basename).encode()))
+
+    @classmethod
+    def load_hnswrs(cls, basename, hint=None, ctx=None):
+        """HnswIo::load_hnsw counterpart for hnsw_rs dumps (reloadhnsw.rs:41-51); `hint`: an Hnsw whose parameters (capacity, level scale,
+        flags, seed, insert batch) later insertions should use"""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(ctx.L.gs_index_load_hnswrs(ctx.h, str(basename).encode(), C.byref(hint.prm) if hint is not None else None, C.byref(h)))
+        self = cls.__new__(cls)
+        self.ctx, self.h = ctx, h
+        self.prm = IndexParams()
+        check(ctx.L.gs_index_get_params(h, C.byref(self.prm)))
+        self.dtype = KIND_DTYPE[self.prm.kind]
+        return self
 
     def insert_evals(self):
         return 0 if self.h is None else self.ctx.L.gs_index_insert_evals(self.h)

@@ -1,0 +1,386 @@
+// gs_files.hip — the reader side of the path on the host: what gsearch does between a directory of FASTA files
+// and the sketcher call, for a LIST of files, with the per-byte work on the device.
+//   /root/reference/src/utils/files.rs:117-146   is_fasta_dna_file / is_fasta_aa_file            -> gs_is_fasta_file
+//   files.rs:220-250 file_to_buffer + needletail's transparent decompression (gz / bz2 / xz)       -> gs_read_fasta_file
+//   files.rs:148-215,345-455 recursive directory walk                                              -> gs_list_fasta_files
+//   files.rs:258-341 process_files_group (`--pio` files read together, parsed in parallel)
+//   src/dna/dnafiles.rs:43-360, src/aa/aafiles.rs:30-300 (by-sequence and --block readers)
+//   src/dna/dnasketch.rs:240-300 (reader thread -> sketcher)                                        -> gs_sketch_files
+// gs_sketch_files pipelines groups of files: host threads read + decompress + find record boundaries of group g+1 while the raw text
+// of group g crosses PCIe from a pinned staging buffer on a copy stream and group g-1 is filtered / 2-bit packed and sketched on the
+// context's stream. One signature per file.
+#include <dirent.h>
+#include <dlfcn.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <zlib.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <future>
+#include <string>
+#include <thread>
+#include <vector>
+#include "gs_internal.hpp"
+
+namespace gs {
+int ingest_records_dev(gs_ctx *c, bool aa, bool contiguous, const void *text_dev, uint64_t n_bytes, const uint64_t *seq_begin, const uint64_t *seq_end,
+                       uint64_t n_rec, void *out_dev, uint64_t out_base0, uint64_t *rec_start_out, uint64_t *rec_len_out, uint64_t *out_end);
+
+// growable byte buffer WITHOUT value initialisation (std::vector::resize zero-fills: one wasted pass over every file)
+struct Bytes {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    Bytes() = default;
+    Bytes(const Bytes &) = delete;
+    Bytes &operator=(const Bytes &) = delete;
+    Bytes(Bytes &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~Bytes() { free(p); }
+    bool reserve(size_t c) { if (c <= cap) return true; void *q = realloc(p, c); if (!q) return false; p = (uint8_t *)q; cap = c; return true; }
+    bool resize(size_t c) { if (!reserve(c)) return false; n = c; return true; }
+    size_t size() const { return n; }
+    uint8_t *data() { return p; }
+    uint8_t operator[](size_t i) const { return p[i]; }
+    const uint8_t *data() const { return p; }
+    bool empty() const { return n == 0; }
+    void swap(Bytes &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+    void release() { free(p); p = nullptr; n = cap = 0; }
+};
+
+static bool ends_with(const std::string &s, const char *suf)
+{
+    const size_t n = strlen(suf);
+    return s.size() >= n && !s.compare(s.size() - n, n, suf);
+}
+
+// ---- decompression by magic bytes, like needletail's parse_fastx_reader -----------------------------------------------------------
+static int inflate_gzip(const uint8_t *in, size_t n, Bytes &out)
+{
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) { set_error("zlib inflateInit2 failed"); return GS_ERR_IO; }       // 32: gzip or zlib header
+    out.resize(std::max<size_t>(n * 4, 1 << 16));
+    zs.next_in = (Bytef *)in; zs.avail_in = (uInt)std::min<size_t>(n, 1u << 30);
+    size_t consumed = 0, produced = 0;
+    for (;;) {
+        if (produced == out.size()) out.resize(out.size() * 2);
+        zs.next_out = out.data() + produced; zs.avail_out = (uInt)std::min<size_t>(out.size() - produced, 1u << 30);
+        const uInt in0 = zs.avail_in, out0 = zs.avail_out;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        consumed += in0 - zs.avail_in; produced += out0 - zs.avail_out;
+        if (zs.avail_in == 0 && consumed < n) zs.avail_in = (uInt)std::min<size_t>(n - consumed, 1u << 30), zs.next_in = (Bytef *)in + consumed;
+        if (rc == Z_STREAM_END) {
+            if (consumed >= n) break;
+            if (inflateReset(&zs) != Z_OK) break;                  // multi-member gzip (bgzip, concatenated files)
+            continue;
+        }
+        if (rc != Z_OK && rc != Z_BUF_ERROR) { inflateEnd(&zs); set_error("gzip stream is corrupt (zlib %d)", rc); return GS_ERR_IO; }
+        if (rc == Z_BUF_ERROR && zs.avail_in == 0 && consumed >= n) { inflateEnd(&zs); set_error("gzip stream is truncated"); return GS_ERR_IO; }
+    }
+    inflateEnd(&zs);
+    out.resize(produced);
+    return GS_OK;
+}
+// bz2 and xz: the image ships the shared libraries without headers, so the two stable one-shot entry points are bound by hand
+typedef int (*fn_bz2)(char *dest, unsigned int *destLen, char *source, unsigned int sourceLen, int small, int verbosity);
+typedef int (*fn_xz)(uint64_t *memlimit, uint32_t flags, const void *allocator, const uint8_t *in, size_t *in_pos, size_t in_size, uint8_t *out, size_t *out_pos, size_t out_size);
+static int decompress_grow(const char *what, const uint8_t *in, size_t n, Bytes &out)
+{
+    static std::atomic<void *> h_bz2{nullptr}, h_xz{nullptr};
+    const bool bz = !strcmp(what, "bz2");
+    std::atomic<void *> &slot = bz ? h_bz2 : h_xz;
+    void *h = slot.load();
+    if (!h) {
+        const char *names_bz[] = {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}, *names_xz[] = {"liblzma.so.5", "liblzma.so"};
+        for (const char *nm : (bz ? std::vector<const char *>(names_bz, names_bz + 3) : std::vector<const char *>(names_xz, names_xz + 2))) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        GS_REQUIRE(h, GS_ERR_UNSUPPORTED, "%s input: the decompression library is not installed (%s)", what, dlerror());
+        slot.store(h);
+    }
+    size_t cap = std::max<size_t>(n * 6, 1 << 16);
+    for (int attempt = 0; attempt < 12; attempt++, cap *= 2) {
+        out.resize(cap);
+        if (bz) {
+            fn_bz2 f = (fn_bz2)dlsym(h, "BZ2_bzBuffToBuffDecompress");
+            GS_REQUIRE(f, GS_ERR_UNSUPPORTED, "libbz2 lacks BZ2_bzBuffToBuffDecompress");
+            GS_REQUIRE(n < (1ull << 32) && cap < (1ull << 32), GS_ERR_UNSUPPORTED, "bz2 members beyond 4 GB are not supported");
+            unsigned int dl = (unsigned int)cap;
+            const int rc = f((char *)out.data(), &dl, (char *)in, (unsigned int)n, 0, 0);
+            if (rc == 0) { out.resize(dl); return GS_OK; }
+            GS_REQUIRE(rc == -8 /* BZ_OUTBUFF_FULL */, GS_ERR_IO, "bz2 stream is corrupt (libbz2 %d)", rc);
+        } else {
+            fn_xz f = (fn_xz)dlsym(h, "lzma_stream_buffer_decode");
+            GS_REQUIRE(f, GS_ERR_UNSUPPORTED, "liblzma lacks lzma_stream_buffer_decode");
+            uint64_t memlimit = UINT64_MAX; size_t ip = 0, op = 0;
+            const int rc = f(&memlimit, 0, nullptr, in, &ip, n, out.data(), &op, cap);
+            if (rc == 0) { out.resize(op); return GS_OK; }
+            GS_REQUIRE(rc == 10 /* LZMA_BUF_ERROR */, GS_ERR_IO, "xz stream is corrupt (liblzma %d)", rc);
+        }
+    }
+    GS_REQUIRE(false, GS_ERR_IO, "%s stream expands beyond every reasonable size", what);
+}
+static int read_whole_file(const char *path, Bytes &raw)
+{
+    FILE *f = fopen(path, "rb");
+    GS_REQUIRE(f, GS_ERR_IO, "cannot open %s", path);
+    struct stat st; size_t want = (fstat(fileno(f), &st) == 0 && st.st_size > 0) ? (size_t)st.st_size : (size_t)10000000;   // files.rs:233 fallback
+    raw.resize(want);
+    size_t got = 0;
+    for (;;) {
+        const size_t r = fread(raw.data() + got, 1, raw.size() - got, f);
+        got += r;
+        if (r == 0) break;
+        if (got == raw.size()) raw.resize(raw.size() * 2);
+    }
+    fclose(f);
+    raw.resize(got);
+    return GS_OK;
+}
+static int read_fasta(const char *path, Bytes &text)
+{
+    Bytes raw;
+    int rc = read_whole_file(path, raw); if (rc) return rc;
+    if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) return inflate_gzip(raw.data(), raw.size(), text);
+    if (raw.size() >= 3 && raw[0] == 'B' && raw[1] == 'Z' && raw[2] == 'h') return decompress_grow("bz2", raw.data(), raw.size(), text);
+    if (raw.size() >= 6 && !memcmp(raw.data(), "\xfd" "7zXZ\0", 6)) return decompress_grow("xz", raw.data(), raw.size(), text);
+    text.swap(raw);
+    return GS_OK;
+}
+
+struct FileBlob {       // one file after the host stage
+    Bytes text; std::vector<uint64_t> sb, se; int rc = GS_OK; std::string err; double read_s = 0;
+};
+static void host_stage(const char *path, FileBlob *b)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    b->rc = read_fasta(path, b->text);
+    if (b->rc == GS_OK) {
+        uint64_t nr = 0;
+        b->rc = gs_fasta_scan((const char *)b->text.data(), b->text.size(), 1, 0, nullptr, nullptr, nullptr, nullptr, &nr);
+        if (b->rc == GS_OK) {
+            b->sb.resize(nr); b->se.resize(nr);
+            b->rc = gs_fasta_scan((const char *)b->text.data(), b->text.size(), 1, nr, b->sb.data(), b->se.data(), nullptr, nullptr, &nr);
+        }
+    }
+    if (b->rc) b->err = gs_last_error();                          // thread-local: carry it to the caller's thread
+    b->read_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+}  // namespace gs
+
+extern "C" {
+
+/* files.rs:117-146: 1 when `path` carries one of the FASTA suffixes gsearch accepts for the data type (DNA: fna fa fasta, also .gz .xz .bz2;
+ * AA: faa, also .gz .xz .bz2) */
+int gs_is_fasta_file(const char *path, int data_t)
+{
+    if (!path) return 0;
+    const std::string f(path);
+    if (data_t == GS_DATA_AA) return gs::ends_with(f, "faa.gz") || gs::ends_with(f, "faa") || gs::ends_with(f, "faa.xz") || gs::ends_with(f, "faa.bz2");
+    static const char *suf[] = {"fna.gz", "fa.gz", "fa.xz", "fna.xz", "fasta.xz", "fa.bz2", "fna.bz2", "fasta.bz2", "fasta.gz", "fna", "fa", "fasta"};
+    for (const char *s : suf) if (gs::ends_with(f, s)) return 1;
+    return 0;
+}
+
+/* read a FASTA file into memory, decompressing gzip (multi-member), bzip2 or xz by magic bytes (needletail::parse_fastx_reader does the
+ * same behind files.rs:220-250 file_to_buffer). *text_out is malloc-ed: release with gs_host_free. */
+int gs_read_fasta_file(const char *path, void **text_out, uint64_t *n_out)
+{
+    GS_REQUIRE(path && text_out && n_out, GS_ERR_INVALID, "null argument");
+    gs::Bytes text;
+    int rc = gs::read_fasta(path, text); if (rc) return rc;
+    void *p = malloc(text.size() + 1);
+    GS_REQUIRE(p, GS_ERR_IO, "out of host memory");
+    memcpy(p, text.data(), text.size());
+    *text_out = p; *n_out = text.size();
+    return GS_OK;
+}
+void gs_host_free(void *p) { free(p); }
+
+/* files.rs:148-215 / 345-455: every accepted file under `dir`, recursively, directory entries in name order (read_dir order is
+ * unspecified upstream). Two calls: paths_buf NULL / cap 0 to learn *n_out and *bytes_out, then a buffer that receives the
+ * NUL-terminated paths back to back. */
+int gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t cap_bytes, uint64_t *n_out, uint64_t *bytes_out)
+{
+    GS_REQUIRE(dir && n_out && bytes_out, GS_ERR_INVALID, "null argument");
+    std::vector<std::string> found, stack{std::string(dir)};
+    while (!stack.empty()) {
+        const std::string d = stack.back(); stack.pop_back();
+        DIR *h = opendir(d.c_str());
+        GS_REQUIRE(h, GS_ERR_IO, "directory %s does not exist or is not readable", d.c_str());
+        std::vector<std::string> files, dirs;
+        while (struct dirent *e = readdir(h)) {
+            if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+            const std::string p = d + "/" + e->d_name;
+            struct stat st;
+            if (stat(p.c_str(), &st)) continue;
+            if (S_ISDIR(st.st_mode)) dirs.push_back(p);
+            else if (gs_is_fasta_file(p.c_str(), data_t)) files.push_back(p);
+        }
+        closedir(h);
+        std::sort(files.begin(), files.end()); std::sort(dirs.rbegin(), dirs.rend());
+        found.insert(found.end(), files.begin(), files.end());
+        stack.insert(stack.end(), dirs.begin(), dirs.end());
+    }
+    uint64_t bytes = 0;
+    for (auto &f : found) bytes += f.size() + 1;
+    *n_out = found.size(); *bytes_out = bytes;
+    if (paths_buf && cap_bytes >= bytes) { char *w = paths_buf; for (auto &f : found) { memcpy(w, f.c_str(), f.size() + 1); w += f.size() + 1; } }
+    return GS_OK;
+}
+
+/*
+ * One signature per file, in input order, for n_files FASTA files (plain, .gz, .bz2, .xz):
+ *   block_mode 0  by sequence: every record is its own sequence, k-mers never span records (process_file_by_sequence)
+ *   block_mode 1  --block: the records of a file are concatenated, k-mers span the joins (process_file_in_one_block)
+ * `capsid` records are skipped in both (dnafiles.rs:62-67,245). pio = files per group (`--pio`, files.rs:258-341; 0 -> 64),
+ * n_threads = host threads that read / decompress / scan (0 -> hardware concurrency).
+ * sig_out: HOST, n_files x sketch_size elements. n_records_out / n_symbols_out (optional, HOST, per file): records kept and bases /
+ * residues that reached the sketcher. stats_out (optional, 4 doubles): host seconds spent reading+decompressing+scanning (summed over
+ * threads), seconds the caller waited for PCIe copies, seconds in device pack + sketch, wall seconds of the call.
+ */
+int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
+                    void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out)
+{
+    int rc = gs_check_params(p);
+    if (rc) return rc;
+    GS_REQUIRE(c && (n_files == 0 || (paths && sig_out)), GS_ERR_INVALID, "null argument");
+    if (n_files == 0) return GS_OK;
+    GS_CTX_LOCK(c);
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    const auto t_call = std::chrono::steady_clock::now();
+    const bool aa = p->data_t == GS_DATA_AA;
+    if (pio == 0) pio = 64;
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t n_groups = (n_files + pio - 1) / pio;
+    const size_t esz = gs_sig_elem_bytes(p), m = p->sketch_size;
+    std::vector<std::vector<gs::FileBlob>> blobs(n_groups);
+    std::vector<std::future<void>> pending(n_groups);
+    // host stage of a group: its files are spread over n_threads threads (files.rs:327 par_iter over the group)
+    auto start_group = [&](uint64_t g) {
+        const uint64_t f0 = g * pio, f1 = std::min<uint64_t>(n_files, f0 + pio);
+        blobs[g].resize(f1 - f0);
+        pending[g] = std::async(std::launch::async, [&, g, f0, f1]() {
+            std::atomic<uint64_t> next{f0};
+            std::vector<std::thread> th;
+            const uint32_t nt = (uint32_t)std::min<uint64_t>(n_threads, f1 - f0);
+            for (uint32_t t = 0; t < nt; t++) th.emplace_back([&]() { for (;;) { const uint64_t f = next.fetch_add(1); if (f >= f1) break; gs::host_stage(paths[f], &blobs[g][f - f0]); } });
+            for (auto &x : th) x.join();
+        });
+    };
+    hipStream_t copy_stream = nullptr;
+    GS_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void *pinned[2] = {nullptr, nullptr}; size_t pinned_cap[2] = {0, 0};
+    gs::DevBuf dtext[2], dout, drs, drl, dgo, dsig;
+    double read_s = 0, copy_wait_s = 0, dev_s = 0;
+    struct Staged { uint64_t bytes = 0; std::vector<uint64_t> sb, se, frec; } staged[2];
+    auto cleanup = [&]() {
+        for (auto &f : pending) if (f.valid()) f.wait();
+        for (int i = 0; i < 2; i++) { if (pinned[i]) (void)hipHostFree(pinned[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    };
+#define GS_FILES_FAIL(code) do { const int rc_ = (code); cleanup(); return rc_; } while (0)
+    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { gs::set_error("hipEventCreate failed"); GS_FILES_FAIL(GS_ERR_HIP); }
+    start_group(0);
+    if (n_groups > 1) start_group(1);
+    // stage group g: wait for its host tasks, lay the texts of its files end to end in pinned memory, start the H2D copy
+    auto stage = [&](uint64_t g) -> int {
+        pending[g].wait();
+        const int b = (int)(g & 1);
+        Staged &S = staged[b];
+        S.sb.clear(); S.se.clear(); S.frec.assign(1, 0);
+        uint64_t total = 0;
+        for (auto &fb : blobs[g]) {
+            if (fb.rc) { gs::set_error("%s", fb.err.c_str()); return fb.rc; }
+            read_s += fb.read_s;
+            for (size_t r = 0; r < fb.sb.size(); r++) { S.sb.push_back(total + fb.sb[r]); S.se.push_back(total + fb.se[r]); }
+            S.frec.push_back(S.sb.size());
+            total += fb.text.size();
+        }
+        S.bytes = total;
+        if (total + 64 > pinned_cap[b]) {
+            if (pinned[b]) GS_HIP_CHECK(hipHostFree(pinned[b]));
+            pinned[b] = nullptr; pinned_cap[b] = (total + 64) * 5 / 4;
+            GS_HIP_CHECK(hipHostMalloc(&pinned[b], pinned_cap[b], hipHostMallocDefault));
+        }
+        {   // lay the files end to end in the pinned buffer: a team of threads copies (one thread moves ~8 GB/s, a group is 100s of MB)
+            std::vector<uint64_t> offs(blobs[g].size());
+            uint64_t off = 0;
+            for (size_t f = 0; f < blobs[g].size(); f++) { offs[f] = off; off += blobs[g][f].text.size(); }
+            std::atomic<size_t> next{0};
+            auto copier = [&]() { for (;;) { const size_t f = next.fetch_add(1); if (f >= blobs[g].size()) break; auto &fb = blobs[g][f];
+                                             if (!fb.text.empty()) memcpy((uint8_t *)pinned[b] + offs[f], fb.text.data(), fb.text.size()); fb.text.release(); } };
+            std::vector<std::thread> team;
+            const uint32_t nt = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(n_threads, 32), blobs[g].size());
+            for (uint32_t t = 1; t < nt; t++) team.emplace_back(copier);
+            copier();
+            for (auto &x : team) x.join();
+        }
+        int rc2;
+        if ((rc2 = dtext[b].ensure(total + 64))) return rc2;
+        if (total) GS_HIP_CHECK(hipMemcpyAsync(dtext[b].p, pinned[b], total, hipMemcpyHostToDevice, copy_stream));
+        GS_HIP_CHECK(hipEventRecord(ev[b], copy_stream));
+        return GS_OK;
+    };
+    // device stage of group g (its text is, or soon will be, in dtext[g & 1])
+    auto device_stage = [&](uint64_t g) -> int {
+        const int b = (int)(g & 1);
+        Staged &S = staged[b];
+        const uint64_t nf = blobs[g].size(), f0 = g * pio, nrec = S.sb.size();
+        auto t0 = std::chrono::steady_clock::now();
+        GS_HIP_CHECK(hipEventSynchronize(ev[b]));
+        copy_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        t0 = std::chrono::steady_clock::now();
+        int rc2;
+        const size_t out_bytes = (aa ? S.bytes : S.bytes / 4) + 8 * (nrec + nf) + 128;
+        if ((rc2 = dout.ensure(out_bytes))) return rc2;
+        GS_HIP_CHECK(hipMemsetAsync(dout.p, 0, out_bytes, c->stream));
+        std::vector<uint64_t> rs(std::max<uint64_t>(nrec, 1)), rl(std::max<uint64_t>(nrec, 1)), goff(nf + 1), rs2, rl2;
+        if (!block_mode) {
+            if ((rc2 = gs::ingest_records_dev(c, aa, false, dtext[b].p, S.bytes, S.sb.data(), S.se.data(), nrec, dout.p, 0, rs.data(), rl.data(), nullptr))) return rc2;
+            for (uint64_t f = 0; f <= nf; f++) goff[f] = S.frec[f];
+            rs2.assign(rs.begin(), rs.begin() + nrec); rl2.assign(rl.begin(), rl.begin() + nrec);
+        } else {   // one record per file: its records concatenated without gaps
+            uint64_t pos = 0;
+            for (uint64_t f = 0; f < nf; f++) {
+                const uint64_t r0 = S.frec[f], r1 = S.frec[f + 1];
+                if (!aa) pos = (pos + 31) / 32 * 32;
+                uint64_t end = pos;
+                if (r1 > r0 && (rc2 = gs::ingest_records_dev(c, aa, true, dtext[b].p, S.bytes, S.sb.data() + r0, S.se.data() + r0, r1 - r0, dout.p, pos, rs.data() + r0, rl.data() + r0, &end))) return rc2;
+                rs2.push_back(pos); rl2.push_back(end - pos); goff[f] = f;
+                pos = end;
+            }
+            goff[nf] = nf;
+        }
+        const uint64_t nr2 = rs2.size();
+        if ((rc2 = drs.ensure(8 * (nr2 + 1))) || (rc2 = drl.ensure(8 * (nr2 + 1))) || (rc2 = dgo.ensure(8 * (nf + 1))) || (rc2 = dsig.ensure(nf * m * esz))) return rc2;
+        if (nr2) {
+            GS_HIP_CHECK(hipMemcpyAsync(drs.p, rs2.data(), 8 * nr2, hipMemcpyHostToDevice, c->stream));
+            GS_HIP_CHECK(hipMemcpyAsync(drl.p, rl2.data(), 8 * nr2, hipMemcpyHostToDevice, c->stream));
+        }
+        GS_HIP_CHECK(hipMemcpyAsync(dgo.p, goff.data(), 8 * (nf + 1), hipMemcpyHostToDevice, c->stream));
+        if ((rc2 = gs_sketch_batch_dev(c, p, dout.p, out_bytes / 8 * 8, drs.as<uint64_t>(), drl.as<uint64_t>(), nr2, dgo.as<uint64_t>(), nf, dsig.p))) return rc2;
+        GS_HIP_CHECK(hipMemcpyAsync((uint8_t *)sig_out + f0 * m * esz, dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (uint64_t f = 0; f < nf; f++) {
+            uint64_t sym = 0;
+            if (!block_mode) for (uint64_t r = S.frec[f]; r < S.frec[f + 1]; r++) sym += rl[r]; else sym = rl2[f];
+            if (n_records_out) n_records_out[f0 + f] = S.frec[f + 1] - S.frec[f];
+            if (n_symbols_out) n_symbols_out[f0 + f] = sym;
+        }
+        dev_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return GS_OK;
+    };
+    for (uint64_t g = 0; g < n_groups; g++) {
+        if ((rc = stage(g))) GS_FILES_FAIL(rc);                    // H2D of group g starts ...
+        if (g + 2 < n_groups) start_group(g + 2);                  // ... the host threads move on to group g+2 ...
+        if (g >= 1 && (rc = device_stage(g - 1))) GS_FILES_FAIL(rc);   // ... while the device packs and sketches group g-1
+    }
+    if ((rc = device_stage(n_groups - 1))) GS_FILES_FAIL(rc);
+    cleanup();
+#undef GS_FILES_FAIL
+    if (stats_out) {
+        stats_out[0] = read_s; stats_out[1] = copy_wait_s; stats_out[2] = dev_s;
+        stats_out[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
+    }
+    return GS_OK;
+}
+
+}  // extern "C"

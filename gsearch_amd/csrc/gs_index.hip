@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <sys/stat.h>
 #include "gs_internal.hpp"
 #include "gs_spec.hpp"
 
@@ -1505,6 +1506,9 @@ int gs_index_create(gs_ctx *c, const gs_index_params *p, gs_index **out)
     GS_REQUIRE(p->max_nb_conn >= 2 && p->max_nb_conn <= 255, GS_ERR_INVALID, "max_nb_conn must be in 2..255 (gsearch.rs:268)");
     GS_REQUIRE(p->max_layer >= 1 && p->max_layer <= 16, GS_ERR_INVALID, "max_layer must be in 1..16");
     GS_REQUIRE(p->ef_construction >= 1, GS_ERR_INVALID, "ef_construction must be positive");
+    GS_REQUIRE(!p->extend_candidates || p->ef_construction > 2 * p->max_nb_conn, GS_ERR_UNSUPPORTED,
+               "extend_candidates with ef_construction (%u) <= 2*max_nb_conn (%u) is not implemented on the device: raise --ef above %u (gsearch's defaults do)",
+               p->ef_construction, 2 * p->max_nb_conn, 2 * p->max_nb_conn);
     gs_index *ix = new gs_index();
     ix->ctx = c; ix->prm = *p;
     if (ix->prm.insert_batch == 0) ix->prm.insert_batch = 64;
@@ -1569,6 +1573,17 @@ int gs_index_import(gs_index *ix, const void *sigs, uint64_t n, const uint8_t *l
         GS_REQUIRE(deg0[i] <= 2 * M, GS_ERR_INVALID, "degree of node %llu out of range", (unsigned long long)i);
         for (uint32_t t = 0; t < deg0[i]; t++) GS_REQUIRE(nbr0[i * 2 * M + t] < n, GS_ERR_INVALID, "neighbour id out of range");
         GS_REQUIRE((levels[i] > 0) == (upidx[i] >= 0), GS_ERR_INVALID, "upidx inconsistent with level at node %llu", (unsigned long long)i);
+        if (upidx[i] >= 0) {
+            GS_REQUIRE((uint64_t)upidx[i] < n_upper, GS_ERR_INVALID, "upidx of node %llu out of range", (unsigned long long)i);
+            for (uint32_t l = 1; l <= levels[i]; l++) {
+                const uint64_t o = (uint64_t)upidx[i] * ML + (l - 1);
+                GS_REQUIRE(degU[o] <= M, GS_ERR_INVALID, "degree of node %llu at layer %u out of range", (unsigned long long)i, l);
+                for (uint32_t t = 0; t < degU[o]; t++) {
+                    const uint32_t e = nbrU[o * M + t];
+                    GS_REQUIRE(e < n && levels[e] >= l, GS_ERR_INVALID, "node %llu links to %u at layer %u, which does not reach that layer", (unsigned long long)i, e, l);
+                }
+            }
+        }
         if (levels[i] > top) top = levels[i];
     }
     GS_REQUIRE(levels[entry] == top, GS_ERR_INVALID, "entry point is not on the top layer");
@@ -1738,7 +1753,18 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     const bool cnt16 = ix->prm.m <= 65535;
     if (ix->pair_cache_budget == 0) {
         const char *e = getenv("GS_PAIR_CACHE_GB");
-        ix->pair_cache_budget = e ? (uint64_t)(atof(e) * 1e9) : (uint64_t)(0.55 * (double)c->hbm_bytes);
+        if (e) ix->pair_cache_budget = (uint64_t)(atof(e) * 1e9);
+        else {
+            // default: 55 % of the device, but never more than what is FREE now minus what this index still has to allocate next to it
+            // (column store, count matrix, query scratch): other indexes and processes may hold memory already
+            size_t fr = 0, tot = 0;
+            uint64_t budget = (uint64_t)(0.55 * (double)c->hbm_bytes);
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+                const uint64_t reserve = (uint64_t)ix->prm.m * ix->cap * ix->esz + ((uint64_t)8 << 30);
+                budget = std::min<uint64_t>(budget, fr > reserve ? (uint64_t)fr - reserve : 0);
+            }
+            ix->pair_cache_budget = std::max<uint64_t>(budget, 1);
+        }
     }
     const uint64_t slab_ld = gs::round_up(first + n, 8);
     gs::DevBuf *slab = nullptr; uint64_t slab_first = 0;      // rows of this call's points, allocated at the first dense batch
@@ -1914,13 +1940,24 @@ int gs_index_load(gs_ctx *c, const char *path, gs_index **out)
     FILE *f = fopen(path, "rb");
     GS_REQUIRE(f, GS_ERR_IO, "cannot open %s", path);
     char magic[8]; gs_index_params prm; uint64_t hdr[4];
+    memset(&prm, 0, sizeof prm);
     bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GSAMDIX1", 8) && fread(&prm, sizeof(prm), 1, f) == 1 && fread(hdr, 8, 4, f) == 4;
     if (!ok) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s is not a gsearch_amd index dump", path); }
     const uint64_t n = hdr[0], U = hdr[1];
     const uint32_t M = prm.max_nb_conn, ML = prm.max_layer;
+    // the header is untrusted: validate it like gs_index_create would, and against the file size, BEFORE sizing any allocation from it
+    struct stat st;
+    const bool sane = (prm.kind == GS_KIND_F32 || prm.kind == GS_KIND_U32 || prm.kind == GS_KIND_U64 || prm.kind == GS_KIND_U16) && prm.m >= 1 && M >= 2 && M <= 255 &&
+                      ML >= 1 && ML <= 16 && prm.ef_construction >= 1 && n >= 1 && n < ((uint64_t)1 << 31) && U <= n && fstat(fileno(f), &st) == 0;
+    if (!sane) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s: corrupt header", path); }
     const size_t rowbytes = gs::kind_bytes(prm.kind) * (size_t)prm.m;
-    std::vector<uint8_t> sigs(rowbytes * n), lv(n); std::vector<uint32_t> d0(n), n0(n * 2 * M), c0(n * 2 * M); std::vector<int32_t> up(n);
-    std::vector<uint32_t> dU(std::max<uint64_t>(U, 1) * ML), nU(std::max<uint64_t>(U, 1) * ML * M), cU(std::max<uint64_t>(U, 1) * ML * M);
+    const unsigned __int128 expect = (unsigned __int128)8 + sizeof(prm) + 32 + (unsigned __int128)n * (rowbytes + 1 + 4 + (size_t)16 * M + 4) + (unsigned __int128)U * ML * (4 + (size_t)8 * M);
+    if (expect != (unsigned __int128)(uint64_t)st.st_size) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s: size %llu does not match its header (truncated or corrupt)", path, (unsigned long long)st.st_size); }
+    std::vector<uint8_t> sigs, lv; std::vector<uint32_t> d0, n0, c0, dU, nU, cU; std::vector<int32_t> up;
+    try {
+        sigs.resize(rowbytes * n); lv.resize(n); d0.resize(n); n0.resize(n * 2 * M); c0.resize(n * 2 * M); up.resize(n);
+        dU.resize(std::max<uint64_t>(U, 1) * ML); nU.resize(std::max<uint64_t>(U, 1) * ML * M); cU.resize(std::max<uint64_t>(U, 1) * ML * M);
+    } catch (const std::exception &) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s: not enough host memory for %llu points", path, (unsigned long long)n); }
     ok = fread(sigs.data(), rowbytes, n, f) == n && fread(lv.data(), 1, n, f) == n && fread(d0.data(), 4, n, f) == n &&
          fread(n0.data(), 4, n * 2 * M, f) == n * 2 * M && fread(c0.data(), 4, n * 2 * M, f) == n * 2 * M && fread(up.data(), 4, n, f) == n &&
          fread(dU.data(), 4, U * ML, f) == U * ML && fread(nU.data(), 4, U * ML * M, f) == U * ML * M && fread(cU.data(), 4, U * ML * M, f) == U * ML * M;

@@ -116,13 +116,27 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
                     rc = (rc >> 2) | ((3 - c) << rcshift);
                 }
             }
+            // (rc never exceeds 2k bits and fwd is masked every step: the minimum needs no further mask.) When every lane of the wave
+            // holds an interior word - all 32 windows inside its record, the case for all but the first and last word of a record - the
+            // per-window bounds test (two 64-bit compares, an exec save / restore and a branch per k-mer) is dropped for the whole word.
+            const bool interior = a0 >= first_valid && a0 + 32 <= re;
+            if (__ballot(interior) == __ballot(true)) {
 #pragma unroll 2
-            for (uint32_t j = 0; j < 32; j++) {
-                uint64_t c = w >> 62; w <<= 2;
-                fwd = ((fwd << 2) | c) & mask;
-                rc = (rc >> 2) | ((3 - c) << rcshift);
-                uint64_t a = a0 + j;
-                if (a >= first_valid && a < re) emit((fwd < rc ? fwd : rc) & mask, lo, a);
+                for (uint32_t j = 0; j < 32; j++) {
+                    uint64_t c = w >> 62; w <<= 2;
+                    fwd = ((fwd << 2) | c) & mask;
+                    rc = (rc >> 2) | ((3 - c) << rcshift);
+                    emit(fwd < rc ? fwd : rc, lo, a0 + j);
+                }
+            } else {
+#pragma unroll 2
+                for (uint32_t j = 0; j < 32; j++) {
+                    uint64_t c = w >> 62; w <<= 2;
+                    fwd = ((fwd << 2) | c) & mask;
+                    rc = (rc >> 2) | ((3 - c) << rcshift);
+                    uint64_t a = a0 + j;
+                    if (a >= first_valid && a < re) emit(fwd < rc ? fwd : rc, lo, a);
+                }
             }
         } else {
             const uint64_t *w64 = (const uint64_t *)seq;

@@ -94,8 +94,15 @@ GS_HD void two_draw(uint64_t h, uint32_t m, uint64_t zone, uint64_t &o1, uint32_
     uint64_t n3 = s3 ^ s1;           // s3 after the first step, before rotation
     uint64_t n0 = s0 ^ n3;           // s0 after the first step
     uint64_t o2 = rotl64(n0 + rotl64(n3, 45), 23) + n0;
-    uint64_t lo = o2 * (uint64_t)m;
-    if (__builtin_expect(lo <= zone, 1)) { bin = (uint32_t)mulhi64(o2, (uint64_t)m); return; }
+    // Uint(g, m) with m < 2^32: the 96-bit product o2 * m from two 32 x 32 -> 64 multiply-adds. Its top 32 bits are the draw, its low 64
+    // bits the rejection test `lo <= zone` - and zone >= 2^64 - 2^32, so a rejection needs the upper half of lo to be all ones: one
+    // 32-bit compare on the hot path, the exact 64-bit test (and the re-run of the full generator) only behind it.
+    const uint64_t t = (uint64_t)(uint32_t)o2 * m;
+    const uint64_t u = (uint64_t)(uint32_t)(o2 >> 32) * m + (t >> 32);
+    bin = (uint32_t)(u >> 32);
+    if (__builtin_expect((uint32_t)u != 0xFFFFFFFFu, 1)) return;
+    const uint64_t lo = (u << 32) | (uint32_t)t;
+    if (lo <= zone) return;
     Rng g; g.seed(h); (void)g.next64();
     bin = (uint32_t)rng_uint(g, (uint64_t)m, zone);
 }

@@ -107,6 +107,28 @@ int gs_fasta_scan(const char *buf, uint64_t n, int skip_capsid, uint64_t cap, ui
  * packed_dev: ZEROED device buffer >= n_bytes/4 + 8*n_rec + 64 bytes; rec_start_out/rec_len_out: HOST, ready for gs_sketch_batch_dev. */
 int gs_pack_fasta_dev(gs_ctx *, const void *text_dev, uint64_t n_bytes, const uint64_t *seq_begin, const uint64_t *seq_end,
                       uint64_t n_rec, void *packed_dev, uint64_t *rec_start_out, uint64_t *rec_len_out);
+/* amino acids: drop everything outside the 20-letter alphabet (filter_out_non_aa, src/aa/aafiles.rs:11-28; newlines of the raw text go
+ * with it) from the text of n_rec records. out_dev: >= n_bytes bytes; rec_start_out / rec_len_out: HOST, residue coordinates. */
+int gs_filter_aa_dev(gs_ctx *, const void *text_dev, uint64_t n_bytes, const uint64_t *seq_begin, const uint64_t *seq_end,
+                     uint64_t n_rec, void *out_dev, uint64_t *rec_start_out, uint64_t *rec_len_out);
+/* ---- files: the reader side of sketchandstore_dir_compressedkmer, src/dna/dnasketch.rs:240-300 ---- */
+/* src/utils/files.rs:117-146: 1 when the name carries a FASTA suffix gsearch accepts for data_t (fna fa fasta / faa, also .gz .xz .bz2) */
+int  gs_is_fasta_file(const char *path, int data_t);
+/* whole file in memory, gzip (multi-member) / bzip2 / xz decompressed by magic bytes like needletail (files.rs:220-250); release the
+ * malloc-ed *text_out with gs_host_free */
+int  gs_read_fasta_file(const char *path, void **text_out, uint64_t *n_out);
+void gs_host_free(void *);
+/* files.rs:148-215,345-455: accepted files under dir, recursively, name order. paths_buf NULL to size (*n_out files, *bytes_out bytes),
+ * then a buffer that receives the NUL-terminated paths back to back */
+int  gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t cap_bytes, uint64_t *n_out, uint64_t *bytes_out);
+/* One signature per file, input order. Groups of `pio` files (--pio, files.rs:258-341; 0 -> 64) are read + decompressed + scanned by
+ * n_threads host threads (0 -> all) while the previous group crosses PCIe from pinned memory on a copy stream and the one before is
+ * filtered / 2-bit packed / sketched on the context's stream. block_mode 0: k-mers never span records (process_file_by_sequence,
+ * dnafiles.rs:43-107); 1: --block, records concatenated (process_file_in_one_block, dnafiles.rs:200-262); `capsid` records skipped.
+ * sig_out: HOST n_files x sketch_size. Optional per-file n_records_out / n_symbols_out (HOST) and stats_out[4] = {host read+decode+scan
+ * seconds summed over threads, seconds waited for PCIe, seconds in device pack + sketch, wall seconds}. */
+int  gs_sketch_files(gs_ctx *, const gs_sketch_params *, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio,
+                     uint32_t n_threads, void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out);
 /* ASCII helpers for hosts that do not pack themselves (Sequence::encode_and_add, dnafiles.rs:70-71) */
 uint64_t gs_pack_dna(const uint8_t *ascii, uint64_t n, uint8_t *packed_zeroed, uint64_t base_off);
 uint64_t gs_filter_aa(const uint8_t *ascii, uint64_t n, uint8_t *out);
@@ -173,6 +195,12 @@ int      gs_index_export(gs_index *, uint8_t *levels, int64_t *entry, uint32_t *
 int      gs_index_get_data(gs_index *, uint64_t first, uint64_t n, void *sigs_out);
 int      gs_index_save(gs_index *, const char *path);
 int      gs_index_load(gs_ctx *, const char *path, gs_index **out);
+/* hnsw_rs' own dump (Hnsw::file_dump / HnswIo::load_hnsw: dumpload.rs:26-31, reloadhnsw.rs:13-51): <basename>.hnsw.graph and
+ * <basename>.hnsw.data, format 3. The byte layout is restated from the un-vendored crate as recalled (gs_hnswio.hip header lists every
+ * recalled constant). dump needs max_layer = 16 and lists of at most 255 neighbours; load takes capacity / scale_modify / flags / seed /
+ * insert_batch for later insertions from `hint` (may be NULL) - the dump itself holds only max_nb_connection, ef and the element type. */
+int      gs_index_dump_hnswrs(gs_index *, const char *basename);
+int      gs_index_load_hnswrs(gs_ctx *, const char *basename, const gs_index_params *hint, gs_index **out);
 uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluations spent by inserts so far */
 /* device-side work counters of the searches and dense-mode inserts since the last reset (bench.py prices kernels with them):
  * out[0] memory-side atomics sent by the match-join, out[1] candidates popped by the dense traversal, out[2] pops that accepted

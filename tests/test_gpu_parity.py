@@ -296,6 +296,13 @@ def test_index_dump_and_reload(gpu_ctx, tmp_path):
     h2.parallel_insert(db[200:])
     a, b = hn.search_arrays(q, 5, 40), h2.search_arrays(q, 5, 40)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # a truncated or corrupt dump is refused with an error code (never an exception across the C ABI)
+    raw = path.read_bytes()
+    for bad in (raw[:len(raw) // 2], raw[:40], raw[:8] + b"\xff" * 80 + raw[88:], b"GSAMDIX1"):
+        (tmp_path / "bad.gsamd").write_bytes(bad)
+        with pytest.raises(G.GsError) as e:
+            G.Hnsw.load(tmp_path / "bad.gsamd")
+        assert e.value.code == -5
 
 
 def test_cpp_host_mirror(gpu_ctx, tmp_path):
@@ -445,8 +452,11 @@ def test_edge_cases_and_error_behaviour(gpu_ctx):
     with pytest.raises(G.GsError) as e:
         hn.search_arrays(db[:1], 5, 200000)
     assert e.value.code == -3
-    h2 = G.Hnsw.new(8, 1000, 16, 8, dh)                                         # efc <= 2M with extend_candidates: refused, not approximated
-    h2.set_extend_candidates(True)
+    h2 = G.Hnsw.new(8, 1000, 16, 8, dh)                                         # efc <= 2M with extend_candidates: refused up front, not approximated
+    with pytest.raises(G.GsError) as e:
+        h2.set_extend_candidates(True)
+    assert e.value.code == -3
+    h2.prm.extend_candidates = 1                                                # a host that bypasses the setter meets the same refusal in gs_index_create
     with pytest.raises(G.GsError) as e:
         h2.parallel_insert(db)
     assert e.value.code == -3
@@ -848,3 +858,151 @@ def test_comm_allgather_single_rank(gpu_ctx):
         for p_ in (d_i, d_d, d_ai, d_ad):
             ctx.free(p_)
         comm.close()
+
+
+@pytest.mark.parametrize("block", [False, True])
+def test_sketch_files_pipeline_matches_oracle(gpu_ctx, tmp_path, block):
+    """f2 end to end: FASTA files on disk (plain, gz, bz2, xz; multi-record, CRLF, lower case, N runs, a `capsid` record, an empty
+    file) -> host threads read / decode / scan -> pinned double-buffered H2D -> device filter + 2-bit pack -> sketch, in groups of 3
+    files, against the oracle fed with the same records; --block concatenates the records of a file (k-mers span the joins)"""
+    import bz2, gzip, lzma
+    import gsearch_amd as G
+    rng = np.random.default_rng(2025)
+
+    def fasta(records, width, nl=b"\n"):
+        out = []
+        for name, s in records:
+            out.append(b">" + name + nl)
+            out += [s[o:o + width] + nl for o in range(0, len(s), width)]
+        return b"".join(out)
+
+    gs_ = [H.dna_ascii(H.rand_dna(rng, n)) for n in (60000, 45000, 30011, 52000, 70000, 41000, 38000)]
+    files = [
+        ("a.fna", fasta([(b"chr1 first", gs_[0][:25000] + b"NNNNNRYK" + gs_[0][25000:40000].lower()), (b"p1 phage capsid protein", gs_[0][40000:41000]), (b"chr2", gs_[0][41000:])], 60)),
+        ("b.fna.gz", gzip.compress(fasta([(b"c%d" % i, gs_[1][i * 4000:(i + 1) * 4000 + 9]) for i in range(11)], 80))),
+        ("c.fa.bz2", bz2.compress(fasta([(b"single", gs_[2])], 70, b"\r\n"))),
+        ("d.fasta.xz", lzma.compress(fasta([(b"x", gs_[3][:26000]), (b"tiny", b"ACG"), (b"y", gs_[3][26000:])], 100))),
+        ("e.fna", b""),
+        ("f.fna", fasta([(b"only", gs_[4])], 61)),
+        ("g.fa.gz", gzip.compress(fasta([(b"g1", gs_[5])], 60)[:20000]) + gzip.compress(fasta([(b"g1", gs_[5])], 60)[20000:])),
+        ("h.fasta", fasta([(b"h", gs_[6])], 75)),
+    ]
+    paths = []
+    for name, data in files:
+        (tmp_path / name).write_bytes(data)
+        paths.append(tmp_path / name)
+    sk = G.OptDensHashSketch.new(G.SeqSketcherParams(21, 1500, "optdens"))
+    sig, nrec, nsym, st = sk.sketch_files(paths, block=block, pio=3, threads=4)
+    # oracle on the same records
+    genomes = []
+    for p_ in paths:
+        text = G.read_fasta_file(p_)
+        recs = [text[b:e] for _, b, e in G.fasta_scan(text)]
+        genomes.append([b"".join(recs)] if block else recs)
+    assert list(nrec) == [2, 11, 1, 3, 0, 1, 1, 1]
+    ref = _oracle_sketch(21, 1500, "optdens", genomes)
+    assert np.array_equal(sig.view(np.uint32), ref.view(np.uint32))
+    orecs = [r for g in genomes for r in g]
+    _, _, orl = O.pack_dna(orecs)
+    goff = np.cumsum([0] + [len(g) for g in genomes])
+    assert [int(orl[goff[i]:goff[i + 1]].sum()) for i in range(len(genomes))] == [int(x) for x in nsym]
+    assert (sig[4] == 1.0).all() and st["wall_s"] > 0
+
+
+def test_sketch_files_amino_acids(gpu_ctx, tmp_path):
+    """.faa files: the AA alphabet filter (filter_out_non_aa, aafiles.rs:11-28) runs on the device"""
+    import gzip
+    import gsearch_amd as G
+    rng = np.random.default_rng(77)
+    prot = [H.aa_ascii(rng.integers(0, 20, n)) for n in (40000, 35000, 28000)]
+    texts = [b">p1 some protein\n" + prot[0][:15000] + b"*XBZ\n" + prot[0][15000:].lower() + b"\n>p2 capsid\nMKV\n>p3\n" + prot[1][:5000] + b"\n",
+             b"".join(b">q%d\n%s*\n" % (i, prot[1][i * 700:(i + 1) * 700]) for i in range(40)),
+             b">r\n" + b"\n".join(prot[2][o:o + 60] for o in range(0, len(prot[2]), 60)) + b"\n"]
+    paths = [tmp_path / "a.faa", tmp_path / "b.faa.gz", tmp_path / "c.faa"]
+    paths[0].write_bytes(texts[0]); paths[1].write_bytes(gzip.compress(texts[1])); paths[2].write_bytes(texts[2])
+    for algo in ("super2", "optdens"):
+        sk = G.sketcher_for(G.SeqSketcherParams(7, 800, algo, "aa"))
+        sig, nrec, nsym, _ = sk.sketch_files(paths, pio=2)
+        genomes = [[t[b:e] for _, b, e in G.fasta_scan(t)] for t in texts]
+        ref = _oracle_sketch(7, 800, algo, genomes, "aa")
+        assert np.array_equal(_bits(sig), _bits(ref)), algo
+    assert list(nrec) == [2, 40, 1]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint64, np.uint16])
+def test_hnswrs_dump_round_trip(gpu_ctx, tmp_path, dtype):
+    """f3: the database files gsearch keeps - hnswdump.hnsw.graph / hnswdump.hnsw.data in hnsw_rs' format 3 (layout recalled from the
+    crate, gs_hnswio.hip) - written and read back: same graph, same vectors, same answers, and insertions continue (the `add` path)"""
+    import gsearch_amd as G
+    m = 150
+    db = H.synth_sig_db(15, 30, m, 71, dtype=dtype, jlo=0.05, jhi=0.9)
+    hn = G.Hnsw.new(12, 1_500_000, 16, 48, G.DistHamming(), dtype=dtype, seed=5, insert_batch=32)
+    hn.modify_level_scale(1.0); hn.set_extend_candidates(True)
+    hn.parallel_insert(db[:400])
+    base = tmp_path / "hnswdump"
+    hn.file_dump_hnswrs(base)
+    assert (tmp_path / "hnswdump.hnsw.graph").exists() and (tmp_path / "hnswdump.hnsw.data").exists()
+    # the description is readable the way reloadhnsw.rs:13-38 reads it: magic, dump mode, M, 16 layers, ef, nb_point, dimension, names
+    import struct
+    raw = (tmp_path / "hnswdump.hnsw.graph").read_bytes()
+    magic, mode, M8, nbl, ef, npnt, dim, ln = struct.unpack_from("<IBBBQQQQ", raw, 0)
+    assert (magic, mode, M8, nbl, ef, npnt, dim) == (0x002A6771, 1, 12, 16, 48, 400, m)
+    o = struct.calcsize("<IBBBQQQQ")
+    assert raw[o:o + ln].endswith(b"DistHamming")
+    ln2, = struct.unpack_from("<Q", raw, o + ln)
+    assert raw[o + ln + 8:o + ln + 8 + ln2].decode() == {np.float32: "f32", np.uint64: "u64", np.uint16: "u16"}[dtype]
+    h2 = G.Hnsw.load_hnswrs(base, hint=hn)
+    assert h2.get_nb_point() == 400 and h2.dtype == np.dtype(dtype)
+    g1, g2 = hn.export_graph(), h2.export_graph()
+    assert g1["entry"] == g2["entry"] and g1["n_upper"] == g2["n_upper"] and g1["n_upper"] > 0
+    for key in ("levels", "deg0"):
+        assert np.array_equal(g1[key], g2[key]), key
+    for i in range(400):
+        d = int(g1["deg0"][i])
+        assert np.array_equal(g1["nbr0"][i, :d], g2["nbr0"][i, :d]) and np.array_equal(g1["cnt0"][i, :d], g2["cnt0"][i, :d])
+    assert np.array_equal(hn.get_data(), h2.get_data())
+    q = H.queries_from(db, 30, 3, frac=0.2)
+    a, b = hn.search_arrays(q, 8, 60), h2.search_arrays(q, 8, 60)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    hn.parallel_insert(db[400:]); h2.parallel_insert(db[400:])
+    a, b = hn.search_arrays(q, 8, 60), h2.search_arrays(q, 8, 60)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(G.GsError):
+        G.Hnsw.load_hnswrs(tmp_path / "missing")
+
+
+def test_hnswrs_dump_assembled_by_hand(gpu_ctx, tmp_path):
+    """a three-point dump written byte by byte from the documented layout (not by this library's writer) loads and searches"""
+    import struct
+    import gsearch_amd as G
+    m = 4
+    vec = np.array([[1, 2, 3, 4], [1, 2, 3, 9], [7, 7, 7, 7]], np.float32)
+    cnt = lambda a, b: int((vec[a] != vec[b]).sum())           # noqa: E731
+    MAGD, MAGP, MAGL, MAGV = 0x002A6771, 0x000A678F, 0x000A676F, 0xA67F0000
+    name = b"anndists::dist::distances::DistHamming"
+    g = struct.pack("<IBBBQQQ", MAGD, 1, 4, 16, 10, 3, m) + struct.pack("<Q", len(name)) + name + struct.pack("<Q", 3) + b"f32" + struct.pack("<B", 16)
+    # layer 0 holds points 0 and 2 (ranks 0, 1), layer 1 holds point 1 (rank 0) - the entry point
+    pid = {0: (0, 0), 2: (0, 1), 1: (1, 0)}
+
+    def point(i, lists):
+        out = struct.pack("<IQBi", MAGP, i, pid[i][0], pid[i][1])
+        for l in range(16):
+            nb = lists.get(l, [])
+            out += struct.pack("<B", len(nb))
+            for j in nb:
+                out += struct.pack("<QBif", j, pid[j][0], pid[j][1], cnt(i, j) / m)
+        return out
+    g += struct.pack("<IQ", MAGL, 2) + point(0, {0: [1, 2]}) + point(2, {0: [0, 1]})
+    g += struct.pack("<IQ", MAGL, 1) + point(1, {0: [0, 2], 1: []})
+    for _ in range(14):
+        g += struct.pack("<IQ", MAGL, 0)
+    g += struct.pack("<QBi", 1, 1, 0)
+    d = struct.pack("<IQ", MAGV, m)
+    for i in (0, 2, 1):
+        d += struct.pack("<IQQ", MAGV, i, 4 * m) + vec[i].tobytes()
+    (tmp_path / "hnswdump.hnsw.graph").write_bytes(g)
+    (tmp_path / "hnswdump.hnsw.data").write_bytes(d)
+    hn = G.Hnsw.load_hnswrs(tmp_path / "hnswdump")
+    assert hn.get_nb_point() == 3 and np.array_equal(hn.get_data(), vec)
+    ids, dist, cnt_, _ = hn.search_arrays(np.array([[1, 2, 3, 4]], np.float32), 3, 10)
+    assert ids[0].tolist() == [0, 1, 2] and dist[0].tolist() == [0.0, 0.25, 1.0] and cnt_[0] == 3

@@ -31,3 +31,26 @@ def test_processing_state_and_seqdict_roundtrip(tmp_path):
     assert text.startswith('{"id":{"path":"/db/GCF_000001.fna.gz","fasta_id":"NZ_CP0001.1"},"len":4379993}{"id":')   # back to back, no separator
     r = S.SeqDict.reload_json(fn)
     assert r.items == d.items and r.get_nb_entries() == 2 and r[0][2] == 4379993
+
+
+def test_floats_are_written_like_ryu():
+    """serde_json prints floats through ryu: no '+', no zero padding in exponents, decimal notation inside [1e-5, 1e16) for f64 and
+    [1e-6, 1e13) for f32, shortest round-trip digits of the TYPE (elapsed_t is an f32 upstream, files.rs:29)"""
+    R = S._ryu
+    assert [R(x) for x in (0.25, 1.0, 7200.0, 1e-5, 1e-6, 1.5e-7, 1e16, 1e15, 123456789012345680.0, 0.1 + 0.2, -2.5, 0.0)] == \
+        ["0.25", "1.0", "7200.0", "0.00001", "1e-6", "1.5e-7", "1e16", "1000000000000000.0", "1.2345678901234568e17", "0.30000000000000004", "-2.5", "0.0"]
+    assert R(0.1, f32=True) == "0.1" and R(7200.5, f32=True) == "7200.5" and R(16777217.0, f32=True) == "16777216.0"
+    assert R(1e13, f32=True) == "1e13" and R(1e-6, f32=True) == "0.000001" and R(1e-7, f32=True) == "1e-7"
+    assert S.ProcessingState(3, 2, 0.1).to_json() == '{"nb_seq":3,"nb_file":2,"elapsed_t":0.1}'
+    assert S.ProcessingState(3, 2, 1234.5678).to_json() == '{"nb_seq":3,"nb_file":2,"elapsed_t":1234.5677}'          # f32(1234.5678) = 1234.5677...
+    p = S.ProcessingParams(S.HnswParams(1, 2, 3, 1e-5), 16, 100, "optdens")
+    assert '"scale_modification":0.00001}' in p.to_json()
+
+
+def test_non_ascii_paths_roundtrip_in_utf8(tmp_path):
+    d = S.SeqDict()
+    d.append("/données/génome_α.fna", "id β", 7)
+    fn = str(tmp_path / "seqdict.json")
+    d.dump(fn)
+    assert "génome_α".encode("utf-8") in open(fn, "rb").read()
+    assert S.SeqDict.reload_json(fn).items == d.items
