@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libgsearch_amd.so")
+SO_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsearch_amd.so")      # GS_LIB_PATH: A/B builds (tools/ only)
 
 GS_OK, GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_UNSUPPORTED, GS_ERR_STATE, GS_ERR_IO = 0, -1, -2, -3, -4, -5
 ALGO = {"prob": 0, "super": 1, "super2": 2, "hll": 3, "optdens": 4, "revoptdens": 5}

@@ -338,7 +338,7 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
 // ======================================================================================================
 constexpr int DT = 512;           // lanes per dense-mode workgroup (two halves of 256: maxdeg <= 256)
 constexpr int DWIN = 64;          // keys of C mirrored in LDS
-constexpr int DCN = 448;          // capacity of the LDS-resident candidate buffer N (>= 2M: an empty N takes a whole expansion; <= DT: one key per lane)
+constexpr int DCN = 432;          // capacity of the LDS-resident candidate buffer N (>= 2M: an empty N takes a whole expansion; <= DT: one key per lane)
 constexpr int TMAXI = 2;          // staged T keys per lane in a merge (knbn <= TMAXI*DT)
 constexpr int HB = 64;            // histogram bins per H1 block (8 groups of 8 bins)
 struct DenseLds { uint64_t *T, *A, *As, *W, *N; uint32_t *Hf, *H2, *H1, *P1, *vis, *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
@@ -347,7 +347,7 @@ __host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uin
 {
     const size_t nb = dense_nblocks(m);
     size_t histb = 4 * ((size_t)DCN + 8); if (histb < 4 * nb) histb = 4 * nb;                   // fold histogram, aliased by P1
-    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * DWIN + 8 * (size_t)DCN + 64 + 4 * nb * 4 /*H2*/ + 4 * nb /*H1*/ +
+    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * (DWIN + 4) + 8 * (size_t)(DCN + 4) + 64 + 4 * nb * 4 /*H2*/ + 4 * nb /*H1*/ +
            8 * (size_t)maxdeg /*Eid,Ecnt (aliased by As)*/ + histb + 4 * 48 + (vlds ? 4 * (size_t)((n + 31) / 32 + 1) : 4 * nb * (HB / 2));
 }
 __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
@@ -357,8 +357,8 @@ __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint3
     size_t histb = 4 * ((size_t)DCN + 8); if (histb < 4 * nb) histb = 4 * nb;
     S.T = (uint64_t *)base; base += 8 * (size_t)((knbn + 1) & ~1u);
     S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
-    S.W = (uint64_t *)base; base += 8 * DWIN;
-    S.N = (uint64_t *)base; base += 8 * (size_t)DCN;
+    S.W = (uint64_t *)base; base += 8 * (DWIN + 4);       // + 3 sentinels (~0) behind the last key, so the head reads need no bounds tests
+    S.N = (uint64_t *)base; base += 8 * (size_t)(DCN + 4);
     S.scal = (uint64_t *)base; base += 64;
     S.Eid = (uint32_t *)base; S.As = (uint64_t *)base; base += 4 * (size_t)maxdeg;     // As (compaction of accepted keys) reuses Eid/Ecnt, dead by then
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
@@ -476,8 +476,10 @@ __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, co
     return tot < keep ? tot : keep;
 }
 
-template <bool VLDS>
-__global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
+// a wave-uniform value the compiler cannot prove uniform (it came through LDS): pin it to an SGPR
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <bool VLDS, bool PROF, int OCC>
+__global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
                                                            uint32_t *__restrict__ scratch, uint32_t scratch_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
                                                            uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out, unsigned long long *__restrict__ prof,
@@ -487,16 +489,26 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t efs = ef > knbn ? ef : knbn;
     const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
-    unsigned long long st_pops = 0, st_acc = 0;                  // work counters (workgroup-uniform): pops / accepting pops of this workgroup
+    uint32_t st_pops = 0, st_acc = 0;                            // work counters (workgroup-uniform): pops / accepting pops of this workgroup (< 2^32)
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, ix.n, VLDS);
+    // adjacency row of a (wave-uniform) candidate: the node id is pinned to an SGPR so that the row base is scalar and the load takes a
+    // 32-bit lane offset instead of a 64-bit per-lane pointer
+#define GS_DROW(K)                                                                                                         \
+    do {                                                                                                                   \
+        const uint32_t rid_ = uni32(KID(K));                                                                               \
+        uint32_t ho_ = hl4;                                                                                                \
+        asm volatile("" : "+v"(ho_));               /* opaque lane offset: keeps the 64-bit row base scalar */            \
+        pdeg = ix.deg0[rid_];                                                                                              \
+        pid = hl < maxdeg ? *(const uint32_t *)((const uint8_t *)(ix.nbr0 + (uint64_t)rid_ * maxdeg) + ho_) : 0;          \
+    } while (0)
     // per-workgroup global scratch: the visited bitmap (VLDS = false) or the fine histogram bins (VLDS = true)
     uint32_t *vis = VLDS ? S.vis : scratch + (uint64_t)blockIdx.x * scratch_words;
     Hist3 hs; hs.Hf = VLDS ? scratch + (uint64_t)blockIdx.x * scratch_words : S.Hf; hs.H2 = S.H2; hs.H1 = S.H1;
     uint64_t *Cb[2] = {cbuf + (uint64_t)blockIdx.x * 2 * capC, cbuf + (uint64_t)blockIdx.x * 2 * capC + capC};
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t half = threadIdx.x >> 8, hl = threadIdx.x & 255;
+    const uint32_t half = threadIdx.x >> 8, hl = threadIdx.x & 255, hl4 = hl * 4;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) S.scal[1] = atomicAdd(counter, 1ull);
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         for (uint32_t w = threadIdx.x; w < hwords; w += DT) hs.Hf[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb * 4; w += DT) S.H2[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb; w += DT) S.H1[w] = 0;
-        uint64_t evals = 1;
+        uint32_t evals = 1;                                      // <= n + upper-layer hops
         uint32_t ep = (uint32_t)ix.entry, ep_cnt = matrow[ep];
         // greedy descent on the upper layers (hnsw_rs::search outer loop)
         for (int L = ix.top; L >= 1; L--) {
@@ -534,6 +546,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         uint32_t dmax = INF_CNT, tieT = 0;                       // worst count of a full R / #keys of R tied at it
         uint64_t Tmax = 0;                                       // T[knbn-1] once T is full
         __syncthreads();
+        if (threadIdx.x < 3) { S.W[threadIdx.x] = ~(uint64_t)0; S.N[1 + threadIdx.x] = ~(uint64_t)0; }
         if (threadIdx.x == 0) {
             S.T[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
             hist_add<VLDS>(hs, ep_cnt, 1);
@@ -556,18 +569,16 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             if (headG < nG && headG - wbase >= wn) {                 // refill the LDS window of G
                 __syncthreads();
                 wbase = headG; wn = nG - headG < (uint32_t)DWIN ? nG - headG : (uint32_t)DWIN;
-                if (threadIdx.x < wn) S.W[threadIdx.x] = Cb[cur][headG + threadIdx.x];
+                if (threadIdx.x < wn + 3) S.W[threadIdx.x] = threadIdx.x < wn ? Cb[cur][headG + threadIdx.x] : ~(uint64_t)0;
                 __syncthreads();
             }
             // heads of G (through its LDS window; beyond the window counts as unknown) and of N, read in one round: the candidate to
             // pop and the two that follow in the current order
             const uint32_t wo = headG - wbase;
-            const uint64_t g0 = headG < nG ? S.W[wo] : ~(uint64_t)0;
-            const uint64_t g1 = (headG + 1 < nG && wo + 1 < wn) ? S.W[wo + 1] : ~(uint64_t)0;
-            const uint64_t g2 = (headG + 2 < nG && wo + 2 < wn) ? S.W[wo + 2] : ~(uint64_t)0;
-            const uint64_t n0 = headN < nN ? S.N[headN] : ~(uint64_t)0;
-            const uint64_t n1 = headN + 1 < nN ? S.N[headN + 1] : ~(uint64_t)0;
-            const uint64_t n2 = headN + 2 < nN ? S.N[headN + 2] : ~(uint64_t)0;
+            // (both arrays end in three ~0 sentinels; behind a pruned N there may be dead keys instead - counts above dmax, which stop
+            // the search exactly like "no candidate" does)
+            const uint64_t g0 = S.W[wo], g1 = S.W[wo + 1], g2 = S.W[wo + 2];
+            const uint64_t n0 = S.N[headN], n1 = S.N[headN + 1], n2 = S.N[headN + 2];
             const uint64_t c = g0 < n0 ? g0 : n0;
             if (c == ~(uint64_t)0) break;
             const bool full = nR == efs;
@@ -575,12 +586,11 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             uint64_t c1, c2;
             if (g0 < n0) { headG++; c1 = g1 < n0 ? g1 : n0; c2 = g1 < n0 ? (g2 < n0 ? g2 : n0) : (g1 < n1 ? g1 : n1); }
             else { headN++; c1 = g0 < n1 ? g0 : n1; c2 = g0 < n1 ? (g1 < n1 ? g1 : n1) : (g0 < n2 ? g0 : n2); }
-            const long long p0 = prof ? clock64() : 0;
+            const long long p0 = PROF ? clock64() : 0;
             uint32_t id = 0, cntv = 0; bool unv = false;
             if (half == (it & 1)) {
                 if (pk != c) {
-                    pdeg = ix.deg0[KID(c)];
-                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(c) * maxdeg + hl] : 0;
+                    GS_DROW(c);
                     pst = 1;
                 }
                 id = pid;
@@ -594,14 +604,12 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 }
                 pk = c2; pst = 1;
                 if (c2 != ~(uint64_t)0) {
-                    pdeg = ix.deg0[KID(c2)];
-                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(c2) * maxdeg + hl] : 0;
+                    GS_DROW(c2);
                 }
             } else if (c1 != ~(uint64_t)0) {
                 if (pk != c1) {
                     pk = c1; pst = 1;
-                    pdeg = ix.deg0[KID(c1)];
-                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(c1) * maxdeg + hl] : 0;
+                    GS_DROW(c1);
                 }
                 if (VLDS) {
                     pclr = false;
@@ -617,16 +625,19 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             // below the worst count of a full R (dmax is INF_CNT until R is full, so "below" = "unvisited" then)
             const bool below = unv && cntv < dmax;
             const uint64_t bal = __ballot(unv), balb = __ballot(below);
-            const long long p1 = prof ? clock64() : 0;
+            const long long p1 = PROF ? clock64() : 0;
             uint32_t *ws = S.wsum + ((it & 1) ? 8 : 0);              // double-buffered: the next pop may start before every wave has read
             if (lane == 0) ws[wv] = (uint32_t)__popcll(bal) | ((uint32_t)__popcll(balb) << 16);
             lds_barrier();
-            const long long p2 = prof ? clock64() : 0;
-            uint32_t off = 0, ne = 0, boff = 0, B = 0;
+            const long long p2 = PROF ? clock64() : 0;
+            // ne <= 2M < 2^16, so the packed words add without carrying into each other; the per-wave prefixes are only needed by an
+            // accepting pop and are computed there
+            uint32_t tot = 0;
 #pragma unroll
-            for (int w = 0; w < DT / 64; w++) { const uint32_t x = ws[w]; if (w < (int)wv) { off += x & 0xFFFFu; boff += x >> 16; } ne += x & 0xFFFFu; B += x >> 16; }
-            const long long p3 = prof ? clock64() : 0;
-            if (prof && blockIdx.x == 0 && threadIdx.x == 0) { t_a += p1 - p0; t_b += p2 - p1; t_c += p3 - p2; n_pop++; }
+            for (int w = 0; w < DT / 64; w++) tot += ws[w];
+            const uint32_t ne = tot & 0xFFFFu, B = tot >> 16;
+            const long long p3 = PROF ? clock64() : 0;
+            if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { t_a += p1 - p0; t_b += p2 - p1; t_c += p3 - p2; n_pop++; }
             st_pops++;
             if (ne == 0) continue;
             evals += ne;
@@ -638,6 +649,10 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
             else { if (B == 0) continue; slow = B > tieT; }
             uint64_t mykey = ~(uint64_t)0, ab; bool acc = false;
             uint32_t na, ci, aoff;
+            uint32_t pre = 0;                                        // packed (unvisited | below << 16) counts of the waves before this one
+#pragma unroll
+            for (int w = 0; w < DT / 64; w++) if (w < (int)wv) pre += ws[w];
+            const uint32_t off = pre & 0xFFFFu, boff = pre >> 16;
             if (!slow) { acc = below; na = B; ci = cntv; mykey = KEY(cntv, id); ab = balb; aoff = boff; }
             else {
                 // the expansion E in adjacency order
@@ -681,8 +696,8 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
 #pragma unroll
                 for (int w = 0; w < DT / 64; w++) { const uint32_t x = S.wsum[24 + w]; if (w < (int)wv) aoff += x; na += x; }
             }
-            const long long p4 = prof ? clock64() : 0;
-            if (prof && blockIdx.x == 0 && threadIdx.x == 0) t_d += p4 - p3;
+            const long long p4 = PROF ? clock64() : 0;
+            if (PROF && blockIdx.x == 0 && threadIdx.x == 0) t_d += p4 - p3;
             if (na == 0) continue;
             n_merge++; st_acc++;
             // accepted keys: histogram update, compaction (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
@@ -706,11 +721,10 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 const uint64_t want = half == (it & 1) ? n1 : n2;
                 if (want != ~(uint64_t)0 && pk != want) {
                     pk = want; pst = 1;
-                    pdeg = ix.deg0[KID(want)];
-                    pid = hl < maxdeg ? ix.nbr0[(uint64_t)KID(want) * maxdeg + hl] : 0;
+                    GS_DROW(want);
                 }
             }
-            const long long q1 = prof ? clock64() : 0;
+            const long long q1 = PROF ? clock64() : 0;
             const uint32_t dold = dmax;
             // R <- ef smallest of R u A: drop the (nR + na - ef) largest counts from the top bins
             if (nR + na >= efs) {
@@ -741,7 +755,7 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 nR = efs;
             } else nR += na;
             const uint32_t dnew = dmax;                              // INF_CNT while R is not full
-            const long long q2 = prof ? clock64() : 0;
+            const long long q2 = PROF ? clock64() : 0;
             const SmallA sa = load_small_a(S.A, na);
             // T <- knbn smallest of T u A (only when A reaches into it)
             if (nT < knbn || S.A[0] < Tmax) {
@@ -788,8 +802,9 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 uint32_t tot = liveG + liveN; if (tot > capC) tot = capC;
                 nG = (nR == efs && alive < tot) ? alive : tot;
                 cur ^= 1; headG = 0; wbase = 0; wn = 0; nN = 0; headN = 0;
+                if (threadIdx.x < 3) S.W[threadIdx.x] = ~(uint64_t)0;      // read as heads if G' is empty (no refill then); ordered by the barriers of the N merge below
             }
-            const long long q3 = prof ? clock64() : 0;
+            const long long q3 = PROF ? clock64() : 0;
             // ---- N <- live N u A (both tiny, in LDS), dead tail dropped
             {
                 const uint32_t liveN = nN - headN;
@@ -800,11 +815,12 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
                 lds_barrier();
                 if (npos != 0xFFFFFFFFu) S.N[npos] = nk;
                 if (apos != 0xFFFFFFFFu) S.N[apos] = ak;
+                if (threadIdx.x >= DT - 3) S.N[liveN + na + (threadIdx.x - (DT - 3))] = ~(uint64_t)0;
                 lds_barrier();
                 nN = liveN + na; headN = 0;
                 if (nR == efs && dnew != dold) { const uint32_t alive = lower_bound_keys(S.N, nN, KEY(dnew, 0xFFFFFFFFu)); if (alive < nN) nN = alive; }
             }
-            if (prof && blockIdx.x == 0 && threadIdx.x == 0) { const long long q4 = clock64(); t_e += q4 - p4; tq1 += q1 - p4; tq2 += q2 - q1; tq3 += q3 - q2; tq4 += q4 - q3; tna += na; }
+            if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const long long q4 = clock64(); t_e += q4 - p4; tq1 += q1 - p4; tq2 += q2 - q1; tq3 += q3 - q2; tq4 += q4 - q3; tna += na; }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
@@ -813,8 +829,9 @@ __global__ __launch_bounds__(DT) void k_hnsw_search_dense(IndexDev ix, uint64_t 
         }
         if (threadIdx.x == 0) { if (count_out) count_out[qi] = nT; if (evals_out) evals_out[qi] = evals; }
     }
-    if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_acc); }
-    if (prof && blockIdx.x == 0 && threadIdx.x == 0) {
+#undef GS_DROW
+    if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], (unsigned long long)st_pops); atomicAdd(&stats[2], (unsigned long long)st_acc); }
+    if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
         atomicAdd(&prof[3], (unsigned long long)t_d); atomicAdd(&prof[4], (unsigned long long)t_e); atomicAdd(&prof[5], (unsigned long long)n_pop); atomicAdd(&prof[6], (unsigned long long)n_merge);
         atomicAdd(&prof[8], (unsigned long long)tq1); atomicAdd(&prof[9], (unsigned long long)tq2); atomicAdd(&prof[10], (unsigned long long)tq3); atomicAdd(&prof[11], (unsigned long long)tq4); atomicAdd(&prof[12], (unsigned long long)tna);
@@ -1339,9 +1356,10 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
     const bool vlds = dense_vis_in_lds(ix, knbn, maxdeg);
     const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, vlds);
-    // two 8-wave workgroups per CU: the kernel needs 127 VGPRs per lane (16 wave slots); a build capped at 80 VGPRs fits a third but
-    // spills ~30 registers and was measured slower or equal at 300 k nodes (NOTES.md)
-    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024 - 1024) / lds));
+    // three 8-wave workgroups per CU while the LDS allows it (n <= ~300 k with the bitmap in LDS): that build is capped at 80 VGPRs
+    // (18 dwords spill, none on the per-pop path); the two-per-CU build (<= 128 VGPRs) takes over for larger n
+    const size_t granted = round_up(lds, 1280);                       // LDS is granted in 1280-byte granules
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / granted));
     if (getenv("GS_DENSE_PER_CU")) per_cu = std::max(1, std::min((int)per_cu, atoi(getenv("GS_DENSE_PER_CU"))));
     // per-workgroup global scratch: visited bitmap (vlds = false) or the fine histogram bins (vlds = true)
     const uint32_t scratch_words = vlds ? dense_nblocks(ix->prm.m) * (HB / 2) : (uint32_t)((ix->n + 31) / 32);
@@ -1359,15 +1377,16 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); prof = profbuf.as<unsigned long long>(); }
     {
     ProfScope ps(c, FAM_SEARCH);
-#define GS_LAUNCH_DSEARCH(V)                                                                                              \
+#define GS_LAUNCH_DSEARCH(V, P, O)                                                                                           \
     do {                                                                                                                  \
-        auto kern = k_hnsw_search_dense<V>;                                                                               \
+        auto kern = k_hnsw_search_dense<V, P, O>;                                                                          \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
                            ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof, ix->stats.as<unsigned long long>());  \
     } while (0)
-    if (vlds) GS_LAUNCH_DSEARCH(true);
-    else GS_LAUNCH_DSEARCH(false);
+    if (prof) { if (vlds) GS_LAUNCH_DSEARCH(true, true, 4); else GS_LAUNCH_DSEARCH(false, true, 4); }
+    else if (per_cu >= 3) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 6); else GS_LAUNCH_DSEARCH(false, false, 6); }
+    else { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4); else GS_LAUNCH_DSEARCH(false, false, 4); }
 #undef GS_LAUNCH_DSEARCH
     }
     GS_HIP_CHECK(hipGetLastError());
