@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ATOMICS_PEAK = 1.6e10          # memory-side (device-scope) 32-bit atomics/s measured on MI355X: profiles/r01_match_join_pmc.txt
+ATOMICS_PEAK = 1.86e10         # scattered no-return 32-bit atomics/s into a 2 GB working set (the count-matrix slab) measured on MI355X: tools/ubench_atomic, profiles/r02_ubench_atomic.txt
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md:52-54: a wave64 VALU op issues in 2 cycles (SIMD-32)
 MASK64 = (1 << 64) - 1
 

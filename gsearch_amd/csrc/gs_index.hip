@@ -602,10 +602,6 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                     unv = !(old & bit);
                     if (unv) cntv = (pst == 2 && pclr) ? pcnt : (uint32_t)matrow[id];   // every 2-byte lookup costs a full HBM sector: only for the unvisited
                 }
-                pk = c2; pst = 1;
-                if (c2 != ~(uint64_t)0) {
-                    GS_DROW(c2);
-                }
             } else if (c1 != ~(uint64_t)0) {
                 if (pk != c1) {
                     pk = c1; pst = 1;
@@ -628,6 +624,12 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             const long long p1 = PROF ? clock64() : 0;
             uint32_t *ws = S.wsum + ((it & 1) ? 8 : 0);              // double-buffered: the next pop may start before every wave has read
             if (lane == 0) ws[wv] = (uint32_t)__popcll(bal) | ((uint32_t)__popcll(balb) << 16);
+            // the expanding half now fetches the adjacency of the candidate after next - issued only here, behind the wait for its own
+            // lookups, so that wait does not include these loads
+            if (half != (it & 1)) {
+                pk = c2; pst = 1;
+                if (c2 != ~(uint64_t)0) GS_DROW(c2);
+            }
             lds_barrier();
             const long long p2 = PROF ? clock64() : 0;
             // ne <= 2M < 2^16, so the packed words add without carrying into each other; the per-wave prefixes are only needed by an
@@ -1326,7 +1328,8 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
         return hamming_qxc_strided(c, ix->ikind, ix->prm.m, qrows, nq, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16, ld);
     if ((rc = ensure_cols(ix, n))) return rc;
     if ((rc = ensure_stats(ix))) return rc;
-    const uint64_t jq = match_join_max_queries();
+    // equal batches: every join call streams all the columns, so a short last batch costs almost as much as a full one
+    const uint64_t parts = (nq + match_join_max_queries() - 1) / match_join_max_queries(), jq = (nq + parts - 1) / parts;
     for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
         const uint64_t nb = std::min<uint64_t>(jq, nq - q0);
         int declined = 0;

@@ -106,7 +106,7 @@ __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t
 template <int KIND, typename T>
 __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
                                                     uint32_t m, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
-                                                    unsigned long long *__restrict__ stats)
+                                                    unsigned long long *__restrict__ stats, int chunk_major)
 {
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
@@ -114,8 +114,11 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     uint32_t *tag = (uint32_t *)s_raw;
     uint32_t *bm = (uint32_t *)(s_raw + 4 * (size_t)P);
     T *key = (T *)(s_raw + 4 * (size_t)P + ((size_t)1 << JB_LOG2) / 8);
-    const uint64_t e0 = (uint64_t)blockIdx.x * (JT * JN) + threadIdx.x;      // the lane's nodes: e0 + i * JT, i < JN
-    const uint32_t s0 = blockIdx.y * slots_per_wg, s1 = s0 + slots_per_wg < m ? s0 + slots_per_wg : m;
+    // chunk_major: consecutive workgroups sweep the slot blocks of ONE node chunk, so the counters being updated at any time are
+    // those of a few chunks (a window of the count matrix that fits the 256 MB Infinity Cache) instead of all of them
+    const uint32_t bchunk = chunk_major ? blockIdx.y : blockIdx.x, bslot = chunk_major ? blockIdx.x : blockIdx.y;
+    const uint64_t e0 = (uint64_t)bchunk * (JT * JN) + threadIdx.x;      // the lane's nodes: e0 + i * JT, i < JN
+    const uint32_t s0 = bslot * slots_per_wg, s1 = s0 + slots_per_wg < m ? s0 + slots_per_wg : m;
     uint32_t sticky[JN];
     uint32_t natom = 0;                                           // memory-side atomics this lane sends (work counter for the bench's roofline)
 #pragma unroll
@@ -295,19 +298,22 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
                     t_join * 1e3, t_tile * 1e3, decline ? "tile" : "join");
         if (decline) { *declined = 1; return GS_OK; }
     }
-    // one workgroup = JT * JN nodes x a block of slots; blocks sized so that the grid is about one round of 2 workgroups per CU
+    // one workgroup = JT * JN nodes x a block of slots; blocks sized so that the grid is about eight rounds of 2 workgroups per CU
+    // (one round leaves the slowest workgroup's tail exposed: 145 -> 125 ms per 10 k-query request), at least 32 slots each
     const uint32_t chunks = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
-    uint32_t blocks = std::max<uint32_t>(1, (2 * c->n_cu) / chunks);
+    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((16 * c->n_cu) / chunks, std::max<uint32_t>(m / 32, (2 * c->n_cu) / chunks)));
     if (getenv("GS_JOIN_BLOCKS")) blocks = (uint32_t)atoi(getenv("GS_JOIN_BLOCKS"));
     blocks = std::min<uint32_t>(std::max<uint32_t>(blocks, 1), m);
     const uint32_t slots_per_wg = (m + blocks - 1) / blocks;
-    dim3 jg(chunks, (m + slots_per_wg - 1) / slots_per_wg);
+    const int chunk_major = getenv("GS_JOIN_CHUNK_MAJOR") ? atoi(getenv("GS_JOIN_CHUNK_MAJOR")) : 0;
+    const uint32_t nblk = (m + slots_per_wg - 1) / slots_per_wg;
+    dim3 jg(chunk_major ? nblk : chunks, chunk_major ? chunks : nblk);
     const size_t lds = (sizeof(T) + 4) * ((size_t)1 << log2p) + ((size_t)1 << JB_LOG2) / 8;
     {
         ProfScope ps(c, FAM_HAMMING);
         auto kern = k_match_join<KIND, T>;
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats);
+        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats, chunk_major);
         GS_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_match_to_count, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, (uint64_t)nq, n, ld, m);
@@ -315,14 +321,14 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     return GS_OK;
 }
 
-uint64_t match_join_max_queries() { return JQ_MAX; }
+uint64_t match_join_max_queries() { const char *e = getenv("GS_JOIN_MAXQ"); return e ? (uint64_t)std::max(1, std::min(4094, atoi(e))) : JQ_MAX; }
 
 // `declined` (optional): set to 1 - and out16 is left zeroed - when the sampled match density says the compare tile kernel is the
 // cheaper producer for this batch (the caller then runs it)
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
                       uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined, unsigned long long *stats)
 {
-    GS_REQUIRE(nq >= 1 && nq <= (uint64_t)JQ_MAX && m <= 65535 && (ld % 2) == 0 && ((uintptr_t)out16 % 4) == 0, GS_ERR_INVALID, "match_join_counts: bad shape");
+    GS_REQUIRE(nq >= 1 && nq <= 4094 && m <= 65535 && (ld % 2) == 0 && ((uintptr_t)out16 % 4) == 0, GS_ERR_INVALID, "match_join_counts: bad shape");
     GS_REQUIRE((uint64_t)m * nq < ((uint64_t)1 << 31), GS_ERR_INVALID, "match_join_counts: batch too large");
     if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
     if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
