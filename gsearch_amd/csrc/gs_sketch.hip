@@ -86,6 +86,83 @@ struct MinEmit {
     }
 };
 
+// Hooks of walk_genome that only the filtered emitter overrides: a k-mer emitted by a FULL wavefront (all 64 lanes inside a record),
+// the end of such a word, and the end of the walk.
+template <class E> __device__ __forceinline__ void emit_full_wave(const E &e, uint64_t v, uint64_t rec, uint64_t pos) { e(v, rec, pos); }
+template <class E> __device__ __forceinline__ void emit_word_done(const E &) {}
+template <class E> __device__ __forceinline__ void emit_finish(const E &) {}
+
+// Filtered form of MinEmit for an LDS-resident slot table. The key of a k-mer only needs two of the three SplitMix64
+// outputs (o1 = f(s0, s3)); its slot needs the third and the second xoshiro output. A key that is not below `thr` - an upper bound of
+// EVERY slot's current minimum, refreshed from the table now and then - cannot lower any slot, whichever slot it falls in, so the rest
+// of its arithmetic is skipped: exact. Lanes diverge on that test, so the survivors (a few % once the table has warmed up) are
+// compacted through a per-wave LDS queue of element hashes and finished 64 at a time by the whole wave. Only full waves use the queue
+// (its fill count stays wave-uniform in a register); record boundaries and partial waves take the direct form.
+constexpr int SKQ = 128;          // queue entries per wave: < 64 pending + <= 64 new
+template <int ALGO, int VBITS, typename T>
+struct MinEmitF {
+    T *table; uint32_t m; uint64_t zone;
+    uint64_t *q;                                  // this wave's queue
+    uint32_t lane;
+    mutable uint32_t qn, words;                   // wave-uniform: pending survivors, full-wave words walked
+    mutable T thr;                                // wave-uniform: every slot's minimum is <= thr
+    static __device__ __forceinline__ T key_of(uint64_t o1)
+    {
+        if (ALGO == ALGO_SUPER2) return sizeof(T) == 8 ? (T)o1 : (T)(o1 >> 32);
+        return (T)(o1 >> 41);
+    }
+    static __device__ __forceinline__ T direct_above()        // survivor rate >= 1/4: the queue costs more than it saves (break-even ~0.34)
+    {
+        if (ALGO == ALGO_SUPER2) return (T)((T)1 << (8 * sizeof(T) - 2));
+        return (T)((T)1 << 21);
+    }
+    __device__ __forceinline__ void apply(uint64_t h) const
+    {
+        uint64_t o1; uint32_t b;
+        two_draw(h, m, zone, o1, b);
+        atomicMin(&table[b], key_of(o1));
+    }
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { apply(elem_hash<ALGO, VBITS>(v)); }
+    __device__ __forceinline__ void full(uint64_t v) const
+    {
+        const uint64_t h = elem_hash<ALGO, VBITS>(v);
+        if (thr >= direct_above()) { apply(h); return; }            // wave-uniform
+        const uint64_t s0 = splitmix_mix(h + GS_GAMMA), s3 = splitmix_mix(h + 4 * GS_GAMMA);
+        const T key = key_of(rotl64(s0 + s3, 23) + s0);
+        const bool pass = key < thr;
+        const uint64_t bal = __ballot(pass);
+        if (bal) {
+            if (pass) q[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = h;
+            qn += (uint32_t)__popcll(bal);
+            if (qn >= 64) {
+                apply(q[lane]);
+                const uint32_t rest = qn - 64;
+                const uint64_t mv = q[64 + lane];
+                if (lane < rest) q[lane] = mv;
+                qn = rest;
+            }
+        }
+    }
+    __device__ __forceinline__ void word_done() const
+    {
+        words++;
+        if (words <= 8 ? (words & (words - 1)) != 0 : (words & (words <= 128 ? 7 : 15)) != 0) return;     // 1, 2, 4, 8, then every 8th word, every 16th after 128
+        T mx = 0;
+        for (uint32_t i = lane; i < m; i += 64) { const T x = table[i]; mx = x > mx ? x : mx; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const T y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+        thr = mx;
+    }
+    __device__ __forceinline__ void finish() const
+    {
+        if (lane < qn) apply(q[lane]);
+        qn = 0;
+    }
+};
+template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_full_wave(const MinEmitF<ALGO, VBITS, T> &e, uint64_t v, uint64_t, uint64_t) { e.full(v); }
+template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_word_done(const MinEmitF<ALGO, VBITS, T> &e) { e.word_done(); }
+template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_finish(const MinEmitF<ALGO, VBITS, T> &e) { e.finish(); }
+
 // The streaming part shared by every sketcher: walk the units of genome g assigned to this workgroup and
 // call emit(v) for each valid canonical k-mer value.
 template <bool AA, class Emit>
@@ -120,7 +197,17 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
             // holds an interior word - all 32 windows inside its record, the case for all but the first and last word of a record - the
             // per-window bounds test (two 64-bit compares, an exec save / restore and a branch per k-mer) is dropped for the whole word.
             const bool interior = a0 >= first_valid && a0 + 32 <= re;
-            if (__ballot(interior) == __ballot(true)) {
+            const uint64_t bint = __ballot(interior);
+            if (bint == ~(uint64_t)0) {                      // all 64 lanes: emitters that compact across the wave may do so
+#pragma unroll 2
+                for (uint32_t j = 0; j < 32; j++) {
+                    uint64_t c = w >> 62; w <<= 2;
+                    fwd = ((fwd << 2) | c) & mask;
+                    rc = (rc >> 2) | ((3 - c) << rcshift);
+                    emit_full_wave(emit, fwd < rc ? fwd : rc, lo, a0 + j);
+                }
+                emit_word_done(emit);
+            } else if (bint == __ballot(true)) {
 #pragma unroll 2
                 for (uint32_t j = 0; j < 32; j++) {
                     uint64_t c = w >> 62; w <<= 2;
@@ -162,10 +249,11 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
             }
         }
     }
+    emit_finish(emit);
 }
 
 // ---- main kernel of optdens / revoptdens / super / super2: per-slot minimum over all k-mers (SPEC 3.1, 3.2 level 0)
-template <bool AA, bool LDS_TABLE, int ALGO, int VBITS, typename T>
+template <bool AA, bool LDS_TABLE, int ALGO, int VBITS, typename T, bool FILT>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
                                                             const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
                                                             const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
@@ -186,8 +274,14 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__rest
         for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s_bound[i] = 0xFFFFu;
         __syncthreads();
     }
-    MinEmit<ALGO, VBITS, T, LDS_TABLE> emit{table, m, zone, s_bound};
-    walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
+    if (FILT) {
+        uint64_t *qbase = (uint64_t *)(s_raw_table + (((size_t)m * sizeof(T) + 15) & ~(size_t)15));
+        MinEmitF<ALGO, VBITS, T> emit{table, m, zone, qbase + (threadIdx.x >> 6) * SKQ, threadIdx.x & 63, 0u, 0u, EMPTY};
+        walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
+    } else {
+        MinEmit<ALGO, VBITS, T, LDS_TABLE> emit{table, m, zone, s_bound};
+        walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
+    }
     if (LDS_TABLE) {
         __syncthreads();
         if (parts == 1) { for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) gtab[i] = s_table[i]; }
@@ -465,21 +559,29 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
     if (!ge.use_lds || ge.parts > 1) GS_HIP_CHECK(hipMemsetAsync(table, 0xFF, (size_t)n_genomes * m * sizeof(T), c->stream));
     const bool aa = p->data_t == GS_DATA_AA;
     const size_t lds = ge.lds;
+    // survivor queues of the filtered emitter (DNA, table in LDS): only where they do not cost a resident workgroup
+    const size_t lds_f = ((lds + 15) & ~(size_t)15) + (size_t)(SK_THREADS / 64) * SKQ * 8;
+    const size_t half_cu = (160 * 1024) / 2 / 1280 * 1280;
+    // (and only for genomes long enough to warm the table up: >= 64 k-mers per slot; below that the survivor rate stays above 1/4)
+    const bool filt = !aa && ge.use_lds && !(getenv("GS_SKETCH_FILTER") && !atoi(getenv("GS_SKETCH_FILTER"))) && avg_units * 32 >= (uint64_t)64 * m &&
+                      (lds_f <= half_cu || (lds > half_cu && lds_f <= 160 * 1024 - 256));
     for (uint64_t g0 = 0; g0 < n_genomes; g0 += 65535) {       // grid.y limit
         uint64_t ng = n_genomes - g0 < 65535 ? n_genomes - g0 : 65535;
         dim3 grid(ge.parts, (uint32_t)ng), block(SK_THREADS);
         const uint64_t *gro = genome_rec_off + g0; const uint64_t *gu = gen_units + g0;
         T *tab = table + g0 * m;
         ProfScope ps(c, FAM_SKETCH);
-#define GS_LAUNCH_MIN(AAV, LDSV)                                                                                        \
+#define GS_LAUNCH_MIN(AAV, LDSV, FV)                                                                                    \
     do {                                                                                                                \
-        auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T>;                                                            \
-        const size_t l = LDSV ? lds : ((size_t)2 * m + 15) & ~(size_t)15;      /* slot table, or its 2-byte filter */            \
+        auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T, FV>;                                                        \
+        const size_t l = LDSV ? (FV ? lds_f : lds) : ((size_t)2 * m + 15) & ~(size_t)15;      /* slot table (+ survivor queues), or its 2-byte filter */  \
         if (l > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
         hipLaunchKernelGGL(kern, grid, block, l, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, p->k, m, zone, tab); \
     } while (0)
-        if (aa) { if (ge.use_lds) GS_LAUNCH_MIN(true, true); else GS_LAUNCH_MIN(true, false); }
-        else    { if (ge.use_lds) GS_LAUNCH_MIN(false, true); else GS_LAUNCH_MIN(false, false); }
+        if (aa) { if (ge.use_lds) GS_LAUNCH_MIN(true, true, false); else GS_LAUNCH_MIN(true, false, false); }
+        else if (!ge.use_lds) GS_LAUNCH_MIN(false, false, false);
+        else if (filt) GS_LAUNCH_MIN(false, true, true);
+        else GS_LAUNCH_MIN(false, true, false);
 #undef GS_LAUNCH_MIN
         GS_HIP_CHECK(hipGetLastError());
     }
