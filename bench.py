@@ -149,15 +149,24 @@ def cpu_sketch_baseline(O, op, args, kmers_per_genome, words, cores):
 
 
 def sketch_valu_model(kmers_per_sec):
-    """VALU issue model of k_sketch_min from the committed ISA instruction mix (tools/isa_mix.py -> profiles/*_sketch_isa_mix.json)"""
+    """VALU issue model of k_sketch_min. Per-opcode issue costs come from the committed ISA mix of the full hash (tools/isa_mix.py +
+    tools/ubench_valu -> profiles/r02_sketch_isa_mix.json); the instruction COUNT per k-mer is the one rocprofv3 measured for this very
+    workload (SQ_INSTS_VALU, tools/pmc_sketch.sh -> profiles/r02_sketch_pmc.json), because the filtered emitter drops most k-mers after
+    two of the three SplitMix64 mixes and its work per k-mer depends on the data."""
     path = os.path.join(ROOT, "profiles", "r02_sketch_isa_mix.json")
     if not os.path.exists(path):
         return None
     mix = json.load(open(path))
-    cyc = mix["issue_cycles_per_kmer"]                     # sum over instruction classes of count x issue cycles (2-cycle base, measured weights)
+    cyc_per_instr = mix["issue_cycles_per_kmer"] / mix["valu_per_kmer"]       # mean issue cycles of a VALU instruction of this mix (wave64)
+    valu, src = mix["valu_per_kmer"], "static ISA count of the unfiltered loop"
+    pmc = os.path.join(ROOT, "profiles", "r02_sketch_pmc.json")
+    if os.path.exists(pmc):
+        valu, src = json.load(open(pmc))["valu_wave_instr_per_64_kmers"], "SQ_INSTS_VALU of profiles/r02_sketch_pmc.json"
+    cyc = valu * cyc_per_instr
     peak = SIMDS * CLOCK_HZ / cyc * 64                     # k-mers/s if every SIMD issued nothing but this stream
-    return {"bound": "valu", "valu_wave_instr_per_kmer": mix["valu_per_kmer"], "issue_cycles_per_kmer_per_lane_x64": cyc,
-            "kmers_per_sec_at_issue_ceiling": peak, "frac": kmers_per_sec / peak, "source": "profiles/r02_sketch_isa_mix.json (static ISA count, tools/isa_mix.py)"}
+    return {"bound": "valu", "valu_wave_instr_per_64_kmers": valu, "valu_wave_instr_per_64_kmers_full_hash": mix["valu_per_kmer"],
+            "mean_issue_cycles_per_valu_instr": cyc_per_instr, "kmers_per_sec_at_issue_ceiling": peak, "frac": kmers_per_sec / peak,
+            "source": "instruction count: %s; issue costs: profiles/r02_sketch_isa_mix.json + profiles/r02_ubench_valu.txt" % src}
 
 
 def run_sketch(args, D):

@@ -42,6 +42,24 @@ def test_sketch_dna_matches_oracle(gpu_ctx, k, m, algo):
     assert np.array_equal(_bits(got), _bits(ref))
 
 
+@pytest.mark.parametrize("algo,m", [("optdens", 2000), ("revoptdens", 1500), ("super", 2000), ("super2", 1200)])
+def test_sketch_early_rejection_is_exact(gpu_ctx, monkeypatch, algo, m):
+    """genomes long enough to warm the slot table up (200+ k-mers per slot): the filtered emitter (keys that cannot lower any slot are
+    dropped after two of the three SplitMix64 mixes, survivors go through the per-wave queues) must give the oracle's bits, and the
+    same bits as the unfiltered kernel (GS_SKETCH_FILTER=0)"""
+    import gsearch_amd as G
+    rng = np.random.default_rng(77 + m)
+    genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (420_000, 300_011, 515_000)]
+    genomes.append([H.dna_ascii(H.rand_dna(rng, 200_000)), b"ACGTNNACGT", H.dna_ascii(H.rand_dna(rng, 250_007))])     # record boundaries inside
+    sk = G.sketcher_for(G.SeqSketcherParams(21, m, algo))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(21, m, algo, genomes)
+    assert got.dtype == ref.dtype and np.array_equal(_bits(got), _bits(ref))
+    monkeypatch.setenv("GS_SKETCH_FILTER", "0")
+    plain = sk.sketch_genomes(genomes)
+    assert np.array_equal(_bits(got), _bits(plain))
+
+
 @pytest.mark.parametrize("algo", ["optdens", "revoptdens"])
 def test_sketch_densification_matches_oracle(gpu_ctx, algo):
     """few k-mers, many bins: exercises the empty-bin densification (cold path at BASELINE sizes)."""
