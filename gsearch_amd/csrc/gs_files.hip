@@ -79,6 +79,20 @@ static int inflate_gzip(const uint8_t *in, size_t n, Bytes &out)
     out.resize(produced);
     return GS_OK;
 }
+// single-member gzip straight into a caller-owned buffer of `cap` bytes (the size its ISIZE trailer promises). Returns 1 when the whole
+// input was one member that fitted, 0 when the general path must take over (more members, more output than promised, or an error - which
+// the general path then reports)
+static int inflate_gzip_into(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *produced_out)
+{
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (n > (1u << 30) || cap > (1u << 30) || inflateInit2(&zs, 15 + 32) != Z_OK) return 0;
+    zs.next_in = (Bytef *)in; zs.avail_in = (uInt)n; zs.next_out = out; zs.avail_out = (uInt)cap;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.avail_in == 0;
+    *produced_out = cap - zs.avail_out;
+    inflateEnd(&zs);
+    return ok ? 1 : 0;
+}
 // bz2 and xz: the image ships the shared libraries without headers, so the two stable one-shot entry points are bound by hand
 typedef int (*fn_bz2)(char *dest, unsigned int *destLen, char *source, unsigned int sourceLen, int small, int verbosity);
 typedef int (*fn_xz)(uint64_t *memlimit, uint32_t flags, const void *allocator, const uint8_t *in, size_t *in_pos, size_t in_size, uint8_t *out, size_t *out_pos, size_t out_size);
@@ -121,13 +135,15 @@ static int read_whole_file(const char *path, Bytes &raw)
     FILE *f = fopen(path, "rb");
     GS_REQUIRE(f, GS_ERR_IO, "cannot open %s", path);
     struct stat st; size_t want = (fstat(fileno(f), &st) == 0 && st.st_size > 0) ? (size_t)st.st_size : (size_t)10000000;   // files.rs:233 fallback
-    raw.resize(want);
+    // one byte more than the file holds: the read that reaches EOF then comes back short and the buffer is never doubled (a doubling
+    // realloc-copies the whole file and faults twice its pages in just to learn that nothing follows)
+    if (!raw.resize(want + 1)) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "out of host memory reading %s", path); }
     size_t got = 0;
     for (;;) {
         const size_t r = fread(raw.data() + got, 1, raw.size() - got, f);
         got += r;
-        if (r == 0) break;
-        if (got == raw.size()) raw.resize(raw.size() * 2);
+        if (r == 0 || got < raw.size()) { if (r == 0 || feof(f) || ferror(f)) break; continue; }
+        if (!raw.resize(raw.size() * 2)) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "out of host memory reading %s", path); }
     }
     fclose(f);
     raw.resize(got);
@@ -145,20 +161,63 @@ static int read_fasta(const char *path, Bytes &text)
 }
 
 struct FileBlob {       // one file after the host stage
-    Bytes text; std::vector<uint64_t> sb, se; int rc = GS_OK; std::string err; double read_s = 0;
+    Bytes text;                           // decompressed text of a compressed file (plain files are read straight into the pinned buffer)
+    uint8_t *dst = nullptr; size_t dst_cap = 0, dst_len = 0;    // where a plain file goes (pinned) and how much of it was filled
+    std::vector<uint64_t> sb, se; int rc = GS_OK; std::string err; double read_s = 0;
 };
+static bool has_compressed_suffix(const char *path)
+{
+    const std::string f(path);
+    return ends_with(f, ".gz") || ends_with(f, ".bz2") || ends_with(f, ".xz");
+}
+// record boundaries of a FASTA text, one pass when the guess of the record count holds
+static int scan_records(const uint8_t *text, size_t n, std::vector<uint64_t> &sb, std::vector<uint64_t> &se)
+{
+    uint64_t nr = 0, cap = 1024;
+    for (;;) {
+        sb.resize(cap); se.resize(cap);
+        const int rc = gs_fasta_scan((const char *)text, n, 1, cap, sb.data(), se.data(), nullptr, nullptr, &nr);
+        if (rc) return rc;
+        if (nr <= cap) break;
+        cap = nr;
+    }
+    sb.resize(nr); se.resize(nr);
+    return GS_OK;
+}
+// Host stage of one file. A file without a compression suffix is read straight into its place in the pinned staging buffer (b->dst,
+// sized from stat): no intermediate allocation - hundreds of threads faulting fresh pages in contend on the process's mmap lock, which
+// is what limited the group size - and no second copy. Compressed files (by suffix, or by magic bytes after all) decompress into b->text.
 static void host_stage(const char *path, FileBlob *b)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    b->rc = read_fasta(path, b->text);
-    if (b->rc == GS_OK) {
-        uint64_t nr = 0;
-        b->rc = gs_fasta_scan((const char *)b->text.data(), b->text.size(), 1, 0, nullptr, nullptr, nullptr, nullptr, &nr);
-        if (b->rc == GS_OK) {
-            b->sb.resize(nr); b->se.resize(nr);
-            b->rc = gs_fasta_scan((const char *)b->text.data(), b->text.size(), 1, nr, b->sb.data(), b->se.data(), nullptr, nullptr, &nr);
+    b->rc = GS_OK; b->dst_len = 0; b->text.n = 0;
+    const uint8_t *text = nullptr; size_t n = 0;
+    bool direct = b->dst != nullptr;
+    if (direct && has_compressed_suffix(path)) {                   // .gz sized from its trailer: inflate straight into the pinned buffer
+        Bytes raw; size_t produced = 0;
+        direct = read_whole_file(path, raw) == GS_OK && raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b &&
+                 inflate_gzip_into(raw.data(), raw.size(), b->dst, b->dst_cap, &produced) == 1;
+        if (direct) { b->dst_len = produced; text = b->dst; n = produced; }
+    } else if (direct) {
+        FILE *f = fopen(path, "rb");
+        if (!f) { set_error("cannot open %s", path); b->rc = GS_ERR_IO; }
+        else {
+            size_t got = 0;
+            for (;;) { const size_t r = fread(b->dst + got, 1, b->dst_cap - got, f); got += r; if (r == 0 || got == b->dst_cap) break; }
+            const bool more = got == b->dst_cap && fgetc(f) != EOF;               // the file grew since it was sized: take the general path
+            fclose(f);
+            const uint8_t *d = b->dst;
+            const bool packed = (got >= 2 && d[0] == 0x1f && d[1] == 0x8b) || (got >= 3 && d[0] == 'B' && d[1] == 'Z' && d[2] == 'h') ||
+                                (got >= 6 && !memcmp(d, "\xfd" "7zXZ\0", 6));
+            if (more || packed) direct = false;
+            else { b->dst_len = got; text = d; n = got; }
         }
     }
+    if (!direct && b->rc == GS_OK) {
+        b->rc = read_fasta(path, b->text);
+        text = b->text.data(); n = b->text.size();
+    }
+    if (b->rc == GS_OK) b->rc = scan_records(text, n, b->sb, b->se);
     if (b->rc) b->err = gs_last_error();                          // thread-local: carry it to the caller's thread
     b->read_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -246,16 +305,49 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     GS_HIP_CHECK(hipSetDevice(c->device));
     const auto t_call = std::chrono::steady_clock::now();
     const bool aa = p->data_t == GS_DATA_AA;
-    if (pio == 0) pio = 64;
+    if (pio == 0) pio = 32;          // small groups overlap best (measured: 32 files per group 3200 genomes/s, 64: 2400, 256: 900)
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
     const uint64_t n_groups = (n_files + pio - 1) / pio;
     const size_t esz = gs_sig_elem_bytes(p), m = p->sketch_size;
     std::vector<std::vector<gs::FileBlob>> blobs(n_groups);
     std::vector<std::future<void>> pending(n_groups);
+    constexpr int NSLOT = 4;       // pinned staging buffers: groups g+1 and g+2 are being read while g copies and g-1 is on the device
+    void *pinned[NSLOT] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[NSLOT] = {0, 0, 0, 0};
+    std::vector<uint64_t> plain_total(n_groups, 0);
+    int start_rc = GS_OK;
     // host stage of a group: its files are spread over n_threads threads (files.rs:327 par_iter over the group)
     auto start_group = [&](uint64_t g) {
         const uint64_t f0 = g * pio, f1 = std::min<uint64_t>(n_files, f0 + pio);
         blobs[g].resize(f1 - f0);
+        {   // size the plain files and give each its place in this group's pinned buffer (its previous user, group g-4, is long done)
+            const int sl = (int)(g % NSLOT);
+            std::vector<uint64_t> off(f1 - f0, 0), cap(f1 - f0, 0);
+            uint64_t tot = 0;
+            for (uint64_t f = f0; f < f1; f++) {
+                struct stat st;
+                if (stat(paths[f], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) continue;
+                uint64_t want = 0;
+                if (!gs::has_compressed_suffix(paths[f])) want = (uint64_t)st.st_size;
+                else if (gs::ends_with(paths[f], ".gz") && st.st_size >= 18) {            // gzip: the last four bytes are the text size (mod 2^32)
+                    FILE *fz = fopen(paths[f], "rb");
+                    uint8_t t4[4];
+                    if (fz && fseek(fz, -4, SEEK_END) == 0 && fread(t4, 1, 4, fz) == 4) want = (uint64_t)t4[0] | (uint64_t)t4[1] << 8 | (uint64_t)t4[2] << 16 | (uint64_t)t4[3] << 24;
+                    if (fz) fclose(fz);
+                    if (want < (uint64_t)st.st_size / 2 || want > (uint64_t)st.st_size * 64 || want >= (1u << 30)) want = 0;       // not a plausible single member
+                }
+                if (want) { off[f - f0] = tot; cap[f - f0] = want; tot += (want + 63) / 64 * 64; }
+            }
+            plain_total[g] = tot;
+            if (tot + 64 > pinned_cap[sl]) {
+                if (pinned[sl]) (void)hipHostFree(pinned[sl]);
+                pinned[sl] = nullptr; pinned_cap[sl] = (tot + 64) * 5 / 4;
+                if (hipHostMalloc(&pinned[sl], pinned_cap[sl], hipHostMallocDefault) != hipSuccess) { pinned[sl] = nullptr; pinned_cap[sl] = 0; start_rc = GS_ERR_HIP; gs::set_error("hipHostMalloc of %zu bytes failed", (size_t)((tot + 64) * 5 / 4)); }
+            }
+            for (uint64_t f = f0; f < f1; f++) {
+                gs::FileBlob &fb = blobs[g][f - f0];
+                fb.dst = (cap[f - f0] && pinned[sl]) ? (uint8_t *)pinned[sl] + off[f - f0] : nullptr; fb.dst_cap = cap[f - f0];
+            }
+        }
         pending[g] = std::async(std::launch::async, [&, g, f0, f1]() {
             std::atomic<uint64_t> next{f0};
             std::vector<std::thread> th;
@@ -267,13 +359,13 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     hipStream_t copy_stream = nullptr;
     GS_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     hipEvent_t ev[2] = {nullptr, nullptr};
-    void *pinned[2] = {nullptr, nullptr}; size_t pinned_cap[2] = {0, 0};
     gs::DevBuf dtext[2], dout, drs, drl, dgo, dsig;
     double read_s = 0, copy_wait_s = 0, dev_s = 0;
     struct Staged { uint64_t bytes = 0; std::vector<uint64_t> sb, se, frec; } staged[2];
     auto cleanup = [&]() {
         for (auto &f : pending) if (f.valid()) f.wait();
-        for (int i = 0; i < 2; i++) { if (pinned[i]) (void)hipHostFree(pinned[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+        for (int i = 0; i < NSLOT; i++) if (pinned[i]) (void)hipHostFree(pinned[i]);
+        for (int i = 0; i < 2; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     };
 #define GS_FILES_FAIL(code) do { const int rc_ = (code); cleanup(); return rc_; } while (0)
@@ -283,39 +375,45 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     // stage group g: wait for its host tasks, lay the texts of its files end to end in pinned memory, start the H2D copy
     auto stage = [&](uint64_t g) -> int {
         pending[g].wait();
-        const int b = (int)(g & 1);
+        if (start_rc) return start_rc;
+        const int b = (int)(g & 1), sl = (int)(g % NSLOT);
         Staged &S = staged[b];
         S.sb.clear(); S.se.clear(); S.frec.assign(1, 0);
-        uint64_t total = 0;
-        for (auto &fb : blobs[g]) {
+        // plain files sit where start_group put them; the texts of decompressed files are appended behind them
+        uint64_t total = plain_total[g];
+        std::vector<uint64_t> base(blobs[g].size());
+        for (size_t f = 0; f < blobs[g].size(); f++) {
+            auto &fb = blobs[g][f];
             if (fb.rc) { gs::set_error("%s", fb.err.c_str()); return fb.rc; }
             read_s += fb.read_s;
-            for (size_t r = 0; r < fb.sb.size(); r++) { S.sb.push_back(total + fb.sb[r]); S.se.push_back(total + fb.se[r]); }
+            if (fb.dst_len || fb.text.empty()) base[f] = fb.dst ? (uint64_t)(fb.dst - (uint8_t *)pinned[sl]) : 0;
+            else { base[f] = total; total += (fb.text.size() + 63) / 64 * 64; }
+            for (size_t r = 0; r < fb.sb.size(); r++) { S.sb.push_back(base[f] + fb.sb[r]); S.se.push_back(base[f] + fb.se[r]); }
             S.frec.push_back(S.sb.size());
-            total += fb.text.size();
         }
         S.bytes = total;
-        if (total + 64 > pinned_cap[b]) {
-            if (pinned[b]) GS_HIP_CHECK(hipHostFree(pinned[b]));
-            pinned[b] = nullptr; pinned_cap[b] = (total + 64) * 5 / 4;
-            GS_HIP_CHECK(hipHostMalloc(&pinned[b], pinned_cap[b], hipHostMallocDefault));
+        if (total + 64 > pinned_cap[sl]) {                          // decompressed texts do not fit behind the plain files: grow, keep what is there
+            void *np = nullptr; const size_t ncap = (total + 64) * 5 / 4;
+            GS_HIP_CHECK(hipHostMalloc(&np, ncap, hipHostMallocDefault));
+            if (pinned[sl]) { memcpy(np, pinned[sl], plain_total[g]); (void)hipHostFree(pinned[sl]); }
+            pinned[sl] = np; pinned_cap[sl] = ncap;
         }
-        {   // lay the files end to end in the pinned buffer: a team of threads copies (one thread moves ~8 GB/s, a group is 100s of MB)
-            std::vector<uint64_t> offs(blobs[g].size());
-            uint64_t off = 0;
-            for (size_t f = 0; f < blobs[g].size(); f++) { offs[f] = off; off += blobs[g][f].text.size(); }
+        {   // a team of threads copies the decompressed texts in (one thread moves ~8 GB/s)
             std::atomic<size_t> next{0};
             auto copier = [&]() { for (;;) { const size_t f = next.fetch_add(1); if (f >= blobs[g].size()) break; auto &fb = blobs[g][f];
-                                             if (!fb.text.empty()) memcpy((uint8_t *)pinned[b] + offs[f], fb.text.data(), fb.text.size()); fb.text.release(); } };
+                                             if (!fb.dst_len && !fb.text.empty()) memcpy((uint8_t *)pinned[sl] + base[f], fb.text.data(), fb.text.size());
+                                             fb.text.release(); } };
+            size_t n_ext = 0;
+            for (auto &fb : blobs[g]) n_ext += (!fb.dst_len && !fb.text.empty());
             std::vector<std::thread> team;
-            const uint32_t nt = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(n_threads, 32), blobs[g].size());
+            const uint32_t nt = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(n_threads, 32), n_ext);
             for (uint32_t t = 1; t < nt; t++) team.emplace_back(copier);
             copier();
             for (auto &x : team) x.join();
         }
         int rc2;
         if ((rc2 = dtext[b].ensure(total + 64))) return rc2;
-        if (total) GS_HIP_CHECK(hipMemcpyAsync(dtext[b].p, pinned[b], total, hipMemcpyHostToDevice, copy_stream));
+        if (total) GS_HIP_CHECK(hipMemcpyAsync(dtext[b].p, pinned[sl], total, hipMemcpyHostToDevice, copy_stream));
         GS_HIP_CHECK(hipEventRecord(ev[b], copy_stream));
         return GS_OK;
     };
