@@ -84,7 +84,9 @@ for v in a.variants:
         if rep and (best is None or srch[0] < best[0][0]):
             best = (srch, join, dt, st)
     srch, join, dt, st = best
-    same = "-" if base is None else all(np.array_equal(x, y) for x, y in zip(res, base))
+    same = "-" if base is None else ("True" if all(np.array_equal(x, y) for x, y in zip(res, base)) else
+                                     "False[ids %s dist %s count %s evals %s; queries differing in ids: %d]" % (np.array_equal(res[0], base[0]), np.array_equal(res[1], base[1]), np.array_equal(res[2], base[2]),
+                                                                                         np.array_equal(res[3], base[3]), int((res[0] != base[0]).any(axis=1).sum())))
     if base is None:
         base = res
     print("%-40s traversal %8.2f ms (%d launches)  join %8.2f ms  call %8.1f ms  pops/q %.0f acc/q %.0f wg %d  same_as_first=%s" %
