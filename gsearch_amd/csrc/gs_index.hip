@@ -321,7 +321,7 @@ __device__ __forceinline__ void greedy_layer_block(const IndexDev &ix, const uin
 // The result set R is NOT kept as a sorted key array here. The accept rule of search_layer_block only needs, of R, the
 // multiset of its counts (rank queries, worst count, number of keys tied at the worst count), and the answer only needs the
 // knbn smallest keys ever accepted (R is always "the ef smallest accepted keys", so its head is exactly that). So R becomes
-//   Hf : u16 histogram of the counts in R (one bin per count), H2 : sums per 8 bins, H1 : sums per 64 bins,
+//   Hf : u16 histogram of the counts in R (one bin per count), H2 : sums per 16 bins, H1 : sums per 64 bins,
 //        registers dmax / tieT / nR;   T : sorted array of the min(knbn, nR) smallest keys (LDS)
 // which turns the O(ef) merge per accepting expansion into O(#accepted) histogram updates; dropping the largest keys of a
 // full R = decrementing the top bins. Candidates: sorted bulk array G (global ping-pong, read through a 64-key LDS window) plus
@@ -340,14 +340,16 @@ constexpr int DT = 512;           // lanes per dense-mode workgroup (two halves 
 constexpr int DWIN = 64;          // keys of C mirrored in LDS
 constexpr int DCN = 432;          // capacity of the LDS-resident candidate buffer N (>= 2M: an empty N takes a whole expansion; <= DT: one key per lane)
 constexpr int TMAXI = 2;          // staged T keys per lane in a merge (knbn <= TMAXI*DT)
-constexpr int HB = 64;            // histogram bins per H1 block (8 groups of 8 bins)
+constexpr int HB = 64;            // histogram bins per H1 block
+constexpr int HG = 16;            // histogram bins per H2 counter (HB / HG counters per block): 2.2 kB of LDS at m = 18000 (8-bin counters took
+                                  // 4.5 kB - the difference keeps three workgroups per CU up to n = 318 k, the size of the NCBI prokaryote set)
 struct DenseLds { uint64_t *T, *A, *As, *W, *N; uint32_t *Hf, *H2, *H1, *P1, *vis, *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
 __host__ __device__ inline uint32_t dense_nblocks(uint32_t m) { return m / HB + 1; }
 __host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
 {
     const size_t nb = dense_nblocks(m);
     size_t histb = 4 * ((size_t)DCN + 8); if (histb < 4 * nb) histb = 4 * nb;                   // fold histogram, aliased by P1
-    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * (DWIN + 4) + 8 * (size_t)(DCN + 4) + 64 + 4 * nb * 4 /*H2*/ + 4 * nb /*H1*/ +
+    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * (DWIN + 4) + 8 * (size_t)(DCN + 4) + 64 + 4 * nb * (HB / HG / 2) /*H2*/ + 4 * nb /*H1*/ +
            8 * (size_t)maxdeg /*Eid,Ecnt (aliased by As)*/ + histb + 4 * 48 + (vlds ? 4 * (size_t)((n + 31) / 32 + 1) : 4 * nb * (HB / 2));
 }
 __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
@@ -362,7 +364,7 @@ __device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint3
     S.scal = (uint64_t *)base; base += 64;
     S.Eid = (uint32_t *)base; S.As = (uint64_t *)base; base += 4 * (size_t)maxdeg;     // As (compaction of accepted keys) reuses Eid/Ecnt, dead by then
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
-    S.H2 = (uint32_t *)base; base += 4 * nb * 4;
+    S.H2 = (uint32_t *)base; base += 4 * nb * (HB / HG / 2);
     S.H1 = (uint32_t *)base; base += 4 * nb;
     S.hist = (uint32_t *)base; S.P1 = (uint32_t *)base; base += histb;                  // P1 (slow accept path) and hist (fold) are never live together
     S.wsum = (uint32_t *)base; base += 4 * 48;                                          // 5 call-site private slots of 8 words
@@ -387,31 +389,32 @@ template <bool VLDS> __device__ __forceinline__ void hist_add(const Hist3 &h, ui
 {
     if (VLDS) __hip_atomic_fetch_add(&h.Hf[c >> 1], v << ((c & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicAdd(&h.Hf[c >> 1], v << ((c & 1) * 16));
-    h16add(h.H2, c >> 3, v); atomicAdd(&h.H1[c / HB], v);
+    h16add(h.H2, c / HG, v); atomicAdd(&h.H1[c / HB], v);
 }
 template <bool VLDS> __device__ __forceinline__ void hist_sub(const Hist3 &h, uint32_t c, uint32_t v)
 {
     if (VLDS) __hip_atomic_fetch_sub(&h.Hf[c >> 1], v << ((c & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicSub(&h.Hf[c >> 1], v << ((c & 1) * 16));
-    h16sub(h.H2, c >> 3, v); atomicSub(&h.H1[c / HB], v);
+    h16sub(h.H2, c / HG, v); atomicSub(&h.H1[c / HB], v);
 }
 // one wave: highest non-empty bin <= d (d wave-uniform) and its multiplicity; bin 0 / 0 when there is none
 template <bool VLDS> __device__ __forceinline__ uint32_t hist_find_down(const Hist3 &h, uint32_t d, uint32_t lane, uint32_t &mult)
 {
-    const uint32_t l8 = lane & 7;
-    uint32_t grp = d >> 3;
+    constexpr uint32_t GPB = HB / HG;                         // H2 counters per H1 block
+    const uint32_t lf = lane % HG, lg = lane % GPB;
+    uint32_t grp = d / HG;
     {   // bins of d's own group
-        const uint32_t b = grp * 8 + l8;
-        const uint32_t v = (lane < 8 && b <= d) ? hf_get<VLDS>(h.Hf, b) : 0;
+        const uint32_t b = grp * HG + lf;
+        const uint32_t v = (lane < (uint32_t)HG && b <= d) ? hf_get<VLDS>(h.Hf, b) : 0;
         const uint64_t bal = __ballot(v != 0);
-        if (bal) { const uint32_t top = 63 - (uint32_t)__clzll((long long)bal); mult = __shfl(v, top); return grp * 8 + top; }
+        if (bal) { const uint32_t top = 63 - (uint32_t)__clzll((long long)bal); mult = __shfl(v, top); return grp * HG + top; }
     }
     bool found = false;
     {   // lower groups of d's block
-        const uint32_t blk = d / HB, g = blk * 8 + l8;
-        const uint32_t v = (lane < 8 && g < grp) ? h16(h.H2, g) : 0;
+        const uint32_t blk = d / HB, g = blk * GPB + lg;
+        const uint32_t v = (lane < GPB && g < grp) ? h16(h.H2, g) : 0;
         const uint64_t bal = __ballot(v != 0);
-        if (bal) { grp = blk * 8 + (63 - (uint32_t)__clzll((long long)bal)); found = true; }
+        if (bal) { grp = blk * GPB + (63 - (uint32_t)__clzll((long long)bal)); found = true; }
         else {
             for (int base = (int)blk - 1; base >= 0 && !found; base -= 64) {
                 const int bi = base - (int)lane;
@@ -419,21 +422,21 @@ template <bool VLDS> __device__ __forceinline__ uint32_t hist_find_down(const Hi
                 const uint64_t b1 = __ballot(v1 != 0);
                 if (b1) {
                     const uint32_t blk2 = (uint32_t)base - (uint32_t)(__ffsll((long long)b1) - 1);
-                    const uint32_t v2 = lane < 8 ? h16(h.H2, blk2 * 8 + l8) : 0;
+                    const uint32_t v2 = lane < GPB ? h16(h.H2, blk2 * GPB + lg) : 0;
                     const uint64_t b2 = __ballot(v2 != 0);
-                    if (b2) { grp = blk2 * 8 + (63 - (uint32_t)__clzll((long long)b2)); found = true; }
+                    if (b2) { grp = blk2 * GPB + (63 - (uint32_t)__clzll((long long)b2)); found = true; }
                     else base = -1;                       // inconsistent summaries cannot happen; stop
                 }
             }
         }
     }
     if (!found) { mult = 0; return 0; }
-    const uint32_t v = lane < 8 ? hf_get<VLDS>(h.Hf, grp * 8 + l8) : 0;
+    const uint32_t v = lane < (uint32_t)HG ? hf_get<VLDS>(h.Hf, grp * HG + lf) : 0;
     const uint64_t bal = __ballot(v != 0);
     if (!bal) { mult = 0; return 0; }
     const uint32_t top = 63 - (uint32_t)__clzll((long long)bal);
     mult = __shfl(v, top);
-    return grp * 8 + top;
+    return grp * HG + top;
 }
 // Barrier that only orders LDS traffic: global loads issued before it (prefetches) stay in flight across it. Everything the
 // dense traversal exchanges between lanes inside a pop goes through LDS; the few places that hand global data between lanes
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         const uint16_t *matrow = mat + qi * mat_ld;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
         for (uint32_t w = threadIdx.x; w < hwords; w += DT) hs.Hf[w] = 0;
-        for (uint32_t w = threadIdx.x; w < nb * 4; w += DT) S.H2[w] = 0;
+        for (uint32_t w = threadIdx.x; w < nb * (HB / HG / 2); w += DT) S.H2[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb; w += DT) S.H1[w] = 0;
         uint32_t evals = 1;                                      // <= n + upper-layer hops
         uint32_t ep = (uint32_t)ix.entry, ep_cnt = matrow[ep];
@@ -677,8 +680,8 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 lds_barrier();
                 if (threadIdx.x < ne && ci < dmax) {
                     uint32_t le = S.P1[ci / HB];
-                    for (uint32_t g = (ci / HB) * 8; g < (ci >> 3); g++) le += h16(S.H2, g);
-                    const uint32_t w0 = (ci >> 3) * 4, w1 = ci >> 1;
+                    for (uint32_t g = (ci / HB) * (HB / HG); g < ci / HG; g++) le += h16(S.H2, g);
+                    const uint32_t w0 = (ci / HG) * (HG / 2), w1 = ci >> 1;
                     for (uint32_t w = w0; w <= w1; w++) {
                         const uint32_t x = hf_word<VLDS>(hs.Hf, w);
                         le += x & 0xFFFFu;
