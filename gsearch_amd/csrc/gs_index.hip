@@ -1172,6 +1172,29 @@ struct gs_index {
 
 namespace gs {
 
+// Gives the insert-time pair cache back. Its slabs are an optimisation (the plan kernel streams the rows of pairs that are not cached);
+// the signatures, their column copy and the count matrix are not, so when one of THOSE cannot be allocated the cache goes and stays off.
+static void drop_pair_cache(gs_index *ix)
+{
+    (void)hipGetLastError();                                       // the failed hipMalloc left its error behind
+    if (!ix->slabs.empty()) {
+        (void)hipStreamSynchronize(ix->ctx->stream);
+        if (ix->rowptr.p) (void)hipMemsetAsync(ix->rowptr.p, 0, ix->rowptr.bytes, ix->ctx->stream);
+        (void)hipStreamSynchronize(ix->ctx->stream);
+        for (auto *b : ix->slabs) delete b;
+        ix->slabs.clear();
+    }
+    ix->pair_cache_bytes = 0; ix->pair_cache_budget = 1;
+}
+// DevBuf::alloc that pays with the pair cache when the device is full
+static int alloc_or_evict(gs_index *ix, DevBuf &b, size_t bytes)
+{
+    int rc = b.alloc(bytes);
+    if (rc == GS_OK || (ix->slabs.empty() && ix->pair_cache_budget == 1)) return rc;
+    drop_pair_cache(ix);
+    return b.alloc(bytes);
+}
+
 static int index_reserve(gs_index *ix, uint64_t need, uint64_t need_upper)
 {
     gs_ctx *c = ix->ctx;
@@ -1182,7 +1205,7 @@ static int index_reserve(gs_index *ix, uint64_t need, uint64_t need_upper)
             {&ix->data, (size_t)ix->stride}, {&ix->levels, 1}, {&ix->deg0, 4}, {&ix->nbr0, (size_t)8 * M}, {&ix->cnt0, (size_t)8 * M}, {&ix->upidx, 4}, {&ix->rowptr, 8}};
         for (auto &a : arr) {
             DevBuf nb;
-            int rc = nb.alloc(a.per * ncap); if (rc) return rc;
+            int rc = alloc_or_evict(ix, nb, a.per * ncap); if (rc) return rc;
             GS_HIP_CHECK(hipMemsetAsync(nb.p, 0, a.per * ncap, c->stream));
             if (ix->n) GS_HIP_CHECK(hipMemcpyAsync(nb.p, a.b->p, a.per * ix->n, hipMemcpyDeviceToDevice, c->stream));
             GS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1305,7 +1328,7 @@ static int ensure_cols(gs_index *ix, uint64_t upto)
     gs_ctx *c = ix->ctx;
     int rc;
     if (ix->cols_cap != ix->cap || !ix->cols.p) {
-        if ((rc = ix->cols.alloc((size_t)ix->prm.m * ix->cap * ix->esz))) return rc;
+        if ((rc = alloc_or_evict(ix, ix->cols, (size_t)ix->prm.m * ix->cap * ix->esz))) return rc;
         ix->cols_cap = ix->cap; ix->cols_n = 0;
     }
     if (ix->cols_n < upto) {
@@ -1508,7 +1531,7 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     QB = std::max<uint64_t>(128, QB / 128 * 128);
     if (getenv("GS_SEARCH_QB")) QB = std::min<uint64_t>(QB, (uint64_t)std::max(1, atoi(getenv("GS_SEARCH_QB"))));
     QB = std::min<uint64_t>(QB, rest);
-    if ((rc = ix->mat.ensure((size_t)2 * QB * ld))) return rc;
+    if (ix->mat.bytes < (size_t)2 * QB * ld && (rc = alloc_or_evict(ix, ix->mat, (size_t)2 * QB * ld))) return rc;
     if (join && (rc = ensure_cols(ix, ix->n))) return rc;
     for (uint64_t q0 = done; q0 < nq; q0 += QB) {
         const uint64_t nb = std::min(QB, nq - q0);
@@ -1827,7 +1850,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             }
             uint16_t *out16;
             if (slab) { out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld; mat_ld = slab_ld; }
-            else { if ((rc = ix->mat.ensure((size_t)2 * B * slab_ld))) return rc; out16 = ix->mat.as<uint16_t>(); mat_ld = slab_ld; }
+            else { if (ix->mat.bytes < (size_t)2 * B * slab_ld && (rc = alloc_or_evict(ix, ix->mat, (size_t)2 * B * slab_ld))) return rc; out16 = ix->mat.as<uint16_t>(); mat_ld = slab_ld; }
             if ((rc = gs::dense_counts(ix, rows, nb, b0, out16, mat_ld))) return rc;
             if (slab) {
                 hipLaunchKernelGGL(gs::k_cache_rows, dim3(nb), dim3(256), 0, c->stream, out16, mat_ld, b0, nb, ix->cntmat.as<uint32_t>(), ix->rowptr.as<uint64_t>());
