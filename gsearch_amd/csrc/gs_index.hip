@@ -1842,7 +1842,14 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             if (!slab_tried) {
                 slab_tried = true;
                 const uint64_t need = (first + n - b0) * slab_ld * 2;
-                if (ix->pair_cache_bytes + need <= ix->pair_cache_budget) {
+                // a slab is only taken while the device keeps room for the next growth step of the index itself: a new signature block
+                // next to the old one (x1.5) and the column copy that follows it, ~2x the signatures held now, + 16 GB of working space
+                bool room = true;
+                {
+                    size_t fr = 0, tot = 0;
+                    if (hipMemGetInfo(&fr, &tot) == hipSuccess) room = (uint64_t)fr >= need + 2 * (uint64_t)ix->stride * ix->cap + ((uint64_t)16 << 30);
+                }
+                if (room && ix->pair_cache_bytes + need <= ix->pair_cache_budget) {
                     slab = new gs::DevBuf();
                     if (slab->alloc(need) != GS_OK) { delete slab; slab = nullptr; }
                     else { ix->slabs.push_back(slab); ix->pair_cache_bytes += need; slab_first = b0; }

@@ -78,6 +78,14 @@ __device__ __forceinline__ uint32_t join_hash(uint64_t k) { return (uint32_t)((k
 #define GS_SEL4(a, i) (((i) & 2) ? (((i) & 1) ? a[3] : a[2]) : (((i) & 1) ? a[1] : a[0]))
 
 constexpr int JN = 8;             // nodes per lane: a workgroup owns JT * JN nodes for a whole block of slots
+// Barrier that only orders LDS traffic (the hash table of a slot): a __syncthreads() also waits for vmcnt(0), i.e. for every count atomic
+// and column prefetch the wave has in flight - three times per slot
+__device__ __forceinline__ void join_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // one match of (tag = query + 1) with the lane's node `slot`: run-length accumulate in the lane's "sticky" register for that node
 // (tag in bits 0-11, run length above) and only send an atomic when the run is evicted. A node related to a query matches it in
@@ -127,10 +135,10 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
 #pragma unroll
     for (int u = 0; u < JU; u++) { const uint64_t e = e0 + (uint64_t)u * JT; vn[u] = (e < n && s0 < s1) ? cols[(uint64_t)s0 * colcap + e] : (T)0; }
     for (uint32_t s = s0; s < s1; s++) {
-        __syncthreads();                                          // the previous slot's probes are done
+        join_lds_barrier();                                       // the previous slot's probes are done
         for (uint32_t i = threadIdx.x; i < P; i += JT) tag[i] = 0;
         for (uint32_t i = threadIdx.x; i < (1u << JB_LOG2) / 32; i += JT) bm[i] = 0;
-        __syncthreads();
+        join_lds_barrier();
         for (uint32_t q = threadIdx.x; q < nq; q += JT) {
             T k = qkey[(uint64_t)s * nq + q];
             if (never_equal<KIND, T>(k)) continue;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
             while (atomicCAS(&tag[h], 0u, q + 1) != 0u) h = (h + 1) & mask;
             key[h] = k;
         }
-        __syncthreads();
+        join_lds_barrier();
         const T *col = cols + (uint64_t)s * colcap;
 #pragma unroll
         for (int it = 0; it < JN / JU; it++) {
