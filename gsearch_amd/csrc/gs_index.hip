@@ -345,22 +345,22 @@ constexpr int HG = 16;            // histogram bins per H2 counter (HB / HG coun
                                   // 4.5 kB - the difference keeps three workgroups per CU up to n = 318 k, the size of the NCBI prokaryote set)
 struct DenseLds { uint64_t *T, *A, *As, *W, *N; uint32_t *Hf, *H2, *H1, *P1, *vis, *Eid, *Ecnt, *hist, *wsum; uint64_t *scal; };
 __host__ __device__ inline uint32_t dense_nblocks(uint32_t m) { return m / HB + 1; }
-__host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
+__host__ __device__ inline size_t dense_lds_bytes(uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds, uint32_t dcn = DCN)
 {
     const size_t nb = dense_nblocks(m);
-    size_t histb = 4 * ((size_t)DCN + 8); if (histb < 4 * nb) histb = 4 * nb;                   // fold histogram, aliased by P1
-    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * (DWIN + 4) + 8 * (size_t)(DCN + 4) + 64 + 4 * nb * (HB / HG / 2) /*H2*/ + 4 * nb /*H1*/ +
+    size_t histb = 4 * ((size_t)dcn + 8); if (histb < 4 * nb) histb = 4 * nb;                   // fold histogram, aliased by P1
+    return 8 * (size_t)((knbn + 1) & ~1u) + 8 * (size_t)maxdeg /*A*/ + 8 * (DWIN + 4) + 8 * (size_t)(dcn + 4) + 64 + 4 * nb * (HB / HG / 2) /*H2*/ + 4 * nb /*H1*/ +
            8 * (size_t)maxdeg /*Eid,Ecnt (aliased by As)*/ + histb + 4 * 48 + (vlds ? 4 * (size_t)((n + 31) / 32 + 1) : 4 * nb * (HB / 2));
 }
-__device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds)
+__device__ __forceinline__ DenseLds carve_dense(uint8_t *base, uint32_t m, uint32_t knbn, uint32_t maxdeg, uint64_t n, bool vlds, uint32_t dcn)
 {
     DenseLds S;
     const size_t nb = dense_nblocks(m);
-    size_t histb = 4 * ((size_t)DCN + 8); if (histb < 4 * nb) histb = 4 * nb;
+    size_t histb = 4 * ((size_t)dcn + 8); if (histb < 4 * nb) histb = 4 * nb;
     S.T = (uint64_t *)base; base += 8 * (size_t)((knbn + 1) & ~1u);
     S.A = (uint64_t *)base; base += 8 * (size_t)maxdeg;
     S.W = (uint64_t *)base; base += 8 * (DWIN + 4);       // + 3 sentinels (~0) behind the last key, so the head reads need no bounds tests
-    S.N = (uint64_t *)base; base += 8 * (size_t)(DCN + 4);
+    S.N = (uint64_t *)base; base += 8 * (size_t)(dcn + 4);
     S.scal = (uint64_t *)base; base += 64;
     S.Eid = (uint32_t *)base; S.As = (uint64_t *)base; base += 4 * (size_t)maxdeg;     // As (compaction of accepted keys) reuses Eid/Ecnt, dead by then
     S.Ecnt = (uint32_t *)base; base += 4 * (size_t)maxdeg;
@@ -481,7 +481,9 @@ __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, co
 
 // a wave-uniform value the compiler cannot prove uniform (it came through LDS): pin it to an SGPR
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-template <bool VLDS, bool PROF, int OCC>
+// ONEG: max_nb_conn > 128 (adjacency rows of up to 512 ids): all 512 lanes form ONE group that expands a candidate, then does the visited
+// hint + lookups of the next one and fetches the row of the one after - the three stages the two 256-lane halves otherwise share out
+template <bool VLDS, bool PROF, int OCC, bool ONEG>
 __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
                                                            uint32_t *__restrict__ scratch, uint32_t scratch_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
@@ -495,23 +497,25 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     uint32_t st_pops = 0, st_acc = 0;                            // work counters (workgroup-uniform): pops / accepting pops of this workgroup (< 2^32)
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
-    DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, ix.n, VLDS);
+    constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;         // capacity of N: >= 2M (an empty N takes a whole expansion), one key per lane in its merge
+    DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, ix.n, VLDS, CN);
     // adjacency row of a (wave-uniform) candidate: the node id is pinned to an SGPR so that the row base is scalar and the load takes a
     // 32-bit lane offset instead of a 64-bit per-lane pointer
-#define GS_DROW(K)                                                                                                         \
+#define GS_DROWX(K, PD, PI)                                                                                                \
     do {                                                                                                                   \
         const uint32_t rid_ = uni32(KID(K));                                                                               \
         uint32_t ho_ = hl4;                                                                                                \
         asm volatile("" : "+v"(ho_));               /* opaque lane offset: keeps the 64-bit row base scalar */            \
-        pdeg = ix.deg0[rid_];                                                                                              \
-        pid = hl < maxdeg ? *(const uint32_t *)((const uint8_t *)(ix.nbr0 + (uint64_t)rid_ * maxdeg) + ho_) : 0;          \
+        PD = ix.deg0[rid_];                                                                                                \
+        PI = hl < maxdeg ? *(const uint32_t *)((const uint8_t *)(ix.nbr0 + (uint64_t)rid_ * maxdeg) + ho_) : 0;           \
     } while (0)
+#define GS_DROW(K) GS_DROWX(K, pdeg, pid)
     // per-workgroup global scratch: the visited bitmap (VLDS = false) or the fine histogram bins (VLDS = true)
     uint32_t *vis = VLDS ? S.vis : scratch + (uint64_t)blockIdx.x * scratch_words;
     Hist3 hs; hs.Hf = VLDS ? scratch + (uint64_t)blockIdx.x * scratch_words : S.Hf; hs.H2 = S.H2; hs.H1 = S.H1;
     uint64_t *Cb[2] = {cbuf + (uint64_t)blockIdx.x * 2 * capC, cbuf + (uint64_t)blockIdx.x * 2 * capC + capC};
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t half = threadIdx.x >> 8, hl = threadIdx.x & 255, hl4 = hl * 4;
+    const uint32_t half = ONEG ? 0u : threadIdx.x >> 8, hl = ONEG ? threadIdx.x : threadIdx.x & 255, hl4 = hl * 4;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) S.scal[1] = atomicAdd(counter, 1ull);
@@ -568,6 +572,8 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         uint64_t pk = ~(uint64_t)0;                              // candidate this half holds data for
         uint32_t pid = 0, pdeg = 0, pcnt = 0, pst = 0, it = 0;   // pst: 1 = adjacency, 2 = + visited hint and lookups
         bool pclr = false;
+        uint64_t nk = ~(uint64_t)0;                              // ONEG: row fetched for the candidate after next (no hint, no lookups yet)
+        uint32_t nid = 0, ndeg = 0;
         for (;;) {
             if (headG < nG && headG - wbase >= wn) {                 // refill the LDS window of G
                 __syncthreads();
@@ -591,9 +597,10 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             else { headN++; c1 = g0 < n1 ? g0 : n1; c2 = g0 < n1 ? (g1 < n1 ? g1 : n1) : (g0 < n2 ? g0 : n2); }
             const long long p0 = PROF ? clock64() : 0;
             uint32_t id = 0, cntv = 0; bool unv = false;
-            if (half == (it & 1)) {
+            if (ONEG || half == (it & 1)) {
                 if (pk != c) {
-                    GS_DROW(c);
+                    if (ONEG && nk == c) { pid = nid; pdeg = ndeg; nk = ~(uint64_t)0; }          // its row is here, the hint stage has not seen it
+                    else GS_DROW(c);
                     pst = 1;
                 }
                 id = pid;
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                     unv = !(old & bit);
                     if (unv) cntv = (pst == 2 && pclr) ? pcnt : (uint32_t)matrow[id];   // every 2-byte lookup costs a full HBM sector: only for the unvisited
                 }
-            } else if (c1 != ~(uint64_t)0) {
+            } else if (!ONEG && c1 != ~(uint64_t)0) {
                 if (pk != c1) {
                     pk = c1; pst = 1;
                     GS_DROW(c1);
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                     }
                     pst = 2;
                 }
-            } else pk = ~(uint64_t)0;
+            } else if (!ONEG) pk = ~(uint64_t)0;
             it++;
             // one barrier per pop: every wave publishes how many of its lanes hit an unvisited node and how many of those are
             // below the worst count of a full R (dmax is INF_CNT until R is full, so "below" = "unvisited" then)
@@ -629,9 +636,24 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             if (lane == 0) ws[wv] = (uint32_t)__popcll(bal) | ((uint32_t)__popcll(balb) << 16);
             // the expanding half now fetches the adjacency of the candidate after next - issued only here, behind the wait for its own
             // lookups, so that wait does not include these loads
-            if (half != (it & 1)) {
-                pk = c2; pst = 1;
-                if (c2 != ~(uint64_t)0) GS_DROW(c2);
+            if (!ONEG) {
+                if (half != (it & 1)) {
+                    pk = c2; pst = 1;
+                    if (c2 != ~(uint64_t)0) GS_DROW(c2);
+                }
+            } else {
+                pk = c1;
+                if (c1 != ~(uint64_t)0) {
+                    if (nk == c1) {
+                        pid = nid; pdeg = ndeg; pclr = false;
+                        if (VLDS) {
+                            if (hl < pdeg) { pclr = !((vis[pid >> 5] >> (pid & 31)) & 1u); if (pclr) pcnt = matrow[pid]; }
+                            pst = 2;
+                        } else pst = 1;
+                    } else { GS_DROW(c1); pst = 1; }                 // not predicted: the row only (its lookups go direct at the expansion)
+                }
+                nk = c2;
+                if (c2 != ~(uint64_t)0) GS_DROWX(c2, ndeg, nid);
             }
             lds_barrier();
             const long long p2 = PROF ? clock64() : 0;
@@ -723,10 +745,21 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 const uint64_t a0 = S.A[0], a1 = na > 1 ? S.A[1] : ~(uint64_t)0;
                 const uint64_t n1 = a0 < c1 ? a0 : c1;
                 const uint64_t n2 = a0 < c1 ? (a1 < c1 ? a1 : c1) : (a0 < c2 ? a0 : c2);
-                const uint64_t want = half == (it & 1) ? n1 : n2;
-                if (want != ~(uint64_t)0 && pk != want) {
-                    pk = want; pst = 1;
-                    GS_DROW(want);
+                if (!ONEG) {
+                    const uint64_t want = half == (it & 1) ? n1 : n2;
+                    if (want != ~(uint64_t)0 && pk != want) {
+                        pk = want; pst = 1;
+                        GS_DROW(want);
+                    }
+                } else {
+                    if (n1 != ~(uint64_t)0 && pk != n1) {
+                        const uint64_t ok = pk; const uint32_t oid = pid, odeg = pdeg;      // the row held so far: usually the new second
+                        if (nk == n1) { pid = nid; pdeg = ndeg; }
+                        else GS_DROW(n1);
+                        pk = n1; pst = 1;
+                        nk = ok; nid = oid; ndeg = odeg;
+                    }
+                    if (n2 != ~(uint64_t)0 && nk != n2) { nk = n2; GS_DROWX(n2, ndeg, nid); }
                 }
             }
             const long long q1 = PROF ? clock64() : 0;
@@ -768,10 +801,10 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 if (nT == knbn) Tmax = S.T[knbn - 1];
             }
             // ---- N full? fold its live part into G first (rare): G' = live G u live N, dead tail dropped
-            if (nN - headN + na > (uint32_t)DCN) {
+            if (nN - headN + na > CN) {
                 const uint32_t liveN = nN - headN, liveG = nG - headG;
                 const uint64_t *NL = S.N + headN;
-                if (threadIdx.x <= liveN) S.hist[threadIdx.x] = 0;
+                for (uint32_t t = threadIdx.x; t <= liveN; t += DT) S.hist[t] = 0;
                 __syncthreads();
                 uint64_t *src = Cb[cur] + headG, *dst = Cb[cur ^ 1];
                 uint32_t alive_loc = 0;
@@ -835,6 +868,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         if (threadIdx.x == 0) { if (count_out) count_out[qi] = nT; if (evals_out) evals_out[qi] = evals; }
     }
 #undef GS_DROW
+#undef GS_DROWX
     if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], (unsigned long long)st_pops); atomicAdd(&stats[2], (unsigned long long)st_acc); }
     if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
@@ -1371,7 +1405,7 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
 static bool dense_vis_in_lds(const gs_index *ix, uint32_t knbn, uint32_t maxdeg)
 {
     const size_t cap = 160 * 1024 - 1024;
-    const size_t l = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true);
+    const size_t l = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true, maxdeg > (uint32_t)DT / 2 ? 512u : (uint32_t)DCN);
     const char *e = getenv("GS_DENSE_VIS");
     if (e && !strcmp(e, "global")) return false;
     if (e && !strcmp(e, "lds")) return l <= cap;
@@ -1384,15 +1418,18 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
     const bool vlds = dense_vis_in_lds(ix, knbn, maxdeg);
-    const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, vlds);
+    const bool oneg = maxdeg > (uint32_t)DT / 2;                       // rows of more than 256 ids: one 512-lane group instead of two halves
+    const uint32_t dcn = oneg ? 512u : (uint32_t)DCN;
+    const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, vlds, dcn);
     // three 8-wave workgroups per CU while the LDS allows it (n <= ~300 k with the bitmap in LDS): that build is capped at 80 VGPRs
     // (18 dwords spill, none on the per-pop path); the two-per-CU build (<= 128 VGPRs) takes over for larger n
     const size_t granted = round_up(lds, 1280);                       // LDS is granted in 1280-byte granules
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / granted));
+    if (oneg) per_cu = std::min<uint32_t>(per_cu, 2);                    // that build is not capped at 80 VGPRs
     if (getenv("GS_DENSE_PER_CU")) per_cu = std::max(1, std::min((int)per_cu, atoi(getenv("GS_DENSE_PER_CU"))));
     // per-workgroup global scratch: visited bitmap (vlds = false) or the fine histogram bins (vlds = true)
     const uint32_t scratch_words = vlds ? dense_nblocks(ix->prm.m) * (HB / 2) : (uint32_t)((ix->n + 31) / 32);
-    const uint32_t capC = 2 * efs + 2 * (uint32_t)DCN + maxdeg + 64;
+    const uint32_t capC = 2 * efs + 2 * dcn + maxdeg + 64;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu * per_cu);
     int rc;
     if ((rc = ensure_stats(ix))) return rc;
@@ -1406,16 +1443,17 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); prof = profbuf.as<unsigned long long>(); }
     {
     ProfScope ps(c, FAM_SEARCH);
-#define GS_LAUNCH_DSEARCH(V, P, O)                                                                                           \
+#define GS_LAUNCH_DSEARCH(V, P, O, G)                                                                                        \
     do {                                                                                                                  \
-        auto kern = k_hnsw_search_dense<V, P, O>;                                                                          \
+        auto kern = k_hnsw_search_dense<V, P, O, G>;                                                                       \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
                            ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof, ix->stats.as<unsigned long long>());  \
     } while (0)
-    if (prof) { if (vlds) GS_LAUNCH_DSEARCH(true, true, 4); else GS_LAUNCH_DSEARCH(false, true, 4); }
-    else if (per_cu >= 3) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 6); else GS_LAUNCH_DSEARCH(false, false, 6); }
-    else { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4); else GS_LAUNCH_DSEARCH(false, false, 4); }
+    if (oneg) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4, true); else GS_LAUNCH_DSEARCH(false, false, 4, true); }
+    else if (prof) { if (vlds) GS_LAUNCH_DSEARCH(true, true, 4, false); else GS_LAUNCH_DSEARCH(false, true, 4, false); }
+    else if (per_cu >= 3) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 6, false); else GS_LAUNCH_DSEARCH(false, false, 6, false); }
+    else { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4, false); else GS_LAUNCH_DSEARCH(false, false, 4, false); }
 #undef GS_LAUNCH_DSEARCH
     }
     GS_HIP_CHECK(hipGetLastError());
@@ -1437,8 +1475,8 @@ static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq,
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
-    if (mat && maxdeg <= (uint32_t)DT / 2 && efs <= 65535u && knbn <= (uint32_t)(TMAXI * DT) && ix->prm.m <= 65535u &&
-        dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, false) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
+    if (mat && maxdeg <= (uint32_t)DT && efs <= 65535u && knbn <= (uint32_t)(TMAXI * DT) && ix->prm.m <= 65535u &&
+        dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, false, maxdeg > (uint32_t)DT / 2 ? 512u : (uint32_t)DCN) <= 160 * 1024 - 1024 && !getenv("GS_DENSE_LEGACY"))
         return search_launch_dense(ix, nq, knbn, ef, mat, mat_ld, ids, dist, count, evals);
     const size_t lds = search_lds_bytes(efs, maxdeg);
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);

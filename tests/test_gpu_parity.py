@@ -571,6 +571,42 @@ def test_dense_traversal_placements_and_regimes(gpu_ctx, monkeypatch, vis, regim
         assert (want[1] == 1.0).mean() > 0.3                      # the data really is tie-heavy
 
 
+@pytest.mark.parametrize("vis", ["lds", "global"])
+@pytest.mark.parametrize("M,regime", [(160, "spread"), (140, "ties"), (200, "tiny_ef")])
+def test_dense_traversal_wide_adjacency(gpu_ctx, monkeypatch, vis, M, regime):
+    """max_nb_conn above 128 (gsearch allows -n up to 255, gsearch.rs:268): layer-0 rows of up to 510 ids are expanded by one 512-lane group
+    (k_hnsw_search_dense<..., ONEG>) instead of two 256-lane halves; same answers and evaluation counts as the oracle, and the lists
+    really are longer than 256"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_DENSE_VIS", vis)
+    m = 160
+    if regime == "ties":
+        m = 64
+        db = H.synth_sig_db(500, 12, m, 177, jlo=0.0, jhi=0.6)   # 6000 mostly unrelated rows: everything ties at distance 1, hubs collect reverse links
+        knbn, ef = 10, 600
+    elif regime == "spread":
+        db = H.synth_sig_db(3, 420, m, 178, jlo=0.02, jhi=0.98)
+        knbn, ef = 25, 700
+    else:
+        db = H.synth_sig_db(10, 110, m, 179, jlo=0.1, jhi=0.9)
+        knbn, ef = 7, 7
+    efc = 2 * M + 90                                            # extend_candidates needs efc > 2M on the device
+    oix = O.Index(np.float32, m, M, efc, seed=19)
+    oix.parallel_insert(db, batch=64)
+    hn = G.Hnsw.new(M, 100000, 16, efc, G.DistHamming(), seed=19, insert_batch=64)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    g = hn.export_graph()
+    assert np.array_equal(g["deg0"], oix.export()["deg0"])
+    if regime == "ties":
+        assert int(g["deg0"].max()) > 256                        # lanes 256..511 of the group really carry neighbours
+    q = np.concatenate([H.queries_from(db, 200, 5, frac=0.25), db[:30]])
+    got, want = hn.search_arrays(q, knbn, ef), oix.parallel_search(q, knbn, ef)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+
+
 def test_insert_with_global_visited_bitmap(gpu_ctx, monkeypatch):
     """k_hnsw_plan keeps its visited bitmap in LDS when it fits; the global-memory fallback (large n) must build the same graph"""
     import gsearch_amd as G
