@@ -483,12 +483,16 @@ __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, co
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // ONEG: max_nb_conn > 128 (adjacency rows of up to 512 ids): all 512 lanes form ONE group that expands a candidate, then does the visited
 // hint + lookups of the next one and fetches the row of the one after - the three stages the two 256-lane halves otherwise share out
-template <bool VLDS, bool PROF, int OCC, bool ONEG>
+// WLOG (insert-time pre-pass): every accepted key is also appended to a per-workgroup log; R is always "the ef smallest
+// accepted keys", so at the end of the query the log, cut at dmax and sorted, IS the sorted result set W of search_layer - which the
+// histogram form of R never materialises. Queries flagged in `skip` are left to the caller.
+template <bool VLDS, bool PROF, int OCC, bool ONEG, bool WLOG>
 __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
                                                            uint32_t *__restrict__ scratch, uint32_t scratch_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
                                                            uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out, unsigned long long *__restrict__ prof,
-                                                           unsigned long long *__restrict__ stats)
+                                                           unsigned long long *__restrict__ stats, uint64_t *__restrict__ wlog, uint32_t cap_log, uint32_t sort_cap,
+                                                           uint64_t *__restrict__ w_out, uint32_t *__restrict__ w_n, const uint32_t *__restrict__ ep_in)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t maxdeg = 2 * ix.M;
@@ -522,6 +526,8 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         __syncthreads();
         const uint64_t qi = S.scal[1];
         if (qi >= nq) break;
+        uint64_t *wl = WLOG ? wlog + (uint64_t)blockIdx.x * cap_log : nullptr;
+        uint32_t nlog = 1;
         const uint16_t *matrow = mat + qi * mat_ld;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
         for (uint32_t w = threadIdx.x; w < hwords; w += DT) hs.Hf[w] = 0;
@@ -529,8 +535,12 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         for (uint32_t w = threadIdx.x; w < nb; w += DT) S.H1[w] = 0;
         uint32_t evals = 1;                                      // <= n + upper-layer hops
         uint32_t ep = (uint32_t)ix.entry, ep_cnt = matrow[ep];
+        // WLOG: the caller may hand the layer-0 entry point over (a point of level > 0 enters layer 0 where its layer-1 search ended);
+        // its evaluations above layer 0 are the caller's to count
+        const bool given = WLOG && ep_in && ep_in[qi] != 0xFFFFFFFFu;
+        if (given) { ep = ep_in[qi]; ep_cnt = matrow[ep]; evals = 0; }
         // greedy descent on the upper layers (hnsw_rs::search outer loop)
-        for (int L = ix.top; L >= 1; L--) {
+        for (int L = given ? 0 : ix.top; L >= 1; L--) {
             for (;;) {
                 const uint32_t *nbr; uint32_t deg;
                 node_neighbours(ix, ep, L, nbr, deg);
@@ -556,6 +566,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         if (threadIdx.x < 3) { S.W[threadIdx.x] = ~(uint64_t)0; S.N[1 + threadIdx.x] = ~(uint64_t)0; }
         if (threadIdx.x == 0) {
             S.T[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
+            if (WLOG) wl[0] = KEY(ep_cnt, ep);
             hist_add<VLDS>(hs, ep_cnt, 1);
             if (VLDS) vis[ep >> 5] = 1u << (ep & 31);
             else __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -740,6 +751,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 }
                 lds_barrier();
             }
+            if (WLOG) { if (nlog + na <= cap_log && threadIdx.x < na) wl[nlog + threadIdx.x] = S.A[threadIdx.x]; nlog += na; }
             {   // the candidate order has changed: start loading the adjacency of the two candidates that now come first
                 // (first two of merge(A, {c1, c2})) so that the loads overlap with the rest of the merge
                 const uint64_t a0 = S.A[0], a1 = na > 1 ? S.A[1] : ~(uint64_t)0;
@@ -861,11 +873,47 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const long long q4 = clock64(); t_e += q4 - p4; tq1 += q1 - p4; tq2 += q2 - q1; tq3 += q3 - q2; tq4 += q4 - q3; tna += na; }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
+        if (ids_out) for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
             if (i < nT) { ids_out[qi * knbn + i] = KID(S.T[i]); dist_out[qi * knbn + i] = (float)KCNT(S.T[i]) / (float)ix.m; }
             else { ids_out[qi * knbn + i] = ~(uint64_t)0; dist_out[qi * knbn + i] = INFINITY; }
         }
         if (threadIdx.x == 0) { if (count_out) count_out[qi] = nT; if (evals_out) evals_out[qi] = evals; }
+        if (WLOG) {
+            // W = the efs smallest keys of the log: cut it at dmax (INF_CNT while R never filled), sort what is left in LDS (the search
+            // arrays are dead), keep the first efs. Anything that does not fit is flagged and redone by the caller the slow way.
+            uint64_t *buf = (uint64_t *)s_raw + 8;
+            uint32_t *cntp = (uint32_t *)s_raw;
+            if (threadIdx.x == 0) cntp[0] = 0;
+            __syncthreads();
+            bool bad = nlog > cap_log;
+            if (!bad) for (uint32_t i = threadIdx.x; i < nlog; i += DT) {
+                const uint64_t k = wl[i];
+                if (KCNT(k) <= dmax) { const uint32_t pos = atomicAdd(&cntp[0], 1u); if (pos < sort_cap) buf[pos] = k; }
+            }
+            __syncthreads();
+            const uint32_t cnt = cntp[0];
+            if (cnt > sort_cap) bad = true;
+            if (bad) { if (threadIdx.x == 0) w_n[qi] = 0xFFFFFFFFu; }
+            else {
+                uint32_t n2 = 2; while (n2 < cnt) n2 <<= 1;
+                for (uint32_t i = cnt + threadIdx.x; i < n2; i += DT) buf[i] = ~(uint64_t)0;
+                __syncthreads();
+                for (uint32_t kk = 2; kk <= n2; kk <<= 1)
+                    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                        for (uint32_t i = threadIdx.x; i < n2; i += DT) {
+                            const uint32_t l = i ^ j;
+                            if (l > i) {
+                                const uint64_t a = buf[i], b = buf[l];
+                                if ((a > b) == ((i & kk) == 0)) { buf[i] = b; buf[l] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                const uint32_t nW = cnt < efs ? cnt : efs;
+                for (uint32_t i = threadIdx.x; i < nW; i += DT) w_out[qi * efs + i] = buf[i];
+                if (threadIdx.x == 0) w_n[qi] = nW;
+            }
+        }
     }
 #undef GS_DROW
 #undef GS_DROWX
@@ -940,6 +988,35 @@ constexpr int PLAN_CH1 = 32;
 
 // Malkov alg. 4 as hnsw_rs::select_neighbours applies it (SPEC 5). Candidates = S.R[0..nW) ascending;
 // accepted keys end up in S.A[0..na) ascending. `heuristic == false` -> take all (|W| <= deg, no extension).
+// one candidate of the neighbour-selection heuristic against the na keys selected so far, by streaming signature rows (pairs the
+// pair cache does not hold): true = no selected s has c(e,s) <= c(x,e)
+template <int KIND>
+__device__ __forceinline__ bool select_check_rows(const IndexDev &ix, const SearchLds &S, uint64_t e, uint32_t na, uint64_t &evals)
+{
+    const uint32_t maxdeg = 2 * ix.M;
+    const uint4 *erow = (const uint4 *)(ix.data + (uint64_t)KID(e) * ix.stride);
+    bool accept = true;
+    uint32_t ch = PLAN_CH0;
+    for (uint32_t s0 = 0; s0 < na && accept; ) {
+        uint32_t nch = na - s0 < ch ? na - s0 : ch;
+        if (nch > maxdeg) nch = maxdeg;
+        if (threadIdx.x < nch) S.Eid[threadIdx.x] = KID(S.A[s0 + threadIdx.x]);
+        __syncthreads();
+        block_distances<KIND>(ix, erow, S.Eid, nch, S.Ecnt);
+        evals += nch;
+        bool conflict = false;
+        for (uint32_t t = 0; t < nch; t++) conflict |= (S.Ecnt[t] <= KCNT(e));
+        __syncthreads();
+        if (conflict) accept = false;
+        s0 += nch; ch = PLAN_CH1;
+    }
+    return accept;
+}
+// hnsw_rs select_neighbours (SPEC 5): walk W in ascending order, keep e iff no kept s has c(e,s) <= c(x,e), stop at deg. With the pair
+// cache the walk takes the candidates SEL_CH at a time: every lane that owns a kept key looks the chunk's candidates up at once (one
+// memory round trip and two barriers per chunk instead of per candidate); the chunk ends at its first accepted candidate - the ones
+// behind it have to see the new member - so the result is the sequential one.
+constexpr int SEL_CH = 8;
 template <int KIND>
 __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const SearchLds &S, uint32_t nW, uint32_t deg, bool heuristic, uint64_t &evals)
 {
@@ -948,60 +1025,80 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
         __syncthreads();
         return nW;
     }
-    const uint32_t maxdeg = 2 * ix.M;
-    uint32_t na = 0;
-    for (uint32_t i = 0; i < nW && na < deg; i++) {
-        const uint64_t e = S.R[i];
-        bool accept = true;
-        if (na > 0) {
-            if (KCNT(e) >= ix.m) accept = false;        // c(e,s) <= m = c(x,e) for every s: always pruned
-            else if (ix.rowptr && na <= ST) {
-                // pair cache: c(e,s) of two existing nodes was computed when the younger one was inserted
-                int conflict = 0, miss = 0;
-                if (threadIdx.x < na) {
-                    const uint32_t sid = KID(S.A[threadIdx.x]), eid = KID(e);
-                    const uint32_t hi = sid > eid ? sid : eid, lo = sid > eid ? eid : sid;
-                    const uint16_t *row = (const uint16_t *)ix.rowptr[hi];
-                    if (row) conflict = (uint32_t)row[lo] <= KCNT(e); else miss = 1;
-                }
-                const int any_miss = __syncthreads_or(miss);
-                if (!any_miss) { evals += na; if (__syncthreads_or(conflict)) accept = false; }
-                else {
-                    const uint4 *erow = (const uint4 *)(ix.data + (uint64_t)KID(e) * ix.stride);
-                    uint32_t ch = PLAN_CH0;
-                    for (uint32_t s0 = 0; s0 < na && accept; ) {
-                        uint32_t nch = na - s0 < ch ? na - s0 : ch;
-                        if (nch > maxdeg) nch = maxdeg;
-                        if (threadIdx.x < nch) S.Eid[threadIdx.x] = KID(S.A[s0 + threadIdx.x]);
-                        __syncthreads();
-                        block_distances<KIND>(ix, erow, S.Eid, nch, S.Ecnt);
-                        evals += nch;
-                        bool cf = false;
-                        for (uint32_t t = 0; t < nch; t++) cf |= (S.Ecnt[t] <= KCNT(e));
-                        __syncthreads();
-                        if (cf) accept = false;
-                        s0 += nch; ch = PLAN_CH1;
-                    }
-                }
-            } else {
-                const uint4 *erow = (const uint4 *)(ix.data + (uint64_t)KID(e) * ix.stride);
-                uint32_t ch = PLAN_CH0;
-                for (uint32_t s0 = 0; s0 < na && accept; ) {
-                    uint32_t nch = na - s0 < ch ? na - s0 : ch;
-                    if (nch > maxdeg) nch = maxdeg;
-                    if (threadIdx.x < nch) S.Eid[threadIdx.x] = KID(S.A[s0 + threadIdx.x]);
-                    __syncthreads();
-                    block_distances<KIND>(ix, erow, S.Eid, nch, S.Ecnt);
-                    evals += nch;
-                    bool conflict = false;
-                    for (uint32_t t = 0; t < nch; t++) conflict |= (S.Ecnt[t] <= KCNT(e));
-                    __syncthreads();
-                    if (conflict) accept = false;
-                    s0 += nch; ch = PLAN_CH1;
+    uint32_t na = 0, i = 0;
+    uint32_t *orw = (uint32_t *)&S.scal[4];
+    while (i < nW && na < deg) {
+        if (na == 0) { if (threadIdx.x == 0) S.A[0] = S.R[i]; na = 1; i++; __syncthreads(); continue; }
+        if (!(ix.rowptr && na <= ST)) {                                   // no pair cache: one candidate at a time, rows streamed
+            const uint64_t e = S.R[i];
+            const bool accept = KCNT(e) < ix.m && select_check_rows<KIND>(ix, S, e, na, evals);
+            if (accept) { if (threadIdx.x == 0) S.A[na] = e; na++; __syncthreads(); }
+            i++;
+            continue;
+        }
+        const uint32_t nc = nW - i < (uint32_t)SEL_CH ? nW - i : (uint32_t)SEL_CH;
+        uint32_t fr = 0;                                                  // c(x,e) = m: c(e,s) <= m for every s, always pruned
+#pragma unroll
+        for (int j = 0; j < SEL_CH; j++) if ((uint32_t)j < nc && KCNT(S.R[i + j]) >= ix.m) fr |= 1u << j;
+        uint32_t cm = 0, pm = 0;                                          // cm: bit j = conflict with my kept key, bit 16 + j = that pair is not cached
+        if (threadIdx.x < na) {
+            const uint32_t sid = KID(S.A[threadIdx.x]);
+            const uint16_t *row[SEL_CH]; uint32_t lo[SEL_CH];
+#pragma unroll
+            for (int j = 0; j < SEL_CH; j++) {
+                row[j] = nullptr; lo[j] = 0;
+                if ((uint32_t)j < nc && !((fr >> j) & 1u)) {
+                    const uint32_t eid = KID(S.R[i + j]);
+                    const uint32_t hi = sid > eid ? sid : eid;
+                    lo[j] = sid > eid ? eid : sid;
+                    row[j] = (const uint16_t *)ix.rowptr[hi];
+                    if (!row[j]) cm |= 1u << (16 + j);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < SEL_CH; j++) if (row[j] && (uint32_t)row[j][lo[j]] <= KCNT(S.R[i + j])) cm |= 1u << j;
+        } else if (threadIdx.x - na < (uint32_t)(SEL_CH * (SEL_CH - 1) / 2)) {
+            // the pairs INSIDE the chunk (j > k): candidate j must also clear the candidates of the chunk that are kept before it.
+            // pm: bit (j * (j - 1) / 2 + k) = c(e_j, e_k) <= c(x, e_j); a pair that is not cached counts as "e_j not cached" (bit 16 + j)
+            uint32_t t = threadIdx.x - na, j = 1;
+            while (t >= j) { t -= j; j++; }
+            const uint32_t k = t;
+            if (j < nc && !((fr >> j) & 1u) && !((fr >> k) & 1u)) {
+                const uint32_t ej = KID(S.R[i + j]), ek = KID(S.R[i + k]);
+                const uint32_t hi = ej > ek ? ej : ek, lo2 = ej > ek ? ek : ej;
+                const uint16_t *row = (const uint16_t *)ix.rowptr[hi];
+                if (!row) cm |= 1u << (16 + j);
+                else if ((uint32_t)row[lo2] <= KCNT(S.R[i + j])) pm |= 1u << (j * (j - 1) / 2 + k);
+            }
         }
-        if (accept) { if (threadIdx.x == 0) S.A[na] = e; na++; __syncthreads(); }
+        if (threadIdx.x == 0) { orw[0] = 0; orw[1] = 0; }
+        __syncthreads();
+        if (cm) atomicOr(&orw[0], cm);
+        if (pm) atomicOr(&orw[1], pm);
+        __syncthreads();
+        const uint32_t v = orw[0], pv = orw[1];
+        // resolve the chunk in order (every lane does the same arithmetic)
+        uint32_t kept = 0, j = 0, nacc = 0;
+        bool slow = false;
+        for (; j < nc && na + nacc < deg; j++) {
+            if ((fr >> j) & 1u) continue;
+            if ((v >> (16 + j)) & 1u) { slow = true; break; }            // some pair of this candidate is not cached: check it the slow way
+            evals += na + nacc;
+            bool ok = !((v >> j) & 1u);
+            const uint32_t prow = (pv >> (j * (j - 1) / 2)) & ((1u << j) - 1u);       // conflicts of j with the earlier candidates of the chunk
+            if (ok && (prow & kept)) ok = false;
+            if (ok) { kept |= 1u << j; nacc++; }
+        }
+        // append the kept ones in order
+        if (threadIdx.x == 0) { uint32_t w = na; for (uint32_t q = 0; q < j; q++) if ((kept >> q) & 1u) S.A[w++] = S.R[i + q]; }
+        na += nacc;
+        if (slow) {
+            __syncthreads();
+            const uint64_t e = S.R[i + j];
+            if (select_check_rows<KIND>(ix, S, e, na, evals)) { if (threadIdx.x == 0) S.A[na] = e; na++; }
+            i += j + 1;
+        } else i += j;
+        __syncthreads();
     }
     return na;
 }
@@ -1010,14 +1107,20 @@ template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint32_t nb, const uint8_t *__restrict__ blevels,
                                                    const uint32_t *__restrict__ cntmat, const uint16_t *__restrict__ mat, uint64_t mat_ld, uint32_t efc, uint32_t ef_lds, int extend,
                                                    uint32_t *__restrict__ visited, uint32_t vis_words, int vis_in_lds, uint64_t *__restrict__ plan_keys,
-                                                   uint32_t *__restrict__ plan_n, unsigned long long *__restrict__ evals_total)
+                                                   uint32_t *__restrict__ plan_n, unsigned long long *__restrict__ evals_total,
+                                                   const uint64_t *__restrict__ w0_keys, const uint32_t *__restrict__ w0_n, const uint64_t *__restrict__ w0_evals,
+                                                   int phase, uint32_t *__restrict__ ep0)
 {
+    // phase 0: the whole plan of a point in one launch. With the pre-pass (plan_prepass) the work is split: phase 1 = the layers above 0
+    // of the points that have any (it leaves the layer-0 entry point in ep0), then the pre-pass works W out for every point, then
+    // phase 2 = layer 0 (selection on W; the sorted-array search only for the points the pre-pass flagged)
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t maxdeg = 2 * ix.M;
     SearchLds S = carve_lds(s_raw, ef_lds, maxdeg);
     const uint32_t i = blockIdx.x;
     const uint64_t id = b0 + i;
     const int lv = blevels[i];
+    if (phase == 1 && lv == 0) return;
     const uint4 *q = (const uint4 *)(ix.data + id * ix.stride);
     // visited bitmap: in LDS behind the search arrays when it fits (a bitmap in global memory costs an L2 atomic per neighbour and
     // thrashes the L2), else this workgroup's slice of the global scratch
@@ -1026,7 +1129,12 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
     const bool have_graph = ix.n > 0;
     const uint16_t *matrow = mat ? mat + (uint64_t)i * mat_ld : nullptr;
     uint32_t ep = 0, ep_cnt = 0;
-    if (have_graph) {
+    // a level-0 point whose layer-0 result set W the pre-pass (k_hnsw_search_dense<.., WLOG>) has already worked out: entry point,
+    // greedy descent and search_layer are done; only the selection remains
+    const bool pre = phase == 2 && have_graph && w0_n[i] != 0xFFFFFFFFu;
+    if (have_graph && phase == 2 && lv > 0 && ep0[i] != 0xFFFFFFFFu) {
+        if (!pre) { ep = ep0[i]; ep_cnt = matrow[ep]; }           // flagged by the pre-pass: search layer 0 here, from where layer 1 ended
+    } else if (have_graph && !pre) {
         if (threadIdx.x == 0) S.Eid[0] = (uint32_t)ix.entry;
         __syncthreads();
         block_distances<KIND>(ix, q, S.Eid, 1, S.Ecnt, matrow);
@@ -1035,9 +1143,14 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
         for (int L = ix.top; L > lv; L--) greedy_layer_block<KIND>(ix, q, S, ep, ep_cnt, L, evals, matrow);
     }
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int L = lv; L >= 0; L--) {
+    for (int L = phase == 2 ? 0 : lv; L >= (phase == 1 ? 1 : 0); L--) {
         uint32_t nW = 0;
-        if (have_graph && L <= ix.top) {
+        if (pre) {
+            nW = w0_n[i];
+            for (uint32_t t = threadIdx.x; t < nW; t += ST) S.R[t] = w0_keys[(uint64_t)i * efc + t];
+            evals += w0_evals[i];
+            __syncthreads();
+        } else if (have_graph && L <= ix.top) {
             for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
             __syncthreads();
             nW = search_layer_block<KIND>(ix, q, S, vis, ep, ep_cnt, efc, L, evals, matrow);
@@ -1070,9 +1183,16 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
         if (threadIdx.x == 0) plan_n[(uint64_t)i * ix.max_layer + (uint32_t)L] = na;
         __syncthreads();
     }
+    if (phase == 1 && threadIdx.x == 0) ep0[i] = have_graph ? ep : 0xFFFFFFFFu;      // where this point enters layer 0
     if (threadIdx.x == 0) atomicAdd(evals_total, (unsigned long long)evals);
 }
 
+// pair cache rows of the nodes that were inserted before the cache existed: rowptr[a] -> row a of an all-pairs count matrix
+__global__ void k_set_rowptr(uint16_t *__restrict__ base, uint64_t ld, uint64_t n, uint64_t *__restrict__ rowptr)
+{
+    const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < n && rowptr[a] == 0) rowptr[a] = (uint64_t)(base + a * ld);
+}
 // pair cache rows of one dense batch: columns [0,b0) come from the tile kernel, [b0,b0+nb) from the mates matrix
 __global__ void k_cache_rows(uint16_t *__restrict__ rowbase, uint64_t ld, uint64_t b0, uint32_t nb, const uint32_t *__restrict__ cntmat, uint64_t *__restrict__ rowptr)
 {
@@ -1185,6 +1305,7 @@ struct gs_index {
     gs::DevBuf visited, counter, cbuf;
     // insert scratch
     gs::DevBuf blevels, cntmat, plan_keys, plan_n, inbox, inbox_cnt, touched, ntouched, evals_dev;
+    gs::DevBuf wlog, w0_keys, w0_n, w0_evals, ep0; // insert pre-pass (plan_prepass)
     uint64_t inbox_lists = 0;
     uint64_t insert_evals = 0;
     // dense mode: count matrix of a query / insert batch against every node, and the running
@@ -1201,6 +1322,7 @@ struct gs_index {
     gs::DevBuf rowptr;
     std::vector<gs::DevBuf *> slabs;
     uint64_t pair_cache_bytes = 0, pair_cache_budget = 0;
+    bool early_cached = false;        // the nodes older than the first cached batch have all-pairs rows (insert_common)
     ~gs_index() { for (auto *b : slabs) delete b; }
 };
 
@@ -1218,7 +1340,7 @@ static void drop_pair_cache(gs_index *ix)
         for (auto *b : ix->slabs) delete b;
         ix->slabs.clear();
     }
-    ix->pair_cache_bytes = 0; ix->pair_cache_budget = 1;
+    ix->pair_cache_bytes = 0; ix->pair_cache_budget = 1; ix->early_cached = false;
 }
 // DevBuf::alloc that pays with the pair cache when the device is full
 static int alloc_or_evict(gs_index *ix, DevBuf &b, size_t bytes)
@@ -1445,10 +1567,11 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     ProfScope ps(c, FAM_SEARCH);
 #define GS_LAUNCH_DSEARCH(V, P, O, G)                                                                                        \
     do {                                                                                                                  \
-        auto kern = k_hnsw_search_dense<V, P, O, G>;                                                                       \
+        auto kern = k_hnsw_search_dense<V, P, O, G, false>;                                                                \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
-                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof, ix->stats.as<unsigned long long>());  \
+                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof, ix->stats.as<unsigned long long>(),  \
+                           (uint64_t *)nullptr, 0u, 0u, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);  \
     } while (0)
     if (oneg) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4, true); else GS_LAUNCH_DSEARCH(false, false, 4, true); }
     else if (prof) { if (vlds) GS_LAUNCH_DSEARCH(true, true, 4, false); else GS_LAUNCH_DSEARCH(false, true, 4, false); }
@@ -1783,6 +1906,63 @@ static int gen_level_host(const gs_index *ix, uint64_t id)
     return l;
 }
 
+// Layer-0 search of an insert batch through the dense traversal kernel: queries = the batch's rows (their counts
+// against every node are in `mat`), ef = ef_construction, one accepted-key log per resident workgroup; points of level > 0 (their
+// entry point comes out of an ef-search on layer 1, not of the greedy descent) are skipped and keep the sorted-array search inside
+// k_hnsw_plan. Leaves the device pointers of W (efc keys per point, sorted), |W| (0xFFFFFFFF = not done) and the evaluation counts.
+namespace gs {
+static bool prepass_ok(const gs_index *ix, uint32_t efc)
+{
+    const uint32_t maxdeg = 2 * ix->prm.max_nb_conn, knbn = 1;
+    if (getenv("GS_PLAN_PREPASS") && !atoi(getenv("GS_PLAN_PREPASS"))) return false;
+    if (ix->n < 4096 || ix->entry < 0 || maxdeg > (uint32_t)DT / 2 || efc > 65535u || efc < 2 || ix->prm.m > 65535u) return false;
+    if (!dense_vis_in_lds(ix, knbn, maxdeg)) return false;                       // WLOG is only instantiated for the LDS bitmap
+    uint32_t sort_cap = 2; while (sort_cap < 4 * efc) sort_cap <<= 1;
+    return std::max<size_t>(dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true), (size_t)8 * sort_cap + 64) <= 160 * 1024 - 1024;
+}
+static int plan_prepass(gs_index *ix, uint32_t nb, uint32_t efc, const uint16_t *mat, uint64_t mat_ld, const uint64_t **w0k, const uint32_t **w0n, const uint64_t **w0e)
+{
+    gs_ctx *c = ix->ctx;
+    *w0k = nullptr; *w0n = nullptr; *w0e = nullptr;
+    const uint32_t maxdeg = 2 * ix->prm.max_nb_conn, knbn = 1;
+    uint32_t sort_cap = 2; while (sort_cap < 4 * efc) sort_cap <<= 1;             // keys the epilogue can sort: ties at dmax ride along
+    size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true);
+    lds = std::max<size_t>(lds, (size_t)8 * sort_cap + 64);
+    const size_t granted = round_up(lds, 1280);
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / granted));
+    const uint32_t scratch_words = dense_nblocks(ix->prm.m) * (HB / 2);
+    const uint32_t capC = 2 * efc + 2 * (uint32_t)DCN + maxdeg + 64, cap_log = 16 * efc;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nb, (uint64_t)c->n_cu * per_cu);
+    int rc;
+    if ((rc = ensure_stats(ix))) return rc;
+    if ((rc = ix->visited.ensure((size_t)4 * scratch_words * c->n_cu * 3))) return rc;
+    if ((rc = ix->cbuf.ensure((size_t)16 * capC * c->n_cu * 3))) return rc;
+    if ((rc = ix->counter.ensure(64))) return rc;
+    if ((rc = ix->wlog.ensure((size_t)8 * cap_log * grid))) return rc;
+    if ((rc = ix->w0_keys.ensure((size_t)8 * efc * nb))) return rc;
+    if ((rc = ix->w0_n.ensure((size_t)4 * nb))) return rc;
+    if ((rc = ix->w0_evals.ensure((size_t)8 * nb))) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
+    IndexDev d = index_dev(ix);
+    {   // (inside the caller's FAM_INSERT profiling scope)
+#define GS_LAUNCH_WL(O)                                                                                                   \
+    do {                                                                                                                  \
+        auto kern = k_hnsw_search_dense<true, false, O, false, true>;                                                     \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, (uint64_t)nb, knbn, efc, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
+                           ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), (uint64_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr, \
+                           ix->w0_evals.as<uint64_t>(), (unsigned long long *)nullptr, (unsigned long long *)nullptr, ix->wlog.as<uint64_t>(), cap_log, sort_cap, \
+                           ix->w0_keys.as<uint64_t>(), ix->w0_n.as<uint32_t>(), ix->ep0.as<uint32_t>());                      \
+    } while (0)
+        if (per_cu >= 3) GS_LAUNCH_WL(6); else GS_LAUNCH_WL(4);
+#undef GS_LAUNCH_WL
+    }
+    GS_HIP_CHECK(hipGetLastError());
+    *w0k = ix->w0_keys.as<uint64_t>(); *w0n = ix->w0_n.as<uint32_t>(); *w0e = ix->w0_evals.as<uint64_t>();
+    return GS_OK;
+}
+}  // namespace gs
+
 static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n)
 {
     GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
@@ -1892,6 +2072,19 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
                     if (slab->alloc(need) != GS_OK) { delete slab; slab = nullptr; }
                     else { ix->slabs.push_back(slab); ix->pair_cache_bytes += need; slab_first = b0; }
                 }
+                // the nodes inserted before the first cached batch (the first 4096 in auto mode) have no rows of their own: a pair of two
+                // of them would send the selection heuristic back to streaming 2M signature rows per candidate - 5 % of the candidates,
+                // most of its time. One all-pairs tile pass (b0^2 counts, 32 MB at 4096) closes the hole.
+                if (slab && !ix->early_cached && b0 > 0 && b0 <= 16384) {
+                    const uint64_t eld = gs::round_up(b0, 8), ebytes = b0 * eld * 2;
+                    gs::DevBuf *early = new gs::DevBuf();
+                    if (ix->pair_cache_bytes + ebytes <= ix->pair_cache_budget && early->alloc(ebytes) == GS_OK) {
+                        if ((rc = gs::hamming_qxc_strided(c, ix->ikind, ix->prm.m, ix->data.p, b0, ix->stride, ix->data.p, b0, ix->stride, nullptr, nullptr, early->as<uint16_t>(), eld))) { delete early; return rc; }
+                        hipLaunchKernelGGL(gs::k_set_rowptr, dim3((uint32_t)((b0 + 255) / 256)), dim3(256), 0, c->stream, early->as<uint16_t>(), eld, b0, ix->rowptr.as<uint64_t>());
+                        GS_HIP_CHECK(hipGetLastError());
+                        ix->slabs.push_back(early); ix->pair_cache_bytes += ebytes; ix->early_cached = true;
+                    } else delete early;
+                }
             }
             uint16_t *out16;
             if (slab) { out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld; mat_ld = slab_ld; }
@@ -1904,6 +2097,13 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             matp = out16;
         }
         if (b0 >= 4096) { seg_den += (double)nb * (double)b0; seg_batches++; }
+        // pre-pass: the layer-0 search of the batch's level-0 points through the dense traversal kernel (accepted-key log -> W)
+        const uint64_t *w0k = nullptr, *w0e = nullptr; const uint32_t *w0n = nullptr;
+        const bool pp = matp && gs::prepass_ok(ix, efc);
+        if (pp) {
+            if ((rc = ix->ep0.ensure((size_t)4 * B))) return rc;
+            GS_HIP_CHECK(hipMemsetAsync(ix->ep0.p, 0xFF, (size_t)4 * nb, c->stream));
+        }
         const size_t lds_vis = ((lds + 15) & ~(size_t)15) + (size_t)4 * vw;
         const int vis_in_lds = lds_vis <= 160 * 1024 - 1024 && !getenv("GS_PLAN_VIS_GLOBAL");
         const size_t lds_plan = vis_in_lds ? lds_vis : lds;
@@ -1915,11 +2115,28 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan));  \
         hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds_plan, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), matp, mat_ld, efc, ef_lds, \
                            ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, vis_in_lds, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
-                           ix->evals_dev.as<unsigned long long>());                                                        \
+                           ix->evals_dev.as<unsigned long long>(), w0k, w0n, w0e, phase, ix->ep0.as<uint32_t>());          \
     } while (0)
-            if (ix->ikind == GS_KIND_F32) GS_LAUNCH_PLAN(GS_KIND_F32);
-            else if (ix->ikind == GS_KIND_U32) GS_LAUNCH_PLAN(GS_KIND_U32);
-            else GS_LAUNCH_PLAN(GS_KIND_U64);
+#define GS_LAUNCH_PLAN_KIND()                                                                                              \
+    do { if (ix->ikind == GS_KIND_F32) GS_LAUNCH_PLAN(GS_KIND_F32); else if (ix->ikind == GS_KIND_U32) GS_LAUNCH_PLAN(GS_KIND_U32); else GS_LAUNCH_PLAN(GS_KIND_U64); } while (0)
+            int phase = 0;
+            if (!pp) GS_LAUNCH_PLAN_KIND();
+            else {
+                phase = 1; GS_LAUNCH_PLAN_KIND();                  // layers above 0 of the few points that have any
+                GS_HIP_CHECK(hipGetLastError());
+                if ((rc = gs::plan_prepass(ix, nb, efc, matp, mat_ld, &w0k, &w0n, &w0e))) return rc;
+                if (getenv("GS_PLAN_DEBUG") && (b0 / B) % 100 == 0) {
+                    std::vector<uint32_t> hw(nb); std::vector<uint64_t> he(nb);
+                    (void)hipMemcpyAsync(hw.data(), w0n, 4 * nb, hipMemcpyDeviceToHost, c->stream);
+                    (void)hipMemcpyAsync(he.data(), w0e, 8 * nb, hipMemcpyDeviceToHost, c->stream);
+                    (void)hipStreamSynchronize(c->stream);
+                    uint32_t fl = 0, mn = ~0u, mx = 0; double ev = 0;
+                    for (uint32_t t = 0; t < nb; t++) { if (hw[t] == 0xFFFFFFFFu) fl++; else { mn = std::min(mn, hw[t]); mx = std::max(mx, hw[t]); ev += (double)he[t]; } }
+                    fprintf(stderr, "[GS_PLAN_DEBUG] b0=%llu: %u of %u flagged, |W| %u..%u, mean evals %.0f\n", (unsigned long long)b0, fl, nb, mn, mx, ev / std::max(1u, nb - fl));
+                }
+                phase = 2; GS_LAUNCH_PLAN_KIND();                  // selection on the W the pre-pass worked out
+            }
+#undef GS_LAUNCH_PLAN_KIND
 #undef GS_LAUNCH_PLAN
         }
         GS_HIP_CHECK(hipGetLastError());

@@ -607,6 +607,33 @@ def test_dense_traversal_wide_adjacency(gpu_ctx, monkeypatch, vis, M, regime):
     assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
 
 
+@pytest.mark.parametrize("dtype,M,efc,scale", [(np.float32, 12, 60, 1.0), (np.uint32, 8, 40, 0.5)])
+def test_insert_prepass_builds_the_oracle_graph(gpu_ctx, monkeypatch, dtype, M, efc, scale):
+    """past 4096 nodes a dense-mode insert batch takes its layer-0 searches through the dense traversal kernel (accepted-key log ->
+    sorted result set W, plan_prepass) and k_hnsw_plan runs in two phases around it; the graph must still be the oracle's, level > 0
+    points included (scale 1.0 gives plenty), and the same as with GS_PLAN_PREPASS=0"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    m = 64
+    db = H.synth_sig_db(130, 50, m, 321, jlo=0.05, jhi=0.9).astype(dtype)
+    oix = O.Index(dtype, m, M, efc, scale_modify=scale, seed=4)
+    oix.parallel_insert(db, batch=256)
+    og = oix.export()
+    graphs = []
+    for pre in ("1", "0"):
+        monkeypatch.setenv("GS_PLAN_PREPASS", pre)
+        hn = G.Hnsw.new(M, 100000, 16, efc, G.DistHamming(), seed=4, insert_batch=256)
+        hn.modify_level_scale(scale); hn.set_extend_candidates(True)
+        hn.parallel_insert(db)
+        graphs.append(hn.export_graph())
+    for g in graphs:
+        assert np.array_equal(g["levels"], og["levels"]) and np.array_equal(g["deg0"], og["deg0"])
+        for i in range(len(db)):
+            d = int(og["deg0"][i])
+            assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d])
+    assert (og["levels"][4096:] > 0).sum() >= 3
+
+
 def test_insert_with_global_visited_bitmap(gpu_ctx, monkeypatch):
     """k_hnsw_plan keeps its visited bitmap in LDS when it fits; the global-memory fallback (large n) must build the same graph"""
     import gsearch_amd as G
