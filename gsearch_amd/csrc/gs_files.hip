@@ -163,6 +163,7 @@ static int read_fasta(const char *path, Bytes &text)
 struct FileBlob {       // one file after the host stage
     Bytes text;                           // decompressed text of a compressed file (plain files are read straight into the pinned buffer)
     uint8_t *dst = nullptr; size_t dst_cap = 0, dst_len = 0;    // where a plain file goes (pinned) and how much of it was filled
+    uint8_t *src = nullptr; size_t src_cap = 0;                 // .gz: where the compressed bytes are read to (a per-slot buffer: no per-file allocation)
     std::vector<uint64_t> sb, se; int rc = GS_OK; std::string err; double read_s = 0;
 };
 static bool has_compressed_suffix(const char *path)
@@ -194,9 +195,17 @@ static void host_stage(const char *path, FileBlob *b)
     const uint8_t *text = nullptr; size_t n = 0;
     bool direct = b->dst != nullptr;
     if (direct && has_compressed_suffix(path)) {                   // .gz sized from its trailer: inflate straight into the pinned buffer
-        Bytes raw; size_t produced = 0;
-        direct = read_whole_file(path, raw) == GS_OK && raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b &&
-                 inflate_gzip_into(raw.data(), raw.size(), b->dst, b->dst_cap, &produced) == 1;
+        size_t produced = 0, got = 0;
+        direct = false;
+        if (b->src) {
+            FILE *f = fopen(path, "rb");
+            if (f) {
+                for (;;) { const size_t r = fread(b->src + got, 1, b->src_cap - got, f); got += r; if (r == 0 || got == b->src_cap) break; }
+                const bool more = got == b->src_cap && fgetc(f) != EOF;
+                fclose(f);
+                direct = !more && got >= 2 && b->src[0] == 0x1f && b->src[1] == 0x8b && inflate_gzip_into(b->src, got, b->dst, b->dst_cap, &produced) == 1;
+            }
+        }
         if (direct) { b->dst_len = produced; text = b->dst; n = produced; }
     } else if (direct) {
         FILE *f = fopen(path, "rb");
@@ -318,6 +327,7 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     const int NSLOT = LA + 2;
     void *pinned[LA_MAX + 2] = {}; size_t pinned_cap[LA_MAX + 2] = {};
     std::vector<uint64_t> plain_total(n_groups, 0);
+    gs::Bytes cbuf[LA_MAX + 2];                               // per slot: the compressed bytes of the group's .gz files
     int start_rc = GS_OK;
     // host stage of a group: its files are spread over n_threads threads (files.rs:327 par_iter over the group)
     auto start_group = [&](uint64_t g) {
@@ -325,8 +335,8 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
         blobs[g].resize(f1 - f0);
         {   // size the plain files and give each its place in this group's pinned buffer (its previous user, group g-4, is long done)
             const int sl = (int)(g % NSLOT);
-            std::vector<uint64_t> off(f1 - f0, 0), cap(f1 - f0, 0);
-            uint64_t tot = 0;
+            std::vector<uint64_t> off(f1 - f0, 0), cap(f1 - f0, 0), coff(f1 - f0, 0), ccap(f1 - f0, 0);
+            uint64_t tot = 0, ctot = 0;
             for (uint64_t f = f0; f < f1; f++) {
                 struct stat st;
                 if (stat(paths[f], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) continue;
@@ -338,6 +348,7 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
                     if (fz && fseek(fz, -4, SEEK_END) == 0 && fread(t4, 1, 4, fz) == 4) want = (uint64_t)t4[0] | (uint64_t)t4[1] << 8 | (uint64_t)t4[2] << 16 | (uint64_t)t4[3] << 24;
                     if (fz) fclose(fz);
                     if (want < (uint64_t)st.st_size / 2 || want > (uint64_t)st.st_size * 64 || want >= (1u << 30)) want = 0;       // not a plausible single member
+                    if (want) { coff[f - f0] = ctot; ccap[f - f0] = (uint64_t)st.st_size; ctot += ((uint64_t)st.st_size + 63) / 64 * 64; }
                 }
                 if (want) { off[f - f0] = tot; cap[f - f0] = want; tot += (want + 63) / 64 * 64; }
             }
@@ -347,9 +358,11 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
                 pinned[sl] = nullptr; pinned_cap[sl] = (tot + 64) * 5 / 4;
                 if (hipHostMalloc(&pinned[sl], pinned_cap[sl], hipHostMallocDefault) != hipSuccess) { pinned[sl] = nullptr; pinned_cap[sl] = 0; start_rc = GS_ERR_HIP; gs::set_error("hipHostMalloc of %zu bytes failed", (size_t)((tot + 64) * 5 / 4)); }
             }
+            const bool have_c = ctot == 0 || cbuf[sl].reserve(ctot + 64);
             for (uint64_t f = f0; f < f1; f++) {
                 gs::FileBlob &fb = blobs[g][f - f0];
                 fb.dst = (cap[f - f0] && pinned[sl]) ? (uint8_t *)pinned[sl] + off[f - f0] : nullptr; fb.dst_cap = cap[f - f0];
+                fb.src = (ccap[f - f0] && have_c) ? cbuf[sl].data() + coff[f - f0] : nullptr; fb.src_cap = ccap[f - f0];
             }
         }
         pending[g] = std::async(std::launch::async, [&, g, f0, f1]() {
