@@ -129,6 +129,31 @@ def run_selftest_launch(args, D):
 
 
 # ------------------------------------------------------------------------------------------------------
+def host_cpu_budget():
+    """(logical CPUs the host reports, CPUs this process may really use): the second is capped by the affinity mask and by the
+    cgroup CPU quota (cpu.max) - a 256-thread box with a quota of 16 CPUs runs 256 OpenMP threads no faster than 16"""
+    logical = os.cpu_count() or 1
+    eff = float(logical)
+    try:
+        eff = min(eff, float(len(os.sched_getaffinity(0))))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt and txt[0] != "max":
+                    eff = min(eff, float(txt[0]) / float(txt[1]))
+            else:
+                q = float(txt[0]); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    eff = min(eff, q / per)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return logical, max(1, int(eff + 0.999))
+
+
 def cpu_sketch_baseline(O, op, args, kmers_per_genome, words, cores):
     """oracle sketch (OpenMP, one task per genome - the reference's decomposition, dnasketch.rs:322-357) on a bounded sample"""
     L = args.genome_len
@@ -142,9 +167,9 @@ def cpu_sketch_baseline(O, op, args, kmers_per_genome, words, cores):
     t0 = time.perf_counter()
     O.sketch_batch(op, buf, srs, np.full(ns, L, np.uint64), np.arange(ns + 1, dtype=np.uint64), nthreads=cores)
     cdt = time.perf_counter() - t0
-    return {"value": kmers_per_genome * ns / cdt, "unit": "k-mers/s", "cores": cores, "threads": cores, "kind": "port",
-            "sample": "%d genomes x %.1f Mbp, k=%d s=%d optdens, oracle/gs_oracle.c with OpenMP on all %d host threads (one task per genome), %.1f s wall"
-                      % (ns, L / 1e6, args.kmer, args.sketch_size, cores, cdt),
+    return {"value": kmers_per_genome * ns / cdt, "unit": "k-mers/s", "cores": cores, "threads": cores, "host_logical_cpus": host_cpu_budget()[0], "kind": "port",
+            "sample": "%d genomes x %.1f Mbp, k=%d s=%d optdens, oracle/gs_oracle.c with OpenMP on the %d CPUs this process may use (affinity / cgroup quota; the host lists %d), one task per genome, %.1f s wall"
+                      % (ns, L / 1e6, args.kmer, args.sketch_size, cores, host_cpu_budget()[0], cdt),
             "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
 
 
@@ -240,7 +265,7 @@ def run_sketch(args, D):
             ref = O.sketch_batch(op, pk, np.zeros(1, np.uint64), np.array([L], np.uint64), np.array([0, 1], np.uint64))
             ok &= bool(np.array_equal(ref.view(np.uint32)[0], sig_dev.view(np.uint32)[g]))
         out["parity_checked"] = {"genomes": chk, "bit_exact_vs_oracle": ok}
-        out["cpu_baseline"] = cpu_sketch_baseline(O, op, args, kmers_per_genome, words, os.cpu_count() or 1) if (D.world == 1 and not args.no_cpu_baseline) else None
+        out["cpu_baseline"] = cpu_sketch_baseline(O, op, args, kmers_per_genome, words, host_cpu_budget()[1]) if (D.world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out))
     for p in (d_seq, d_sig, d_rs, d_rl, d_goff):
         ctx.free(p)
@@ -473,8 +498,8 @@ def request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, n
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     k, m, L, qps, knbn, ef = args.kmer, args.sketch_size, args.genome_len, args.queries_per_step, args.knbn, args.ef_search
-    cores = os.cpu_count() or 1
-    ns = min(max(args.cpu_sample_queries, cores), qps)             # at least one query per host thread: the CPU leg uses every core
+    logical, cores = host_cpu_budget()
+    ns = min(max(args.cpu_sample_queries, cores), qps)             # at least one query per usable CPU: the CPU leg uses every core it may
     last = (args.steps - 1) % nsteps_q
     qsig = ctx.download(d_qsig, (qps, m), np.float32)[:ns]
     ids_g = ids_t.cpu().numpy().view(np.uint64)[:ns]
@@ -507,9 +532,9 @@ def request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, n
     out["parity_checked"] = {"queries": ns, "sketch_bit_exact_vs_oracle": sketch_ok, "neighbour_ids_and_distances_equal_oracle": ids_ok,
                              "dist_evaluation_counts_equal_oracle": evals_ok, "max_ani_abs_err": ani_err}
     out["recall_at_%d" % knbn] = {"gpu": rec_gpu, "cpu_oracle": rec_cpu, "queries": nb, "reference": "exhaustive DistHamming top-k, tie-aware"}
-    out["cpu_baseline"] = {"value": ns / (cpu_sketch_s + cpu_search_s), "unit": "genomes/s", "cores": cores, "threads": min(cores, ns), "kind": "port",
-                           "sample": "%d of the step's query genomes on %d OpenMP threads (host reports %d): oracle sketch %.2fs + oracle parallel_search (same graph, ef=%d) %.2fs"
-                                     % (ns, min(cores, ns), cores, cpu_sketch_s, ef, cpu_search_s),
+    out["cpu_baseline"] = {"value": ns / (cpu_sketch_s + cpu_search_s), "unit": "genomes/s", "cores": cores, "threads": min(cores, ns), "host_logical_cpus": logical, "kind": "port",
+                           "sample": "%d of the step's query genomes on %d OpenMP threads = the CPUs this process may use (affinity / cgroup quota; the host lists %d): oracle sketch %.2fs + oracle parallel_search (same graph, ef=%d) %.2fs"
+                                     % (ns, min(cores, ns), logical, cpu_sketch_s, ef, cpu_search_s),
                            "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
     return out
 

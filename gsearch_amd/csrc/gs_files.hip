@@ -12,6 +12,7 @@
 #include <dirent.h>
 #include <dlfcn.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <zlib.h>
 #include <algorithm>
@@ -160,6 +161,20 @@ static int read_fasta(const char *path, Bytes &text)
     return GS_OK;
 }
 
+// CPUs this process may really use: hardware_concurrency capped by the affinity mask and the cgroup quota (a container that lists 256
+// threads with cpu.max = 16 CPUs runs 256 host threads no faster than 16, only with more contention)
+static uint32_t usable_cpus()
+{
+    double eff = (double)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) eff = std::min(eff, (double)CPU_COUNT(&set));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0}; double per = 0;
+        if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) eff = std::min(eff, atof(q) / per);
+        fclose(f);
+    }
+    return (uint32_t)std::max(1.0, eff + 0.999);
+}
 struct FileBlob {       // one file after the host stage
     Bytes text;                           // decompressed text of a compressed file (plain files are read straight into the pinned buffer)
     uint8_t *dst = nullptr; size_t dst_cap = 0, dst_len = 0;    // where a plain file goes (pinned) and how much of it was filled
@@ -315,7 +330,7 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     const auto t_call = std::chrono::steady_clock::now();
     const bool aa = p->data_t == GS_DATA_AA;
     if (pio == 0) pio = 32;          // small groups overlap best (measured: 32 files per group 3200 genomes/s, 64: 2400, 256: 900)
-    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads == 0) n_threads = gs::usable_cpus();
     const uint64_t n_groups = (n_files + pio - 1) / pio;
     const size_t esz = gs_sig_elem_bytes(p), m = p->sketch_size;
     std::vector<std::vector<gs::FileBlob>> blobs(n_groups);
