@@ -2125,15 +2125,6 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
                 phase = 1; GS_LAUNCH_PLAN_KIND();                  // layers above 0 of the few points that have any
                 GS_HIP_CHECK(hipGetLastError());
                 if ((rc = gs::plan_prepass(ix, nb, efc, matp, mat_ld, &w0k, &w0n, &w0e))) return rc;
-                if (getenv("GS_PLAN_DEBUG") && (b0 / B) % 100 == 0) {
-                    std::vector<uint32_t> hw(nb); std::vector<uint64_t> he(nb);
-                    (void)hipMemcpyAsync(hw.data(), w0n, 4 * nb, hipMemcpyDeviceToHost, c->stream);
-                    (void)hipMemcpyAsync(he.data(), w0e, 8 * nb, hipMemcpyDeviceToHost, c->stream);
-                    (void)hipStreamSynchronize(c->stream);
-                    uint32_t fl = 0, mn = ~0u, mx = 0; double ev = 0;
-                    for (uint32_t t = 0; t < nb; t++) { if (hw[t] == 0xFFFFFFFFu) fl++; else { mn = std::min(mn, hw[t]); mx = std::max(mx, hw[t]); ev += (double)he[t]; } }
-                    fprintf(stderr, "[GS_PLAN_DEBUG] b0=%llu: %u of %u flagged, |W| %u..%u, mean evals %.0f\n", (unsigned long long)b0, fl, nb, mn, mx, ev / std::max(1u, nb - fl));
-                }
                 phase = 2; GS_LAUNCH_PLAN_KIND();                  // selection on the W the pre-pass worked out
             }
 #undef GS_LAUNCH_PLAN_KIND
