@@ -2075,7 +2075,7 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
                 // the nodes inserted before the first cached batch (the first 4096 in auto mode) have no rows of their own: a pair of two
                 // of them would send the selection heuristic back to streaming 2M signature rows per candidate - 5 % of the candidates,
                 // most of its time. One all-pairs tile pass (b0^2 counts, 32 MB at 4096) closes the hole.
-                if (slab && !ix->early_cached && b0 > 0 && b0 <= 16384) {
+                if (slab && !ix->early_cached && b0 > 0 && b0 <= 32768) {
                     const uint64_t eld = gs::round_up(b0, 8), ebytes = b0 * eld * 2;
                     gs::DevBuf *early = new gs::DevBuf();
                     if (ix->pair_cache_bytes + ebytes <= ix->pair_cache_budget && early->alloc(ebytes) == GS_OK) {
