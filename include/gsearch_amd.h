@@ -121,8 +121,8 @@ void gs_host_free(void *);
 /* files.rs:148-215,345-455: accepted files under dir, recursively, name order. paths_buf NULL to size (*n_out files, *bytes_out bytes),
  * then a buffer that receives the NUL-terminated paths back to back */
 int  gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t cap_bytes, uint64_t *n_out, uint64_t *bytes_out);
-/* One signature per file, input order. Groups of `pio` files (--pio, files.rs:258-341; 0 -> 64) are read + decompressed + scanned by
- * n_threads host threads (0 -> all) while the previous group crosses PCIe from pinned memory on a copy stream and the one before is
+/* One signature per file, input order. Groups of `pio` files (--pio, files.rs:258-341; 0 -> 32) are read + decompressed + scanned by
+ * n_threads host threads (0 -> the CPUs the process may use: affinity mask and cgroup quota) while the previous group crosses PCIe from pinned memory on a copy stream and the one before is
  * filtered / 2-bit packed / sketched on the context's stream. block_mode 0: k-mers never span records (process_file_by_sequence,
  * dnafiles.rs:43-107); 1: --block, records concatenated (process_file_in_one_block, dnafiles.rs:200-262); `capsid` records skipped.
  * sig_out: HOST n_files x sketch_size. Optional per-file n_records_out / n_symbols_out (HOST) and stats_out[4] = {host read+decode+scan
