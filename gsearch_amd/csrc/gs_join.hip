@@ -100,7 +100,7 @@ __device__ __forceinline__ void join_lds_barrier()
 __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t st, uint64_t e)
 {
     const uint64_t idx = (uint64_t)((st & 0xFFFu) - 1) * ld + e;
-    atomicAdd(&mm32[idx >> 1], (st >> 12) << ((idx & 1) * 16));
+    atomicSub(&mm32[idx >> 1], (st >> 12) << ((idx & 1) * 16));      // counters start at m and count DOWN: a half-word never borrows (matches <= m)
 }
 
 // grid: (node chunks of JT*JN, slot blocks). matches[q * ld + e] (16-bit counters, incremented through their 32-bit container).
@@ -253,16 +253,6 @@ __global__ __launch_bounds__(JT) void k_match_sample(const T *__restrict__ qkey,
     if ((threadIdx.x & 63) == 0 && hits) { atomicAdd(&out[0], (unsigned long long)hits); atomicAdd(&out[1], (unsigned long long)reps); }
 }
 
-// matches -> mismatch counts, in place:  c = m - matches
-__global__ void k_match_to_count(uint16_t *mm, uint64_t nq, uint64_t n, uint64_t ld, uint32_t m)
-{
-    const uint64_t total = nq * n;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t q = i / n, e = i % n;
-        mm[q * ld + e] = (uint16_t)(m - mm[q * ld + e]);
-    }
-}
-
 template <int KIND, typename T>
 static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstride, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint16_t *out16,
                      uint64_t ld, DevBuf *scratch /* [5] reusable */, int *declined, unsigned long long *stats)
@@ -272,8 +262,9 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     const size_t items = (size_t)m * nq;
     DevBuf &k0 = scratch[0];
     if ((rc = k0.ensure(sizeof(T) * items))) return rc;
-    // zero the 16-bit match counters of the used rows (ld may exceed n: only [0,n) of each row is used)
-    GS_HIP_CHECK(hipMemset2DAsync(out16, ld * 2, 0, n * 2, nq, c->stream));
+    // every 16-bit counter starts at m and every match takes one off: the matrix leaves the join as mismatch counts, without the pass that
+    // used to turn matches into mismatches (6 GB read + written per 10 000-query request)
+    GS_HIP_CHECK(hipMemsetD16Async((hipDeviceptr_t)out16, (unsigned short)m, (size_t)nq * ld, c->stream));
     dim3 tg((nq + 31) / 32, (m + 31) / 32);
     hipLaunchKernelGGL((k_query_cols<KIND, T>), tg, dim3(256), 0, c->stream, qrows, qstride, nq, m, k0.as<T>());
     GS_HIP_CHECK(hipGetLastError());
@@ -324,14 +315,12 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats, chunk_major);
         GS_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_match_to_count, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, (uint64_t)nq, n, ld, m);
-    GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
 
 uint64_t match_join_max_queries() { const char *e = getenv("GS_JOIN_MAXQ"); return e ? (uint64_t)std::max(1, std::min(4094, atoi(e))) : JQ_MAX; }
 
-// `declined` (optional): set to 1 - and out16 is left zeroed - when the sampled match density says the compare tile kernel is the
+// `declined` (optional): set to 1 - and out16 is left at its initial value m - when the sampled match density says the compare tile kernel is the
 // cheaper producer for this batch (the caller then runs it)
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
                       uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined, unsigned long long *stats)
