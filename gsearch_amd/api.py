@@ -484,8 +484,6 @@ class Hnsw:
 
     def set_extend_candidates(self, flag):
         self._frozen_check()
-        if flag and self.prm.ef_construction <= 2 * self.prm.max_nb_conn:      # refused here, before any sketching is done (gs_index_create repeats it)
-            raise GsError(_lib.GS_ERR_UNSUPPORTED, "extend_candidates with ef_construction <= 2*max_nb_conn is not implemented on the device")
         self.prm.extend_candidates = int(bool(flag))
 
     def set_keeping_pruned(self, flag):

@@ -1018,14 +1018,14 @@ __device__ __forceinline__ bool select_check_rows(const IndexDev &ix, const Sear
 // behind it have to see the new member - so the result is the sequential one.
 constexpr int SEL_CH = 8;
 template <int KIND>
-__device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const SearchLds &S, uint32_t nW, uint32_t deg, bool heuristic, uint64_t &evals)
+__device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const SearchLds &S, uint32_t nW, uint32_t deg, bool heuristic, uint64_t &evals, uint32_t na0 = 0)
 {
     if (!heuristic) {
         for (uint32_t t = threadIdx.x; t < nW; t += ST) S.A[t] = S.R[t];
         __syncthreads();
         return nW;
     }
-    uint32_t na = 0, i = 0;
+    uint32_t na = na0, i = 0;                                           // na0 > 0: S.A[0..na0) holds what earlier windows of the candidate list kept
     uint32_t *orw = (uint32_t *)&S.scal[4];
     while (i < nW && na < deg) {
         if (na == 0) { if (threadIdx.x == 0) S.A[0] = S.R[i]; na = 1; i++; __syncthreads(); continue; }
@@ -1103,13 +1103,89 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
     return na;
 }
 
+// hnsw_rs select_neighbours with extend_candidates when |W| <= deg (SPEC 5; oracle select_neighbours): the candidate set becomes
+// W u { layer-0 neighbours of the members of W }, walked in ascending (c, id) order by the same heuristic. With ef_construction > 2M the
+// extension adds nothing (k_hnsw_plan skips it: a result shorter than ef is the whole component); with ef_construction <= 2M - gsearch's
+// default --ef 400 with -n 200..255 (gsearch.rs:219-225,268) - EVERY layer-0 selection extends, up to efc * 2M candidates. They are
+// gathered per member of W (visited bitmap, distances through the same block_distances as the search), kept as keys in a per-workgroup
+// global array E (a few hundred kB, L2 resident), bitonic-sorted there, and fed to select_block in LDS windows. A window that starts at
+// distance 1.0 after the first kept neighbour ends the walk: every later candidate is pruned by c(e,s) <= m.
+template <int KIND>
+__device__ __forceinline__ uint32_t select_extended(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t *vis, uint32_t vis_words, uint32_t nW,
+                                                    uint32_t deg, uint32_t win, uint64_t *__restrict__ E, uint32_t capE, const uint16_t *__restrict__ matrow, uint64_t &evals)
+{
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < nW; t += ST) {
+        const uint64_t kx = S.R[t];
+        E[t] = kx;
+        if (KID(kx) < ix.n) __hip_atomic_fetch_or(&vis[KID(kx) >> 5], 1u << (KID(kx) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    uint32_t nE = nW;
+    for (uint32_t wi = 0; wi < nW; wi++) {
+        const uint32_t wid = KID(S.R[wi]);
+        if (wid >= ix.n) continue;                                        // a batch-mate: not linked yet, no neighbours
+        const uint32_t *nbr; uint32_t dg;
+        node_neighbours(ix, wid, 0, nbr, dg);
+        bool unv = false; uint32_t id = 0;
+        if (threadIdx.x < dg) {
+            id = nbr[threadIdx.x];
+            const uint32_t bit = 1u << (id & 31);
+            const uint32_t old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unv = !(old & bit);
+        }
+        const uint64_t bal = __ballot(unv);
+        if (lane == 0) S.wsum[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = 0, ne = 0;
+#pragma unroll
+        for (int w = 0; w < ST / 64; w++) { const uint32_t x = S.wsum[w]; if (w < (int)wv) off += x; ne += x; }
+        if (unv) S.Eid[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = id;
+        __syncthreads();
+        if (ne == 0) continue;
+        evals += ne;
+        block_distances<KIND>(ix, q, S.Eid, ne, S.Ecnt, matrow);
+        if (threadIdx.x < ne && nE + threadIdx.x < capE) E[nE + threadIdx.x] = KEY(S.Ecnt[threadIdx.x], S.Eid[threadIdx.x]);
+        nE += ne;
+        __syncthreads();
+    }
+    if (nE > capE) nE = capE;                                             // (capE >= every reachable count: host sizing)
+    uint32_t P = 2; while (P < nE) P <<= 1;
+    for (uint32_t i = nE + threadIdx.x; i < P; i += ST) E[i] = ~(uint64_t)0;
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= P; kk <<= 1)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += ST) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = E[i], b = E[l];
+                    if ((a > b) == ((i & kk) == 0)) { E[i] = b; E[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    uint32_t na = 0;
+    for (uint32_t pos = 0; pos < nE && na < deg; pos += win) {
+        const uint32_t wn = nE - pos < win ? nE - pos : win;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < wn; t += ST) S.R[t] = E[pos + t];
+        __syncthreads();
+        if (na >= 1 && KCNT(S.R[0]) >= ix.m) break;
+        na = select_block<KIND>(ix, S, wn, deg, true, evals, na);
+    }
+    __syncthreads();
+    return na;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint32_t nb, const uint8_t *__restrict__ blevels,
                                                    const uint32_t *__restrict__ cntmat, const uint16_t *__restrict__ mat, uint64_t mat_ld, uint32_t efc, uint32_t ef_lds, int extend,
                                                    uint32_t *__restrict__ visited, uint32_t vis_words, int vis_in_lds, uint64_t *__restrict__ plan_keys,
                                                    uint32_t *__restrict__ plan_n, unsigned long long *__restrict__ evals_total,
                                                    const uint64_t *__restrict__ w0_keys, const uint32_t *__restrict__ w0_n, const uint64_t *__restrict__ w0_evals,
-                                                   int phase, uint32_t *__restrict__ ep0)
+                                                   int phase, uint32_t *__restrict__ ep0, uint64_t *__restrict__ ext_keys, uint32_t ext_cap)
 {
     // phase 0: the whole plan of a point in one launch. With the pre-pass (plan_prepass) the work is split: phase 1 = the layers above 0
     // of the points that have any (it leaves the layer-0 entry point in ep0), then the pre-pass works W out for every point, then
@@ -1177,7 +1253,11 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
         const uint32_t deg = L == 0 ? 2 * ix.M : ix.M;
         const bool ext = (L == 0) && extend;
         uint32_t na = 0;
-        if (nW) na = select_block<KIND>(ix, S, nW, deg, !(nW <= deg && !ext), evals);
+        if (nW && ext && nW <= deg && ext_keys) {
+            // R and C are one contiguous LDS region (carve_lds) and C is dead by now: the selection windows may run over both
+            const uint32_t room = 3 * ef_lds + maxdeg, win = room < 512u ? room : 512u;
+            na = select_extended<KIND>(ix, q, S, vis, vis_words, nW, deg, win, ext_keys + (uint64_t)i * ext_cap, ext_cap, matrow, evals);
+        } else if (nW) na = select_block<KIND>(ix, S, nW, deg, !(nW <= deg && !ext), evals);
         uint64_t *pk = plan_keys + ((uint64_t)i * ix.max_layer + (uint32_t)L) * maxdeg;
         for (uint32_t t = threadIdx.x; t < na; t += ST) pk[t] = S.A[t];
         if (threadIdx.x == 0) plan_n[(uint64_t)i * ix.max_layer + (uint32_t)L] = na;
@@ -1306,6 +1386,7 @@ struct gs_index {
     // insert scratch
     gs::DevBuf blevels, cntmat, plan_keys, plan_n, inbox, inbox_cnt, touched, ntouched, evals_dev;
     gs::DevBuf wlog, w0_keys, w0_n, w0_evals, ep0; // insert pre-pass (plan_prepass)
+    gs::DevBuf ext_keys;                           // candidate keys of the extended selection (extend_candidates with efc <= 2M)
     uint64_t inbox_lists = 0;
     uint64_t insert_evals = 0;
     // dense mode: count matrix of a query / insert batch against every node, and the running
@@ -1715,9 +1796,6 @@ int gs_index_create(gs_ctx *c, const gs_index_params *p, gs_index **out)
     GS_REQUIRE(p->max_nb_conn >= 2 && p->max_nb_conn <= 255, GS_ERR_INVALID, "max_nb_conn must be in 2..255 (gsearch.rs:268)");
     GS_REQUIRE(p->max_layer >= 1 && p->max_layer <= 16, GS_ERR_INVALID, "max_layer must be in 1..16");
     GS_REQUIRE(p->ef_construction >= 1, GS_ERR_INVALID, "ef_construction must be positive");
-    GS_REQUIRE(!p->extend_candidates || p->ef_construction > 2 * p->max_nb_conn, GS_ERR_UNSUPPORTED,
-               "extend_candidates with ef_construction (%u) <= 2*max_nb_conn (%u) is not implemented on the device: raise --ef above %u (gsearch's defaults do)",
-               p->ef_construction, 2 * p->max_nb_conn, 2 * p->max_nb_conn);
     gs_index *ix = new gs_index();
     ix->ctx = c; ix->prm = *p;
     if (ix->prm.insert_batch == 0) ix->prm.insert_batch = 64;
@@ -1973,8 +2051,6 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer, maxdeg = 2 * M, efc = ix->prm.ef_construction;
     const uint32_t B = std::min<uint32_t>(std::min<uint32_t>(ix->prm.insert_batch, 256u), gs::ST);
     GS_REQUIRE(!ix->prm.keep_pruned, GS_ERR_UNSUPPORTED, "keep_pruned=true is not implemented on the device (gsearch sets false, dnasketch.rs:160)");
-    GS_REQUIRE(!ix->prm.extend_candidates || efc > maxdeg, GS_ERR_UNSUPPORTED,
-               "extend_candidates needs ef_construction > 2*max_nb_conn on the device (then the extension is provably a no-op, DESIGN.md)");
     GS_REQUIRE(ix->n + n < ((uint64_t)1 << 32) - 1, GS_ERR_INVALID, "too many points");
     GS_HIP_CHECK(hipSetDevice(c->device));
     // levels and upper-layer slots of the new points (host: needs libm log, like the oracle)
@@ -2001,6 +2077,14 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     if ((rc = ix->plan_n.ensure((size_t)4 * B * ML))) return rc;
     if ((rc = ix->touched.ensure((size_t)4 * B * (maxdeg + (size_t)ML * M)))) return rc;
     if ((rc = ix->ntouched.ensure(64))) return rc;
+    // extend_candidates with ef_construction <= 2M: every layer-0 selection extends W by the neighbours of its members (select_extended);
+    // one key array per point of a batch, sized for every node the extension can reach (a power of two: it is bitonic-sorted in place)
+    uint32_t ext_cap = 0;
+    if (ix->prm.extend_candidates && efc <= maxdeg) {
+        const uint64_t reach = std::min<uint64_t>(ix->n + n, (uint64_t)efc * maxdeg) + efc;
+        ext_cap = 2; while (ext_cap < reach) ext_cap <<= 1;
+        if ((rc = ix->ext_keys.ensure((size_t)8 * ext_cap * B))) return rc;
+    }
     if (!ix->evals_dev.p) { if ((rc = ix->evals_dev.alloc(64))) return rc; GS_HIP_CHECK(hipMemsetAsync(ix->evals_dev.p, 0, 64, c->stream)); }
     const uint64_t nlists = ix->cap + ix->cap_upper * ML;
     if (nlists != ix->inbox_lists) {
@@ -2057,6 +2141,10 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         const bool dense = (mode == gs::MODE_DENSE && b0 > 0) || (mode == gs::MODE_AUTO && b0 >= 4096 && nb >= 64 && ix->insert_frac >= 0 && gs::dense_pays(ix, ix->insert_frac, nb));
         const uint16_t *matp = nullptr; uint64_t mat_ld = 0;
         if (dense && cnt16) {
+            // the column copy is (re)allocated here, BEFORE a slab is taken or used: ensure_cols may have to evict the pair cache to find
+            // room, and a slab pointer held across that would dangle
+            if (gs::use_join(ix) && (rc = gs::ensure_cols(ix, b0))) return rc;
+            if (slab && ix->slabs.empty()) slab = nullptr;           // the cache was given back (drop_pair_cache): rows go to ix->mat from here on
             if (!slab_tried) {
                 slab_tried = true;
                 const uint64_t need = (first + n - b0) * slab_ld * 2;
@@ -2090,6 +2178,12 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             if (slab) { out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld; mat_ld = slab_ld; }
             else { if (ix->mat.bytes < (size_t)2 * B * slab_ld && (rc = alloc_or_evict(ix, ix->mat, (size_t)2 * B * slab_ld))) return rc; out16 = ix->mat.as<uint16_t>(); mat_ld = slab_ld; }
             if ((rc = gs::dense_counts(ix, rows, nb, b0, out16, mat_ld))) return rc;
+            if (slab && ix->slabs.empty()) {                         // evicted under our feet after all: this batch's counts again, into ix->mat
+                slab = nullptr;
+                if (ix->mat.bytes < (size_t)2 * B * slab_ld && (rc = ix->mat.alloc((size_t)2 * B * slab_ld))) return rc;
+                out16 = ix->mat.as<uint16_t>();
+                if ((rc = gs::dense_counts(ix, rows, nb, b0, out16, mat_ld))) return rc;
+            }
             if (slab) {
                 hipLaunchKernelGGL(gs::k_cache_rows, dim3(nb), dim3(256), 0, c->stream, out16, mat_ld, b0, nb, ix->cntmat.as<uint32_t>(), ix->rowptr.as<uint64_t>());
                 GS_HIP_CHECK(hipGetLastError());
@@ -2115,7 +2209,8 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan));  \
         hipLaunchKernelGGL(kern, dim3(nb), dim3(gs::ST), lds_plan, c->stream, d, b0, nb, ix->blevels.as<uint8_t>(), ix->cntmat.as<uint32_t>(), matp, mat_ld, efc, ef_lds, \
                            ix->prm.extend_candidates, ix->visited.as<uint32_t>(), vw, vis_in_lds, ix->plan_keys.as<uint64_t>(), ix->plan_n.as<uint32_t>(), \
-                           ix->evals_dev.as<unsigned long long>(), w0k, w0n, w0e, phase, ix->ep0.as<uint32_t>());          \
+                           ix->evals_dev.as<unsigned long long>(), w0k, w0n, w0e, phase, ix->ep0.as<uint32_t>(),           \
+                           ext_cap ? ix->ext_keys.as<uint64_t>() : (uint64_t *)nullptr, ext_cap);                          \
     } while (0)
 #define GS_LAUNCH_PLAN_KIND()                                                                                              \
     do { if (ix->ikind == GS_KIND_F32) GS_LAUNCH_PLAN(GS_KIND_F32); else if (ix->ikind == GS_KIND_U32) GS_LAUNCH_PLAN(GS_KIND_U32); else GS_LAUNCH_PLAN(GS_KIND_U64); } while (0)

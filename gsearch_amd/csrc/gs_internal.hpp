@@ -56,7 +56,9 @@ struct gs_ctx {
     // points call one another (save -> export / get_data, bruteforce -> hamming).
     std::recursive_mutex mu;
 };
-#define GS_CTX_LOCK(c) std::lock_guard<std::recursive_mutex> gs_ctx_lock_((c)->mu)
+// Taking the lock also binds the calling thread to the context's device: a worker thread's current device is 0 until it says otherwise, and
+// allocations / launches made from it must land on the device that owns the stream.
+#define GS_CTX_LOCK(c) std::lock_guard<std::recursive_mutex> gs_ctx_lock_((c)->mu); (void)hipSetDevice((c)->device)
 
 namespace gs {
 

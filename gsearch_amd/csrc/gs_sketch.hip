@@ -1097,7 +1097,8 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         __syncthreads();
         const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
         const uint32_t nchunks = (uint32_t)std::max<uint64_t>(1, units / ((uint64_t)T * 8));
-        for (int pass = 0; pass < 2; pass++) {
+        bool outgrown = false;                                    // workgroup-uniform: some warm lane's walk outgrew its registers
+        for (int pass = 0; pass < 2 && !outgrown; pass++) {
             HllEmit<COLD> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1};
             for (uint32_t ch = 0; ch < nchunks; ch++) {
                 walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, ch, nchunks, emit);
@@ -1115,12 +1116,14 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
                     if (threadIdx.x == 0) { const uint32_t kl = S.ctl[2]; const uint64_t cu = ucut[kl]; S.ctl[0] = kl; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); }
                     __syncthreads();
                 }
-                if (!COLD && S.ctl[3]) break;
+                // the overflow flag is raised by single lanes in mid-walk: every wave must take the SAME decision here (a wave that read
+                // it a moment earlier than the others would leave the loop alone and pair its barriers with the wrong ones), so the flag
+                // goes through a barrier-wide OR
+                if (!COLD && __syncthreads_or(S.ctl[3] != 0)) { outgrown = true; break; }
             }
-            if (!COLD && S.ctl[3]) break;
         }
         __syncthreads();
-        if (!COLD && S.ctl[3]) { if (threadIdx.x == 0) cold_flag[g] = 1; continue; }
+        if (!COLD && outgrown) { if (threadIdx.x == 0) cold_flag[g] = 1; continue; }
         for (uint32_t i = threadIdx.x; i < m; i += T) sig[g * (uint64_t)m + i] = (uint16_t)S.tab[i];
     }
 }

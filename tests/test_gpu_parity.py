@@ -197,6 +197,48 @@ def test_parallel_insert_matches_oracle(gpu_ctx, dtype, m, M, efc, B, scale, n_r
     assert np.array_equal(ids, oids) and np.array_equal(dist, odist) and np.array_equal(ev, oev)
 
 
+@pytest.mark.parametrize("mode", ["gather", "dense"])
+@pytest.mark.parametrize("dtype,m,M,efc,B,scale,n_roots,per,jlo", [
+    (np.float32, 256, 8, 8, 16, 1.0, 20, 25, 0.05),        # efc < 2M: every layer-0 selection extends
+    (np.float32, 256, 8, 16, 1, 1.0, 12, 12, 0.05),        # efc == 2M, sequential insertion
+    (np.uint64, 120, 16, 20, 64, 0.5, 30, 30, 0.05),
+    (np.float32, 512, 255, 400, 256, 0.25, 40, 60, 0.3),   # gsearch -n 255 with the default --ef 400 (gsearch.rs:219-225,268)
+    (np.uint32, 200, 200, 400, 128, 0.25, 25, 50, 0.0),    # -n 200, many ties at distance 1.0 (jlo = 0: unrelated members)
+    (np.float32, 128, 16, 24, 256, 0.25, 50, 100, 0.05),   # 5000 points: in dense mode W comes from the insert pre-pass (n >= 4096)
+])
+def test_extend_candidates_with_small_ef_construction(gpu_ctx, monkeypatch, mode, dtype, m, M, efc, B, scale, n_roots, per, jlo):
+    """extend_candidates = true (always, dnasketch.rs:159) with ef_construction <= 2 * max_nb_conn: hnsw_rs' select_neighbours adds the
+    neighbours of the candidates (SPEC 5); device graph == oracle graph, searches identical"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", mode)
+    db = H.synth_sig_db(n_roots, per, m, 5, dtype=dtype, jlo=jlo, jhi=0.95)
+    oix = O.Index(dtype, m, M, efc, scale_modify=scale, seed=3)
+    hn = G.Hnsw.new(M, 10000, 16, efc, G.DistHamming(), dtype=dtype, seed=3, insert_batch=B)
+    hn.modify_level_scale(scale)
+    hn.set_extend_candidates(True)
+    hn.set_keeping_pruned(False)
+    half = len(db) // 2 + 1
+    for part in (db[:half], db[half:]):
+        oix.parallel_insert(part, batch=B)
+        hn.parallel_insert(part)
+    g, og = hn.export_graph(), oix.export()
+    assert g["entry"] == og["entry"] and g["n_upper"] == og["n_upper"]
+    for key in ("levels", "upidx", "deg0", "degU"):
+        assert np.array_equal(g[key], og[key]), key
+    for i in range(len(db)):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]), ("nbr0", i)
+        assert np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d]), ("cnt0", i)
+    for u in range(og["n_upper"]):
+        for L in range(og["degU"].shape[1]):
+            d = int(og["degU"][u, L])
+            assert np.array_equal(g["nbrU"][u, L, :d], og["nbrU"][u, L, :d]), ("nbrU", u, L)
+    q = H.queries_from(db, 24, 6, frac=0.3)
+    ids, dist, cnt, ev = hn.search_arrays(q, 10, 50)
+    oids, odist, ocnt, oev = oix.parallel_search(q, 10, 50)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist) and np.array_equal(ev, oev)
+
+
 @pytest.mark.parametrize("k,m,algo,data", [(21, 2000, "super", "dna"), (21, 2000, "super2", "dna"), (16, 1024, "super2", "dna"), (14, 300, "super2", "dna"),
                                            (7, 1000, "super2", "aa"), (5, 640, "super2", "aa"), (7, 24000, "super2", "aa"), (12, 512, "super", "aa")])
 def test_sketch_super_matches_oracle(gpu_ctx, k, m, algo, data):
@@ -469,14 +511,6 @@ def test_edge_cases_and_error_behaviour(gpu_ctx):
         assert (ids[i, cnt[i]:] == np.iinfo(np.uint64).max).all() and np.isinf(dist[i, cnt[i]:]).all()
     with pytest.raises(G.GsError) as e:
         hn.search_arrays(db[:1], 5, 200000)
-    assert e.value.code == -3
-    h2 = G.Hnsw.new(8, 1000, 16, 8, dh)                                         # efc <= 2M with extend_candidates: refused up front, not approximated
-    with pytest.raises(G.GsError) as e:
-        h2.set_extend_candidates(True)
-    assert e.value.code == -3
-    h2.prm.extend_candidates = 1                                                # a host that bypasses the setter meets the same refusal in gs_index_create
-    with pytest.raises(G.GsError) as e:
-        h2.parallel_insert(db)
     assert e.value.code == -3
     with pytest.raises(G.GsError):
         G.Hnsw.new(300, 1000, 16, 32, dh).parallel_insert(db)                   # max_nb_conn > 255 (gsearch.rs:268)
