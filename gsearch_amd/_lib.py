@@ -88,6 +88,7 @@ SYMBOLS = {
     "gs_index_save": (_i, [_vp, C.c_char_p]),
     "gs_index_load": (_i, [_vp, C.c_char_p, C.POINTER(_vp)]),
     "gs_index_dump_hnswrs": (_i, [_vp, C.c_char_p]),
+    "gs_index_dump_hnswrs_ex": (_i, [_vp, C.c_char_p, _u32]),
     "gs_index_load_hnswrs": (_i, [_vp, C.c_char_p, C.POINTER(IndexParams), C.POINTER(_vp)]),
     "gs_index_insert_evals": (_u64, [_vp]),
     "gs_index_search_stats": (_i, [_vp, _vp, _i]),

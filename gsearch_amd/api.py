@@ -614,9 +614,10 @@ class Hnsw:
         return {"join_atomics": int(out[0]), "pops": pops, "accepting_pops": int(out[2]), "wg_in_flight": int(out[3]),
                 "adj_bytes": pops * int(out[4])}
 
-    def file_dump_hnswrs(self, basename):
-        """Hnsw::file_dump(dir, "hnswdump") in hnsw_rs' own format: <basename>.hnsw.graph + <basename>.hnsw.data (dumpload.rs:26-31)"""
-        check(self.ctx.L.gs_index_dump_hnswrs(self.h, str(basename).encode()))
+    def file_dump_hnswrs(self, basename, truncate_255=False):
+        """Hnsw::file_dump(dir, "hnswdump") in hnsw_rs' own format: <basename>.hnsw.graph + <basename>.hnsw.data (dumpload.rs:26-31).
+        truncate_255: the format keeps neighbour counts in one byte; cut longer layer-0 lists to their 255 closest entries instead of refusing"""
+        check(self.ctx.L.gs_index_dump_hnswrs_ex(self.h, str(basename).encode(), 1 if truncate_255 else 0))
 
     @classmethod
     def load_hnswrs(cls, basename, hint=None, ctx=None):

@@ -170,7 +170,6 @@ int gs_check_params(const gs_sketch_params *p)
     GS_REQUIRE(p, GS_ERR_INVALID, "null params");
     GS_REQUIRE(p->sketch_size >= 2, GS_ERR_INVALID, "sketch_size must be >= 2");
     GS_REQUIRE(p->algo <= GS_ALGO_REVOPTDENS, GS_ERR_INVALID, "unknown sketch algo %u", p->algo);
-    GS_REQUIRE(p->algo != GS_ALGO_HLL || p->sketch_size <= 40000, GS_ERR_UNSUPPORTED, "hll (SetSketch): sketch_size > 40000 does not fit the LDS register table");
     if (p->data_t == GS_DATA_DNA) {
         GS_REQUIRE(p->k >= 1 && p->k <= 32, GS_ERR_INVALID, "DNA kmer size must be in 1..32");
         GS_REQUIRE(p->k != 15, GS_ERR_INVALID, "kmer size 15 is rejected (dnarequest.rs:451-454)");

@@ -51,9 +51,16 @@ extern "C" {
 
 /* Hnsw::file_dump(dir, "hnswdump") (dumpload.rs:26-31): writes <basename>.hnsw.graph and <basename>.hnsw.data in hnsw_rs' format 3
  * (layout above; recalled, see the file header). max_layer must be 16 and no neighbour list may exceed 255 entries (one-byte count). */
-int gs_index_dump_hnswrs(gs_index *ix, const char *basename)
+int gs_index_dump_hnswrs(gs_index *ix, const char *basename) { return gs_index_dump_hnswrs_ex(ix, basename, 0); }
+
+/* flags: GS_DUMP_TRUNCATE_255 - the format stores every neighbour count in ONE byte (`len() as u8` upstream), while layer 0 holds up to
+ * 2 * max_nb_connection = 256 .. 510 entries: a full list cannot be written faithfully (upstream, 256 would wrap to 0 and desynchronise the
+ * reader). Without the flag such an index is refused (use gs_index_save, which is lossless); with it, lists longer than 255 are cut to their
+ * 255 closest entries - a file upstream can read, at the price that the reloaded graph lacks the farthest link(s) of those nodes. */
+int gs_index_dump_hnswrs_ex(gs_index *ix, const char *basename, uint32_t flags)
 {
     GS_REQUIRE(ix && basename, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE((flags & ~(uint32_t)GS_DUMP_TRUNCATE_255) == 0, GS_ERR_INVALID, "unknown dump flags %x", flags);
     gs_index_params prm;
     int rc = gs_index_get_params(ix, &prm); if (rc) return rc;
     const uint64_t n = gs_index_nb_point(ix);
@@ -69,7 +76,9 @@ int gs_index_dump_hnswrs(gs_index *ix, const char *basename)
     // PointId = (top layer, rank among the points of that layer in id order)
     std::vector<int32_t> rank(n); std::vector<std::vector<uint32_t>> by_layer(ML);
     for (uint64_t i = 0; i < n; i++) { rank[i] = (int32_t)by_layer[lv[i]].size(); by_layer[lv[i]].push_back((uint32_t)i); }
-    for (uint64_t i = 0; i < n; i++) GS_REQUIRE(d0[i] <= 255, GS_ERR_UNSUPPORTED, "node %llu has %u layer-0 neighbours: hnsw_rs stores the count in one byte", (unsigned long long)i, d0[i]);
+    if (flags & GS_DUMP_TRUNCATE_255) { for (uint64_t i = 0; i < n; i++) if (d0[i] > 255) d0[i] = 255; }       // lists are (count, id)-ascending: the head is the 255 closest
+    else for (uint64_t i = 0; i < n; i++)
+        GS_REQUIRE(d0[i] <= 255, GS_ERR_UNSUPPORTED, "node %llu has %u layer-0 neighbours: hnsw_rs stores the count in one byte (dump with GS_DUMP_TRUNCATE_255, or use gs_index_save)", (unsigned long long)i, d0[i]);
     const std::string gname = std::string(basename) + ".hnsw.graph", dname = std::string(basename) + ".hnsw.data";
     FILE *fg = fopen(gname.c_str(), "wb"), *fd = fopen(dname.c_str(), "wb");
     if (!fg || !fd) { if (fg) fclose(fg); if (fd) fclose(fd); gs::set_error("cannot open %s / %s for writing", gname.c_str(), dname.c_str()); return GS_ERR_IO; }

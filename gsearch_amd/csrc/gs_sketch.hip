@@ -1012,8 +1012,14 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
 constexpr int HL_T = 512;          // lanes per workgroup
 constexpr int HL_JR = 12;          // displaced positions a warm lane can remember
 constexpr int HL_CT = 256;         // lanes per workgroup of the cold instantiation
-struct HllShared { uint32_t *tab; volatile uint32_t *ctl; };   // ctl: [0] klow, [1] work item, [2] scratch min, [3] overflow flag, [4,5] ucut[klow]
-template <bool COLD>
+// GTAB (register files beyond the LDS: sketch_size > ~40 000, the reference takes sketch_size as is, dnasketch.rs:541-574): the u32
+// registers live in a per-workgroup global table and LDS holds a 2-byte FILTER per register - a value that is never above the
+// register (the last k this workgroup sent there, refreshed from the table between chunks). A k that does not exceed the filter
+// cannot raise the register and stops after one LDS read; the rest go to atomicMax in memory. Racy plain 16-bit stores can only leave
+// the filter lower, i.e. more conservative: exact. Beyond ~80 000 registers the filter does not fit either (filt == nullptr) and every
+// k above K_low goes to memory.
+struct HllShared { uint32_t *tab; volatile uint32_t *ctl; uint16_t *filt; };   // ctl: [0] klow, [1] work item, [2] scratch min, [3] overflow flag, [4,5] ucut[klow]
+template <bool COLD, bool GTAB>
 struct HllEmit {
     HllShared S; uint32_t m; uint64_t zone_m; double inv_lnb, am;
     uint32_t *q, *perm; uint32_t *stamp; bool walk;
@@ -1028,7 +1034,7 @@ struct HllEmit {
         uint32_t k = hll_k(x, inv_lnb);
         if (k <= klow) return;
         uint32_t t = (uint32_t)rng_uint(g, (uint64_t)m, zone_m);
-        atomicMax(&S.tab[t], k);                                  // j = 0: p[0] after swap(p[0], p[t]) is t
+        reg_max(t, k);                                            // j = 0: p[0] after swap(p[0], p[t]) is t
         if (!walk) return;
         // j >= 1: lazily materialised permutation. Position 0 now holds t and position t holds 0.
         uint32_t tpos[HL_JR], tval[HL_JR]; uint32_t nt = 0;
@@ -1067,19 +1073,27 @@ struct HllEmit {
                 }
                 sl = (t != j) ? pt : pj;
             }
-            atomicMax(&S.tab[sl], k);
+            reg_max(sl, k);
         }
     }
+    __device__ __forceinline__ void reg_max(uint32_t t, uint32_t k) const
+    {
+        if (!GTAB) { atomicMax(&S.tab[t], k); return; }
+        if (S.filt) { if (k <= S.filt[t]) return; S.filt[t] = (uint16_t)k; }      // k <= q + 1 = 65535
+        atomicMax(&S.tab[t], k);
+    }
 };
-template <bool AA, bool COLD>
+template <bool AA, bool COLD, bool GTAB>
 __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
         const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off,
         const uint64_t *__restrict__ gen_units, const uint32_t *__restrict__ list, uint32_t n_items, uint32_t k, uint32_t m, double inv_lnb,
         const uint64_t *__restrict__ ucut, uint32_t *__restrict__ lane_q, uint32_t *__restrict__ lane_perm, unsigned long long *__restrict__ counter,
-        uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig)
+        uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig, uint32_t *__restrict__ gtab, int use_filter)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_hll[];
-    HllShared S; S.tab = (uint32_t *)s_hll; S.ctl = (volatile uint32_t *)(S.tab + m);
+    HllShared S;
+    if (!GTAB) { S.tab = (uint32_t *)s_hll; S.ctl = (volatile uint32_t *)(S.tab + m); S.filt = nullptr; }
+    else { S.ctl = (volatile uint32_t *)s_hll; S.filt = use_filter ? (uint16_t *)(s_hll + 32) : nullptr; S.tab = gtab + (uint64_t)blockIdx.x * m; }
     const uint32_t T = COLD ? HL_CT : HL_T;
     uint32_t *q = COLD ? lane_q + (uint64_t)blockIdx.x * m * HL_CT : nullptr, *perm = COLD ? lane_perm + (uint64_t)blockIdx.x * m * HL_CT : nullptr;
     uint32_t stamp = 0;
@@ -1092,14 +1106,14 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         const uint32_t c = S.ctl[1];
         if (c >= n_items) break;
         const uint64_t g = list ? list[c] : c;
-        for (uint32_t i = threadIdx.x; i < m; i += T) S.tab[i] = 0;
+        for (uint32_t i = threadIdx.x; i < m; i += T) { S.tab[i] = 0; if (GTAB && S.filt) S.filt[i] = 0; }
         if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[3] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; }
         __syncthreads();
         const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
         const uint32_t nchunks = (uint32_t)std::max<uint64_t>(1, units / ((uint64_t)T * 8));
         bool outgrown = false;                                    // workgroup-uniform: some warm lane's walk outgrew its registers
         for (int pass = 0; pass < 2 && !outgrown; pass++) {
-            HllEmit<COLD> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1};
+            HllEmit<COLD, GTAB> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1};
             for (uint32_t ch = 0; ch < nchunks; ch++) {
                 walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, ch, nchunks, emit);
                 if (pass == 0 || ch + 1 == nchunks) {
@@ -1108,7 +1122,12 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
                     if (threadIdx.x == 0) S.ctl[2] = 0xFFFFFFFFu;
                     __syncthreads();
                     uint32_t lo = 0xFFFFFFFFu;
-                    for (uint32_t i = threadIdx.x; i < m; i += T) lo = min(lo, S.tab[i]);
+                    for (uint32_t i = threadIdx.x; i < m; i += T) {
+                        // (a global table is only ever written by atomics performed in the L2: read it there too, not through the vector L1)
+                        const uint32_t r = GTAB ? __hip_atomic_load(&S.tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.tab[i];
+                        if (GTAB && S.filt) S.filt[i] = (uint16_t)r;
+                        lo = min(lo, r);
+                    }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_down((int)lo, o));
                     if ((threadIdx.x & 63) == 0) atomicMin((uint32_t *)&S.ctl[2], lo);
@@ -1124,7 +1143,8 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         }
         __syncthreads();
         if (!COLD && outgrown) { if (threadIdx.x == 0) cold_flag[g] = 1; continue; }
-        for (uint32_t i = threadIdx.x; i < m; i += T) sig[g * (uint64_t)m + i] = (uint16_t)S.tab[i];
+        for (uint32_t i = threadIdx.x; i < m; i += T)
+            sig[g * (uint64_t)m + i] = (uint16_t)(GTAB ? __hip_atomic_load(&S.tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.tab[i]);
     }
 }
 
@@ -1149,18 +1169,26 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     GS_HIP_CHECK(hipMemcpyAsync(dcut.p, ucut.data(), 8 * ucut.size(), hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemsetAsync(cold.p, 0, n_genomes, c->stream));
     GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 8, c->stream));
-    const size_t lds = 4 * ((size_t)m + 8);
+    // register file: u32 in LDS while it fits; beyond that a per-workgroup global table behind a 2-byte LDS filter (while THAT fits)
+    const size_t lds_cap = 160 * 1024 - 256;
+    const bool gtab = 4 * ((size_t)m + 8) > lds_cap;
+    const int use_filter = gtab && 32 + 2 * (size_t)m <= lds_cap;
+    const size_t lds = !gtab ? 4 * ((size_t)m + 8) : (use_filter ? 32 + 2 * (size_t)m : 32);
     const uint32_t wgs = (uint32_t)std::min<uint64_t>(n_genomes, (uint64_t)c->n_cu * 2);
+    PoolBuf gt(c, 19);
+    if (gtab && (rc = gt.alloc((size_t)4 * m * std::max<uint32_t>(wgs, (uint32_t)c->n_cu)))) return rc;
     {
         ProfScope ps(c, FAM_SKETCH);
-#define GS_LAUNCH_HLL(AAV)                                                                                                     \
+#define GS_LAUNCH_HLL(AAV, GV)                                                                                                 \
     do {                                                                                                                       \
-        auto kern = k_sketch_hll<AAV, false>;                                                                                  \
+        auto kern = k_sketch_hll<AAV, false, GV>;                                                                              \
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(HL_T), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, (const uint32_t *)nullptr, \
-                           (uint32_t)n_genomes, p->k, m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out); \
+                           (uint32_t)n_genomes, p->k, m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
+                           gt.as<uint32_t>(), use_filter);                                                                     \
     } while (0)
-        if (aa) GS_LAUNCH_HLL(true); else GS_LAUNCH_HLL(false);
+        if (aa) { if (gtab) GS_LAUNCH_HLL(true, true); else GS_LAUNCH_HLL(true, false); }
+        else { if (gtab) GS_LAUNCH_HLL(false, true); else GS_LAUNCH_HLL(false, false); }
 #undef GS_LAUNCH_HLL
     }
     GS_HIP_CHECK(hipGetLastError());
@@ -1180,14 +1208,16 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     GS_HIP_CHECK(hipMemcpyAsync(dl.p, list.data(), 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemsetAsync(lq.p, 0xFF, (size_t)4 * cw * m * HL_CT, c->stream));
     GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 8, c->stream));
-#define GS_LAUNCH_HLLC(AAV)                                                                                                    \
+#define GS_LAUNCH_HLLC(AAV, GV)                                                                                                \
     do {                                                                                                                       \
-        auto kern = k_sketch_hll<AAV, true>;                                                                                   \
+        auto kern = k_sketch_hll<AAV, true, GV>;                                                                               \
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(cw), dim3(HL_CT), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, p->k, m, \
-                           inv_lnb, dcut.as<uint64_t>(), lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out); \
+                           inv_lnb, dcut.as<uint64_t>(), lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
+                           gt.as<uint32_t>(), use_filter);                                                                     \
     } while (0)
-    if (aa) GS_LAUNCH_HLLC(true); else GS_LAUNCH_HLLC(false);
+    if (aa) { if (gtab) GS_LAUNCH_HLLC(true, true); else GS_LAUNCH_HLLC(true, false); }
+    else { if (gtab) GS_LAUNCH_HLLC(false, true); else GS_LAUNCH_HLLC(false, false); }
 #undef GS_LAUNCH_HLLC
     GS_HIP_CHECK(hipGetLastError());
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -200,6 +200,10 @@ int      gs_index_load(gs_ctx *, const char *path, gs_index **out);
  * recalled constant). dump needs max_layer = 16 and lists of at most 255 neighbours; load takes capacity / scale_modify / flags / seed /
  * insert_batch for later insertions from `hint` (may be NULL) - the dump itself holds only max_nb_connection, ef and the element type. */
 int      gs_index_dump_hnswrs(gs_index *, const char *basename);
+/* flags = GS_DUMP_TRUNCATE_255: neighbour counts are ONE byte in this format while layer 0 holds up to 2 * max_nb_conn = 256..510 ids; lists
+ * longer than 255 are cut to their 255 closest entries (lossy for those nodes; without the flag such an index is refused - gs_index_save is lossless) */
+enum { GS_DUMP_TRUNCATE_255 = 1 };
+int      gs_index_dump_hnswrs_ex(gs_index *, const char *basename, uint32_t flags);
 int      gs_index_load_hnswrs(gs_ctx *, const char *basename, const gs_index_params *hint, gs_index **out);
 uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluations spent by inserts so far */
 /* device-side work counters of the searches and dense-mode inserts since the last reset (bench.py prices kernels with them):

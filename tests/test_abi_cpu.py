@@ -34,9 +34,7 @@ def test_parameter_validation_mirrors_reference():
             P(*args)
         assert e.value.code == -1
     assert P(21, 18000, "hll").sig_dtype() == np.uint16                   # HyperLogLogSketch<Kmer, u16> (dnasketch.rs:541-574)
-    with pytest.raises(G.GsError) as e:
-        P(21, 50000, "hll")                                                # register table beyond LDS: refused, not approximated
-    assert e.value.code == -3
+    assert P(21, 90000, "hll").sig_dtype() == np.uint16                   # sketch_size is taken as is (register file beyond LDS: global table)
 
 
 def test_host_helpers_match_oracle():
@@ -87,3 +85,20 @@ def test_fasta_scan_capsid_filter_uses_the_whole_header_line():
     assert [r[0] for r in recs] == ["NC_2", "NC_3", "last"]
     assert [txt[b:e] for _, b, e in recs] == [b"GG\n", b"ACGTA\r\n", b"A"]
     assert [r[0] for r in G.fasta_scan(txt, skip_capsid=False)] == ["NC_0123.1", "NC_2", "x_capsid_y", "NC_3", "NC_4", "last"]
+
+
+def test_integration_md_binds_every_exported_symbol():
+    """INTEGRATION.md's Rust `extern "C"` block (the binding a maintainer of the reference would add) names every function the header
+    declares, with the generated signature (tools/gen_rust_extern.py), and the ctypes table of the Python host does the same"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_rust_extern", os.path.join(root, "tools", "gen_rust_extern.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    md = " ".join(open(os.path.join(root, "INTEGRATION.md")).read().split())
+    import gsearch_amd as G
+    names = []
+    for name, params, ret in gen.functions():
+        names.append(name)
+        decl = "pub fn %s(%s)%s;" % (name, ", ".join("%s: %s" % p for p in params), (" -> " + ret) if ret else "")
+        assert " ".join(decl.split()) in md, decl
+    assert sorted(names) == sorted(G.SYMBOLS), set(names) ^ set(G.SYMBOLS)

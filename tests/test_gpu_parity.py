@@ -875,6 +875,21 @@ def test_sketch_hll_cold_path_matches_oracle(gpu_ctx):
     assert (got[4] == 0).all() and (got[5] == 0).all()                          # no k-mer at all -> all registers 0
 
 
+@pytest.mark.parametrize("m,length", [(50000, 1600000), (90000, 2600000)])
+def test_sketch_hll_register_file_beyond_lds(gpu_ctx, m, length):
+    """sketch_size is taken as is by the reference (dnasketch.rs:541-574): beyond ~40 000 registers the table moves to global memory behind a
+    2-byte LDS filter (50 000), beyond ~80 000 without one (90 000); warm genomes, a cold one (walks of hundreds of steps) and an empty one"""
+    import gsearch_amd as G
+    rng = np.random.default_rng(m)
+    fam = H.family(rng, length, [0.03])
+    genomes = [[H.dna_ascii(g)] for g in fam] + [[H.dna_ascii(H.rand_dna(rng, 5000))], [b"ACGT"]]
+    sk = G.HyperLogLogSketch.new(G.SeqSketcherParams(21, m, "hll"))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(21, m, "hll", genomes)
+    assert got.dtype == ref.dtype == np.uint16 and got.shape == (4, m)
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("mode,impl", [("gather", None), ("dense", "join"), ("dense", "tile")])
 def test_u16_signatures_distance_and_index(gpu_ctx, monkeypatch, mode, impl):
     """DistHamming and the HNSW build / search on u16 signatures (hll): rows are zero-extended to u32 on the device, so every count -
@@ -1121,3 +1136,129 @@ def test_hnswrs_dump_assembled_by_hand(gpu_ctx, tmp_path):
     assert hn.get_nb_point() == 3 and np.array_equal(hn.get_data(), vec)
     ids, dist, cnt_, _ = hn.search_arrays(np.array([[1, 2, 3, 4]], np.float32), 3, 10)
     assert ids[0].tolist() == [0, 1, 2] and dist[0].tolist() == [0.0, 0.25, 1.0] and cnt_[0] == 3
+
+
+def test_hnswrs_dump_of_full_m128_lists(gpu_ctx, tmp_path):
+    """gsearch's own parameters (-n 128: layer 0 holds 2M = 256 ids) against the format's ONE-byte neighbour count: a graph with full
+    lists is refused by the plain dump (nothing silently wrapped), dumped with GS_DUMP_TRUNCATE_255 it reloads with every such list cut
+    to its 255 closest entries and everything else identical; the library's own dump stays lossless"""
+    import gsearch_amd as G
+    m, M = 96, 128
+    db = H.synth_sig_db(6, 80, m, 9, dtype=np.uint32, jlo=0.5, jhi=0.99)               # 480 points
+    built = G.Hnsw.new(M, 1_500_000, 16, 400, G.DistHamming(), dtype=np.uint32, seed=2, insert_batch=64)
+    built.modify_level_scale(0.25); built.set_extend_candidates(True)
+    built.parallel_insert(db)
+    g0 = built.export_graph()
+    # hubs with full lists (what reverse links do to popular nodes of a 300 k-genome database): nodes 0..4 get their 256 / 255 / 256 ...
+    # closest other nodes as layer-0 neighbours, in the library's (count, id) order with the true counts
+    for hub, deg in ((0, 256), (1, 255), (2, 256), (7, 256), (11, 254)):
+        cnt = (db != db[hub]).sum(axis=1).astype(np.uint64)
+        keys = np.sort(np.delete((cnt << np.uint64(32)) | np.arange(len(db), dtype=np.uint64), hub))[:deg]
+        g0["deg0"][hub] = deg
+        g0["nbr0"][hub, :deg] = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        g0["cnt0"][hub, :deg] = (keys >> np.uint64(32)).astype(np.uint32)
+    hn = G.Hnsw.new(M, 1_500_000, 16, 400, G.DistHamming(), dtype=np.uint32, seed=2, insert_batch=64)
+    hn.modify_level_scale(0.25); hn.set_extend_candidates(True)
+    hn.import_graph(db, g0)
+    g1 = hn.export_graph()
+    assert int(g1["deg0"].max()) == 2 * M
+    with pytest.raises(G.GsError) as e:
+        hn.file_dump_hnswrs(tmp_path / "plain")
+    assert e.value.code == -3 and "one byte" in str(e.value)
+    hn.file_dump_hnswrs(tmp_path / "hnswdump", truncate_255=True)
+    h2 = G.Hnsw.load_hnswrs(tmp_path / "hnswdump", hint=hn)
+    g2 = h2.export_graph()
+    assert np.array_equal(g2["deg0"], np.minimum(g1["deg0"], 255)) and np.array_equal(g1["levels"], g2["levels"]) and g1["entry"] == g2["entry"]
+    for i in range(len(db)):
+        d = int(g2["deg0"][i])
+        assert np.array_equal(g1["nbr0"][i, :d], g2["nbr0"][i, :d]) and np.array_equal(g1["cnt0"][i, :d], g2["cnt0"][i, :d])
+    assert np.array_equal(hn.get_data(), h2.get_data())
+    hn.file_dump(tmp_path / "own.gsix")
+    h3 = G.Hnsw.load(tmp_path / "own.gsix")
+    g3 = h3.export_graph()
+    assert np.array_equal(g1["deg0"], g3["deg0"]) and np.array_equal(g1["nbr0"], g3["nbr0"])
+
+
+def test_hnswrs_dump_sizes_against_the_readme_sample(gpu_ctx, tmp_path):
+    """The only reference-held datum that touches the dump layout: README.md:164-168 lists the sample database (README.md:69: -k 16
+    -s 18000 -n 128 optdens, i.e. 18000 f32 per vector; its parameters.json is the 180-byte KAT of test_state_json) at 9.7G for
+    hnswdump.hnsw.data and 58M for hnswdump.hnsw.graph (`ls -lh`: powers of 1024, rounded UP to one decimal). The per-vector and
+    per-neighbour byte costs are taken from files THIS writer produces (two dumps, linear fit - not from the layout comment); the sample's
+    sizes must then be explained by an integer number of genomes and a mean degree a -n 128 graph can have."""
+    import gsearch_amd as G
+    m = 40
+
+    def dump(n, M, tag):
+        db = H.synth_sig_db(8, (n + 7) // 8, m, 13, jlo=0.1, jhi=0.9)[:n]
+        hn = G.Hnsw.new(M, 1_500_000, 16, 64, G.DistHamming(), seed=11, insert_batch=32)
+        hn.modify_level_scale(0.5); hn.set_extend_candidates(True)
+        hn.parallel_insert(db)
+        hn.file_dump_hnswrs(tmp_path / tag)
+        g = hn.export_graph()
+        links = int(g["deg0"].sum()) + int(g["degU"].sum())
+        return n, links, os.path.getsize(tmp_path / (tag + ".hnsw.data")), os.path.getsize(tmp_path / (tag + ".hnsw.graph"))
+    (n1, l1, d1, gr1), (n2, l2, d2, gr2), (n3, l3, d3, gr3) = dump(200, 8, "a"), dump(330, 8, "b"), dump(330, 16, "c")
+    # data file = fixed + n * (header + 4 * m)
+    per_vec = (d2 - d1) // (n2 - n1)
+    assert (d2 - d1) % (n2 - n1) == 0 and per_vec > 4 * m
+    fixed_d, hdr = d1 - n1 * per_vec, per_vec - 4 * m
+    assert fixed_d == d3 - n3 * per_vec and 0 < fixed_d < 64 and 0 < hdr < 64
+    # graph file = fixed + n * per_point + links * per_link: three dumps, three unknowns
+    A = np.array([[1, n1, l1], [1, n2, l2], [1, n3, l3]], float)
+    fixed_g, per_point, per_link = np.linalg.solve(A, np.array([gr1, gr2, gr3], float))
+    assert abs(per_point - round(per_point)) < 1e-6 and abs(per_link - round(per_link)) < 1e-6 and 8 < per_link < 40 and 16 < per_point < 80
+    per_point, per_link = round(per_point), round(per_link)
+    GiB, MiB = 1 << 30, 1 << 20
+    row = hdr + 4 * 18000
+    n_lo, n_hi = int(9.6 * GiB - fixed_d) // row + 1, int(9.7 * GiB - fixed_d) // row            # 9.6G < size <= 9.7G
+    assert n_lo <= n_hi and 100_000 <= n_lo and n_hi < 1_000_000, (n_lo, n_hi)     # a 6-digit genome count: the sample's processing_state.json is 55 bytes, {"nb_seq":NNNNNN,"nb_file":NNNNNN,"elapsed_t":...}
+    deg_lo = ((57 * MiB - fixed_g) / n_hi - per_point) / per_link                      # 57M < size <= 58M
+    deg_hi = ((58 * MiB - fixed_g) / n_lo - per_point) / per_link
+    assert 1.0 < deg_lo < deg_hi < 2 * 128, (deg_lo, deg_hi)
+    print("README sample explained by %d..%d genomes with %.1f..%.1f links per node (vector record %d + 72000 B, point %d B, link %d B)" %
+          (n_lo, n_hi, deg_lo, deg_hi, hdr, per_point, per_link))
+
+
+def test_config0_tohnsw_then_request_end_to_end(gpu_ctx):
+    """BASELINE configs[0], the reference's own CPU-runnable case, on the HIP path end to end: `tohnsw` on 1000 synthetic 1 Mbp DNA genomes
+    (10 roots x 100 mutants), k=21 s=12000 --algo optdens, -n 128 --ef 1600 --scale_modify_f 0.25, then `request` with 100 queries, n=50,
+    ef_search=5000 (gsearch.rs:893). Sketch bits, graph, neighbour ids / distances / evaluation counts == oracle; recall@50 == CPU == 1
+    against exhaustive search; the answers formatted like ReqAnswer::dump (answer.rs:45-71) agree between both sides."""
+    import gsearch_amd as G
+    N, NQ, L, k, m, M, efc, ef, knbn, B = 1000, 100, 1_000_000, 21, 12000, 128, 1600, 5000, 50, 64
+    rng = np.random.default_rng(1)
+    roots = [H.rand_dna(rng, L) for _ in range(10)]
+    mus = [0.001, 0.005, 0.01, 0.02, 0.05, 0.10]
+    genomes = [[H.dna_ascii(H.mutate(rng, roots[i % 10], mus[(i // 10) % 6]))] for i in range(N)]
+    queries = [[H.dna_ascii(H.mutate(rng, roots[i % 10], 0.01))] for i in range(NQ)]
+    cores = os.cpu_count()
+    # CPU side (oracle)
+    seq, rs, rl = O.pack_dna([g[0] for g in genomes])
+    osig = O.sketch_batch(O.params(k, m, "optdens"), seq, rs, rl, np.arange(N + 1, dtype=np.uint64), nthreads=cores)
+    oix = O.Index(np.float32, m, M, efc, scale_modify=0.25, seed=7)
+    oix.parallel_insert(osig, batch=B)
+    qseq, qrs, qrl = O.pack_dna([q[0] for q in queries])
+    oq = O.sketch_batch(O.params(k, m, "optdens"), qseq, qrs, qrl, np.arange(NQ + 1, dtype=np.uint64), nthreads=cores)
+    oids, odist, ocnt, oev = oix.parallel_search(oq, knbn, ef, nthreads=cores)
+    # HIP side
+    sk = G.OptDensHashSketch.new(G.SeqSketcherParams(k, m, "optdens"))
+    gsig = sk.sketch_genomes(genomes)
+    assert gsig.dtype == np.float32 and np.array_equal(gsig.view(np.uint32), osig.view(np.uint32))
+    hn = G.Hnsw.new(M, 1_500_000, 16, efc, G.DistHamming(), seed=7, insert_batch=B)
+    hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+    hn.parallel_insert(gsig)
+    g, og = hn.export_graph(), oix.export()
+    assert g["entry"] == og["entry"] and np.array_equal(g["levels"], og["levels"]) and np.array_equal(g["deg0"], og["deg0"])
+    for i in range(N):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]) and np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d]), i
+    gq = sk.sketch_genomes(queries)
+    assert np.array_equal(gq.view(np.uint32), oq.view(np.uint32))
+    ids, dist, cnt, ev = hn.search_arrays(gq, knbn, ef)
+    assert np.array_equal(ids, oids) and np.array_equal(dist.view(np.uint32), odist.view(np.uint32)) and np.array_equal(cnt, ocnt) and np.array_equal(ev, oev)
+    bi, bd = O.bruteforce_topk(osig, oq, knbn, nthreads=cores)
+    rec = float(np.mean([(dist[i] <= bd[i, -1]).mean() for i in range(NQ)]))
+    assert rec == 1.0
+    # every query's best hits are its own root's family (ids i % 10 == root), nearest first
+    assert all(int(ids[i, 0]) % 10 == i % 10 for i in range(NQ)) and (np.diff(dist, axis=1) >= 0).all()
+    assert abs(G.ani(float(dist[0][0]), k, 1) - O.ani(float(dist[0][0]), k, 1)) < 1e-6
