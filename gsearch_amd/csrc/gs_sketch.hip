@@ -11,6 +11,8 @@
 // k-mer through the element hash into an m-slot min table held in LDS (ds_min_u32). HBM traffic is the
 // algorithmic minimum: each packed word is read once (plus an L1/L2-served halo word) and m slots written.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <vector>
 #include <hipcub/hipcub.hpp>
@@ -163,17 +165,14 @@ template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_
 template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_word_done(const MinEmitF<ALGO, VBITS, T> &e) { e.word_done(); }
 template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_finish(const MinEmitF<ALGO, VBITS, T> &e) { e.finish(); }
 
-// The streaming part shared by every sketcher: walk the units of genome g assigned to this workgroup and
-// call emit(v) for each valid canonical k-mer value.
+// The streaming part shared by every sketcher. walk_unit: flat unit f of a genome (32 symbols: one packed word of DNA, 32 bytes of AA) ->
+// emit(v) for each valid canonical k-mer value that starts... ends in it; walk_genome: the units of genome g assigned to this workgroup.
 template <bool AA, class Emit>
-__device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
-                                            const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
-                                            uint64_t r0, uint64_t r1, uint64_t units, uint32_t k, uint32_t part,
-                                            uint32_t parts, const Emit &emit)
+__device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
+                                          const uint64_t *__restrict__ rec_upre, uint64_t r0, uint64_t r1, uint64_t f, uint32_t k, uint64_t mask, uint32_t rcshift,
+                                          const Emit &emit)
 {
-    const uint64_t mask = AA ? (((uint64_t)1 << (5 * k)) - 1) : (k == 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1));
-    const uint32_t rcshift = 2 * (k - 1);
-    for (uint64_t f = (uint64_t)part * blockDim.x + threadIdx.x; f < units; f += (uint64_t)parts * blockDim.x) {
+    {
         // record owning flat unit f: last r in [r0,r1) with rec_upre[r] <= f
         uint64_t lo = r0, hi = r1;
         while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (rec_upre[mid] <= f) lo = mid; else hi = mid; }
@@ -249,6 +248,18 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
             }
         }
     }
+}
+__device__ __forceinline__ uint64_t kmer_mask(bool aa, uint32_t k) { return aa ? (((uint64_t)1 << (5 * k)) - 1) : (k == 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1)); }
+template <bool AA, class Emit>
+__device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
+                                            const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
+                                            uint64_t r0, uint64_t r1, uint64_t units, uint32_t k, uint32_t part,
+                                            uint32_t parts, const Emit &emit)
+{
+    const uint64_t mask = kmer_mask(AA, k);
+    const uint32_t rcshift = 2 * (k - 1);
+    for (uint64_t f = (uint64_t)part * blockDim.x + threadIdx.x; f < units; f += (uint64_t)parts * blockDim.x)
+        walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, emit);
     emit_finish(emit);
 }
 
@@ -860,8 +871,585 @@ __global__ void k_prob_write(const uint64_t *__restrict__ q, const uint64_t *__r
         out[i] = q[i] == GS_INF_BITS ? (T)0 : (T)sig[i];
 }
 
+// =====================================================================================================
+// prob, bucketed form (round 3; DESIGN.md 3.1 "ProbMinHash3a"). The global 64-bit radix sort above moves every k-mer across HBM ~14
+// times only to learn multiplicities. Here a genome's k-mers are PARTITIONED once by the top bits of a multiplicative hash into
+// buckets of ~PB_AVG values (count pass -> exact offsets -> scatter pass: two cheap walks, 8 B written per k-mer), and each bucket is
+// then turned into (value, multiplicity) pairs by an LDS hash table (one 64-bit LDS CAS per k-mer) inside the kernel that also
+// evaluates the first ProbMinHash point of every distinct element - so the k-mers cross HBM three times (read text, write bucket,
+// read bucket).
+//   k_prob_count    per (genome, part): bucket histogram in LDS; the first tile of every part also applies its k-mers to q[] with
+//                   w = 1: x / 1 >= x / w, so those are UPPER bounds of the final slot minima (the true points arrive later and can
+//                   only be lower) - they give the bucket kernel a finite rejection threshold from its first bucket on
+//   k_prob_scan     per genome: bucket offsets, per-part scatter bases, thr = max_b q[b]
+//   k_prob_scatter  per (genome, part): the same walk, values appended to their buckets through LDS cursors (no global atomics)
+//   k_prob_buckets  persistent workgroups over all buckets of the chunk: LDS hash -> (v, w); an element whose first point
+//                   h = w^-1 TE exceeds thr (any snapshot of max_b q[b] bounds the final one) cannot win a slot and stops after two
+//                   SplitMix64 mixes (exact: strict >, ties must reach the claim); the rest lower q[b] and, when they are the slot's
+//                   minimum at that moment, go on a short candidate list; elements with w^-1 <= thr may see pass 2 and go on the
+//                   active list with their generator state
+//   k_prob_claim_list + k_prob_fold as before; passes >= 2 run over the active list only.
+// Genomes the scheme does not suit fall back to the sorted form above: fewer than 64 k-mers per slot (no warm-up: every element stays
+// alive for many passes), more than PB_NBMAX * PB_AVG k-mers, or a bucket with more than PB_TAB distinct values (flagged on the device).
+// =====================================================================================================
+constexpr int PBK_T = 1024;        // lanes of the count / scatter kernels
+constexpr int PBK_WPL = 4;         // units per lane per tile
+constexpr int PB2_T = 512;         // lanes of the bucket kernel
+constexpr int PB_AVG = 1536;       // k-mers per bucket aimed at
+constexpr int PB_TAB = 4096;       // LDS hash entries per bucket
+constexpr int PB_NBMAX = 16384;    // buckets per genome (LDS cursors of the scatter kernel: 64 kB)
+constexpr int PB_CST = 256;        // candidate winners staged per bucket
+constexpr int PB_SVQ = 3072;       // elements (table slots) queued for the full generator per bucket
+// The bucket of a value comes from a BIJECTION of the vbits-bit values (multiplication by an odd constant modulo 2^vbits): bucket = its top
+// lg bits, and the low sh = vbits - lg bits identify the value inside its bucket - 30 bits for k = 21 with 4096 buckets, so the bucket
+// kernel's hash table holds 4-byte ids instead of 8-byte values (half the LDS, full-rate 32-bit LDS atomics) and gets the value back by
+// multiplying with the inverse constant.
+#define GS_PB_MUL 0x9E3779B97F4A7C15ULL
+constexpr uint64_t pb_inverse(uint64_t a) { uint64_t x = a; for (int i = 0; i < 6; i++) x *= 2 - a * x; return x; }      // Newton: a odd, inverse modulo 2^64
+constexpr uint64_t GS_PB_INV = pb_inverse(GS_PB_MUL);
+static_assert(GS_PB_MUL * GS_PB_INV == 1ULL, "modular inverse");
+__device__ __forceinline__ uint64_t pb_hash(uint64_t v, uint64_t vmask) { return (v * GS_PB_MUL) & vmask; }
+__device__ __forceinline__ uint64_t pb_unhash(uint64_t hv, uint64_t vmask) { return (hv * GS_PB_INV) & vmask; }
+__device__ __forceinline__ uint32_t pb_bucket(uint64_t v, uint64_t vmask, uint32_t sh) { return sh >= 64 ? 0u : (uint32_t)(pb_hash(v, vmask) >> sh); }
+struct PbCountEmit {
+    uint32_t *hist; uint32_t sh; uint64_t vmask;
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { atomicAdd(&hist[pb_bucket(v, vmask, sh)], 1u); }
+};
+struct PbWarmEmit {
+    uint32_t *hist; uint32_t sh; uint64_t vmask; uint64_t *q; uint32_t m; uint64_t zone; ProbConst pc;
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const
+    {
+        atomicAdd(&hist[pb_bucket(v, vmask, sh)], 1u);
+        Rng rg; rg.seed(v);
+        const double x = texp_sample(pc, rg);
+        const uint32_t b = (uint32_t)rng_uint(rg, (uint64_t)m, zone);
+        const uint64_t hb = (uint64_t)__double_as_longlong(x);
+        if (hb < q[b]) atomicMin((unsigned long long *)&q[b], (unsigned long long)hb);
+    }
+};
+struct PbScatterEmit {
+    uint32_t *cur; uint32_t sh; uint64_t vmask; uint64_t *out;
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { out[atomicAdd(&cur[pb_bucket(v, vmask, sh)], 1u)] = v; }
+};
+// MODE 0: count (+ warm-up on the first tile), MODE 1: scatter
+template <bool AA, int MODE>
+__global__ __launch_bounds__(PBK_T) void k_prob_partition(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
+                                                           const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
+                                                           uint64_t g0, uint32_t k, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff, uint32_t parts,
+                                                           uint32_t *__restrict__ hist, uint64_t *__restrict__ q, uint32_t m, uint64_t zone, ProbConst pc,
+                                                           uint64_t *__restrict__ vals, const uint64_t *__restrict__ g_vbase)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pb[];
+    const uint32_t gl = blockIdx.y, part = blockIdx.x;
+    const uint64_t g = g0 + gl;
+    const uint32_t sh = g_sh[gl], NB = 1u << (vbits - sh);        // sh = vbits - log2(NB): bits of a hashed value below its bucket number
+    uint32_t *hg = hist + (uint64_t)g_boff[gl] * parts + (uint64_t)part * NB;
+    for (uint32_t b = threadIdx.x; b < NB; b += PBK_T) s_pb[b] = MODE == 0 ? 0u : hg[b];
+    __syncthreads();
+    const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
+    const uint64_t mask = kmer_mask(AA, k);
+    const uint32_t rcshift = 2 * (k - 1);
+    const uint64_t TILE = (uint64_t)PBK_T * PBK_WPL;
+    for (uint64_t t0 = (uint64_t)part * TILE; t0 < units; t0 += (uint64_t)parts * TILE) {
+#pragma unroll 1
+        for (int j = 0; j < PBK_WPL; j++) {
+            const uint64_t f = t0 + (uint64_t)j * PBK_T + threadIdx.x;
+            if (f >= units) continue;
+            if (MODE == 0) {
+                if (t0 == (uint64_t)part * TILE) { PbWarmEmit e{s_pb, sh, mask, q + (uint64_t)gl * m, m, zone, pc}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, e); }
+                else { PbCountEmit e{s_pb, sh, mask}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, e); }
+            } else { PbScatterEmit e{s_pb, sh, mask, vals + g_vbase[gl]}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, e); }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < NB; b += PBK_T) hg[b] = s_pb[b];
+    }
+}
+// per genome: bucket sizes / starts, per-part scatter bases (hist is rewritten in place), thr = max_b q[b]
+__global__ __launch_bounds__(1024) void k_prob_scan(uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff, uint32_t parts, uint32_t *__restrict__ hist,
+                                                     uint32_t *__restrict__ bstart, uint32_t *__restrict__ bsize, uint32_t *__restrict__ bgen, const uint64_t *__restrict__ q, uint32_t m,
+                                                     uint64_t *__restrict__ thr)
+{
+    __shared__ uint32_t s_w[16]; __shared__ unsigned long long s_mx;
+    const uint32_t gl = blockIdx.x, sh = g_sh[gl], NB = 1u << (vbits - sh);
+    const uint32_t b0 = g_boff[gl];
+    uint32_t *hg = hist + (uint64_t)b0 * parts;
+    const uint32_t CH = (NB + 1023) / 1024;                    // consecutive buckets per lane
+    uint32_t loc = 0;
+    for (uint32_t c = 0; c < CH; c++) { const uint32_t b = threadIdx.x * CH + c; if (b < NB) for (uint32_t p = 0; p < parts; p++) loc += hg[(uint64_t)p * NB + b]; }
+    uint32_t inc = loc;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+    if (lane == 63) s_w[wv] = inc;
+    if (threadIdx.x == 0) s_mx = 0;
+    __syncthreads();
+    uint32_t run = inc - loc;
+    for (uint32_t w = 0; w < wv; w++) run += s_w[w];
+    for (uint32_t c = 0; c < CH; c++) {
+        const uint32_t b = threadIdx.x * CH + c;
+        if (b >= NB) break;
+        bstart[b0 + b] = run; bgen[b0 + b] = gl;
+        uint32_t tot = 0;
+        for (uint32_t p = 0; p < parts; p++) { const uint32_t x = hg[(uint64_t)p * NB + b]; hg[(uint64_t)p * NB + b] = run + tot; tot += x; }
+        bsize[b0 + b] = tot; run += tot;
+    }
+    unsigned long long mx = 0;
+    for (uint32_t i = threadIdx.x; i < m; i += 1024) { const unsigned long long x = q[(uint64_t)gl * m + i]; mx = x > mx ? x : mx; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+    if (lane == 0) atomicMax(&s_mx, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) thr[gl] = s_mx;
+}
+struct PbLists {
+    uint64_t *cand_v, *cand_h, *cand_gb; uint32_t cand_cap, ovf_cap; uint32_t *n_cand, *seg_n;      // [0, cand_cap): per-workgroup segments; [cand_cap, + ovf_cap): shared overflow
+    uint64_t *akey; uint32_t *agl, *acnt; uint64_t *astate; uint32_t act_cap; uint32_t *n_act;
+    unsigned long long *prof;                                     // GS_PROB_PROFILE: cycle stamps of workgroup 0 per phase (nullptr otherwise)
+};
+// KT = uint32_t: the table holds the sh-bit id of a value inside its bucket (sh <= 31 for every genome of the launch; ~0 = empty);
+// KT = uint64_t: it holds the value itself (k = 32, AA k = 12, or genomes with so few buckets that an id needs 32 bits).
+template <typename KT>
+__global__ __launch_bounds__(PB2_T, 6) void k_prob_buckets(const uint64_t *__restrict__ vals, const uint64_t *__restrict__ g_vbase, const uint32_t *__restrict__ bstart,
+                                                           const uint32_t *__restrict__ bsize, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff,
+                                                           uint32_t ng, uint32_t lg_max, uint32_t m, uint64_t zone,
+                                                           ProbConst pc, uint64_t *__restrict__ q, uint64_t *__restrict__ thr, uint32_t *__restrict__ wmax, PbLists L,
+                                                           uint32_t *__restrict__ ovf)
+{
+    // LDS per workgroup (4-byte ids): 16 kB table + 8 kB duplicate counts + 6 kB queue + 5 kB candidates = 35 kB. What the kernel spends
+    // its time on (GS_PROB_PROFILE, cycles per bucket of 1220 keys on 512 lanes, before / after this form): LDS atomics of the insert
+    // 6360 / see DESIGN (one 32-bit CAS per k-mer instead of a 64-bit CAS plus an add: the LDS pipeline is shared by the whole CU, so
+    // residency does not help there), the cheap test 2930 (its two SplitMix64 mixes now run during the insert, under the LDS wait), the
+    // threshold read 1390 (now fetched one bucket ahead), the few full points 4600 (global read + atomicMin latency).
+    __shared__ KT tab[PB_TAB];
+    __shared__ uint32_t dup[PB_TAB / 2];                          // 16-bit counts of the REPEATED occurrences, two per word (65535 saturates: flagged)
+    __shared__ unsigned long long s_mx;
+    // elements that pass the cheap threshold test are compacted into an LDS queue (of table slots) so that the full generator (truncated
+    // exponential + uniform slot) runs on dense wavefronts; possible winners are staged too and go to this workgroup's PRIVATE segment
+    // of the candidate list (no global counter: one bumped per candidate by thousands of lanes serialised in the L2)
+    __shared__ uint16_t sv_s[PB_SVQ];
+    __shared__ uint64_t sc_v[PB_CST], sc_h[PB_CST]; __shared__ uint32_t sc_b[PB_CST];
+    __shared__ uint32_t s_nc, s_ns;
+    const KT EMPTY = (KT)~(KT)0;
+    const uint64_t EMPTY64 = ~(uint64_t)0;
+    const uint64_t vmask = vbits >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << vbits) - 1);
+    constexpr int KPL = 6;                                        // keys per lane held in registers (buckets of up to KPL * PB2_T keys)
+    const uint32_t seg = L.cand_cap / gridDim.x;                  // this workgroup's share of the candidate list
+    uint32_t my_nc = 0;
+    // Work items in BUCKET-major order over the chunk: (position j of 2^lg_max, genome) - a genome with fewer buckets takes part at every
+    // (2^lg_max / NB)-th position. All genomes advance together, so a genome's buckets are spread over the whole launch and its
+    // threshold has time to tighten (the first buckets see max_b q[b] of the warm-up, the last ones nearly the final one); genome-major
+    // order had ~1000 workgroups finish a genome's 8192 buckets within microseconds of each other, all under the loosest bound.
+    // The description of the item after this one (and its genome's threshold: a slightly older bound is still a bound) is fetched while
+    // this one is worked on.
+    const uint64_t n_items = (uint64_t)ng << lg_max;
+    auto describe = [&](uint64_t idx, uint32_t &gl_, uint32_t &n_, uint32_t &st_, uint64_t &vb_, uint32_t &pos_, uint32_t &sh_, uint32_t &bk_, uint64_t &thr_) {
+        n_ = 0; gl_ = 0; st_ = 0; vb_ = 0; pos_ = 1; sh_ = 0; bk_ = 0; thr_ = 0;
+        if (idx >= n_items) return;
+        const uint32_t j = (uint32_t)(idx / ng), g = (uint32_t)(idx % ng);
+        const uint32_t sh = g_sh[g], lg = vbits - sh, rs = lg_max - lg;          // this genome has 2^lg buckets
+        if (j & ((1u << rs) - 1u)) return;
+        const uint32_t fb = g_boff[g] + (j >> rs);
+        gl_ = g; n_ = bsize[fb]; st_ = bstart[fb]; vb_ = g_vbase[g]; pos_ = j; sh_ = sh; bk_ = j >> rs;
+        thr_ = __hip_atomic_load(&thr[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    uint64_t item = blockIdx.x;
+    uint32_t n_gl, n_n, n_st, n_pos, n_sh, n_bk; uint64_t n_vb, n_thr;
+    describe(item, n_gl, n_n, n_st, n_vb, n_pos, n_sh, n_bk, n_thr);
+    for (; item < n_items; item += gridDim.x) {
+        const uint32_t gl = n_gl, n = n_n, jpos = n_pos, sh = n_sh, bk = n_bk;
+        const uint64_t *keys = vals + n_vb + n_st;
+        uint64_t *qg = q + (uint64_t)gl * m;
+        uint64_t thr_b = n_thr;
+        uint64_t kreg[KPL];
+#pragma unroll
+        for (int u = 0; u < KPL; u++) { const uint32_t i = u * PB2_T + threadIdx.x; kreg[u] = i < n ? keys[i] : EMPTY64; }
+        describe(item + gridDim.x, n_gl, n_n, n_st, n_vb, n_pos, n_sh, n_bk, n_thr);
+        if (n == 0) continue;                                      // (workgroup-uniform) nothing of this genome at this position
+        const bool pf = L.prof && blockIdx.x == 0 && threadIdx.x == 0;
+        long long t0 = pf ? clock64() : 0, t1;
+#define GS_PSTAMP(i) do { if (pf) { t1 = clock64(); atomicAdd(&L.prof[i], (unsigned long long)(t1 - t0)); t0 = t1; } } while (0)
+        __syncthreads();                                           // the previous bucket's LDS is dead
+        for (uint32_t s = threadIdx.x; s < PB_TAB; s += PB2_T) tab[s] = EMPTY;
+        for (uint32_t s = threadIdx.x; s < PB_TAB / 2; s += PB2_T) dup[s] = 0;
+        if (threadIdx.x == 0) { s_nc = 0; s_ns = 0; s_mx = 0; }
+        // rejection threshold: any snapshot of max_b q[b] bounds the final maximum (q only ever decreases). 32 times per genome a bucket
+        // rescans the genome's q[] (m loads, eight in flight per lane) and publishes the new bound; everybody else reads the published one.
+        if ((jpos & ((1u << (lg_max > 5 ? lg_max - 5 : 0)) - 1u)) == 0) {
+            unsigned long long mx = 0;
+            for (uint32_t i0 = 0; i0 < m; i0 += 8 * PB2_T) {
+                unsigned long long x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + u * PB2_T + threadIdx.x; x[u] = i < m ? __hip_atomic_load(&qg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) mx = x[u] > mx ? x[u] : mx;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) atomicMax(&s_mx, mx);
+            __syncthreads();
+            const unsigned long long t = s_mx;
+            if (threadIdx.x == 0) atomicMin((unsigned long long *)&thr[gl], t);
+            if (t < thr_b) thr_b = t;
+        }
+        const double thr_d = __longlong_as_double((long long)thr_b);
+        __syncthreads();
+        GS_PSTAMP(0);
+        // ---- (value, multiplicity) pairs: LDS hash table, ONE atomic per k-mer. The lane whose CAS created an entry OWNS that element
+        //      (count 1); a later occurrence of the same value finds it there and bumps the entry's duplicate count instead (a second
+        //      atomic, for repeats only). After the barrier the owners - dense over the lanes, unlike the 70 %-empty table - go on with
+        //      multiplicity 1 + duplicates. The first draw of every key (two SplitMix64 mixes) is computed here, under the LDS wait.
+        bool over = false;
+        uint32_t own[KPL]; double x0r[KPL];
+        const uint64_t idmask = sizeof(KT) == 4 ? (((uint64_t)1 << sh) - 1) : ~(uint64_t)0;
+        auto insert = [&](uint64_t v) -> uint32_t {
+            const KT id = sizeof(KT) == 4 ? (KT)(pb_hash(v, vmask) & idmask) : (KT)v;
+            uint32_t s = (uint32_t)((v * 0xD6E8FEB86659FD93ULL) >> 40) & (PB_TAB - 1);
+            for (uint32_t probe = 0; probe < PB_TAB; probe++) {
+                const KT old = atomicCAS(&tab[s], EMPTY, id);
+                if (old == EMPTY) return s;
+                if (old == id) {
+                    const uint32_t before = atomicAdd(&dup[s >> 1], 1u << ((s & 1) * 16));
+                    if (((before >> ((s & 1) * 16)) & 0xFFFFu) == 0xFFFFu) over = true;      // a k-mer 65537 times in one genome: 16 bits wrapped
+                    return 0xFFFFFFFFu;
+                }
+                s = (s + 1) & (PB_TAB - 1);
+            }
+            over = true;
+            return 0xFFFFFFFFu;
+        };
+        auto first_draw = [&](uint64_t v) -> double {             // x = c1 * U64f from two of the four state words; when x < 1 it IS the truncated exponential (SPEC 3.3)
+            const uint64_t s0 = splitmix_mix(v + GS_GAMMA), s3 = splitmix_mix(v + 4 * GS_GAMMA);
+            return pc.c1 * ((double)((rotl64(s0 + s3, 23) + s0) >> 12) * 0x1.0p-52);
+        };
+#pragma unroll
+        for (int u = 0; u < KPL; u++) {
+            own[u] = 0xFFFFFFFFu; x0r[u] = 0.0;
+            if ((uint32_t)(u * PB2_T) + threadIdx.x < n) { own[u] = insert(kreg[u]); x0r[u] = first_draw(kreg[u]); }
+        }
+        // (buckets beyond KPL * PB2_T keys - heavy repeats - : the tail's owners are found by the table sweep below)
+        const bool tail = n > (uint32_t)(KPL * PB2_T);
+        for (uint32_t i = KPL * PB2_T + threadIdx.x; i < n; i += PB2_T) (void)insert(keys[i]);
+        if (over) ovf[gl] = 1;                                  // table full or a count wrapped: the host redoes this genome the sorted way
+        __syncthreads();
+        GS_PSTAMP(1);
+        // ---- cheap test of every distinct element; the ones that may matter go to the queue
+        uint32_t wloc = 0;
+        auto count_of = [&](uint32_t s) -> uint32_t { return 1u + ((dup[s >> 1] >> ((s & 1) * 16)) & 0xFFFFu); };
+        auto value_of = [&](uint32_t s) -> uint64_t {
+            if (sizeof(KT) == 4) return pb_unhash(((uint64_t)bk << sh) | (uint64_t)tab[s], vmask);
+            return (uint64_t)tab[s];
+        };
+        auto full_point = [&](uint32_t s) {
+            const uint64_t v = value_of(s);
+            const uint32_t w = count_of(s);
+            const double winv = w == 1 ? 1.0 : 1.0 / (double)w;
+            const bool alive2 = !(winv > thr_d);
+            Rng rg; rg.seed(v);
+            const double x = texp_sample(pc, rg);
+            const uint32_t b = (uint32_t)rng_uint(rg, (uint64_t)m, zone);
+            const double h = 0.0 + winv * x;
+            if (!(h > thr_d)) {
+                const uint64_t hb = (uint64_t)__double_as_longlong(h);
+                uint64_t *slot = qg + b;
+                if (hb <= __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    const uint64_t old = atomicMin((unsigned long long *)slot, (unsigned long long)hb);
+                    if (hb <= old) {                             // the slot's minimum (or tied with it) at this moment: a possible winner
+                        const uint32_t sp = atomicAdd(&s_nc, 1u);
+                        if (sp < (uint32_t)PB_CST) { sc_v[sp] = v; sc_h[sp] = hb; sc_b[sp] = b; }
+                        else {                                   // staging full (first buckets of a genome): the shared overflow region behind the segments
+                            const uint32_t pos = atomicAdd(L.n_cand, 1u);
+                            if (pos < L.ovf_cap) { const uint32_t o = L.cand_cap + pos; L.cand_v[o] = v; L.cand_h[o] = hb; L.cand_gb[o] = (uint64_t)gl * m + b; }
+                        }
+                    }
+                }
+            }
+            if (alive2) {                                        // may still reach a slot in pass 2 (superset: thr >= the final max q)
+                const uint32_t pos = atomicAdd(L.n_act, 1u);
+                if (pos < L.act_cap) {
+                    L.akey[pos] = v; L.agl[pos] = gl; L.acnt[pos] = w;
+                    L.astate[pos] = rg.s0; L.astate[(uint64_t)L.act_cap + pos] = rg.s1; L.astate[2 * (uint64_t)L.act_cap + pos] = rg.s2; L.astate[3 * (uint64_t)L.act_cap + pos] = rg.s3;
+                }
+            }
+        };
+        auto cheap_test = [&](double x0, uint32_t s) {
+            const uint32_t w = count_of(s);
+            wloc = w > wloc ? w : wloc;
+            const double winv = w == 1 ? 1.0 : 1.0 / (double)w;      // (1.0 / 1.0 is exact: the common case skips the f64 division)
+            if (x0 < 1.0 && winv * x0 > thr_d && winv > thr_d) return;      // cannot win a slot (strict: ties must reach the claim), dead in pass 2
+            const uint32_t sp = atomicAdd(&s_ns, 1u);
+            if (sp < (uint32_t)PB_SVQ) sv_s[sp] = (uint16_t)s;
+            else full_point(s);                                  // queue full (a first bucket under a loose threshold): straight away
+        };
+        if (!tail) {
+#pragma unroll
+            for (int u = 0; u < KPL; u++) if (own[u] != 0xFFFFFFFFu) cheap_test(x0r[u], own[u]);
+        } else {
+            for (uint32_t s = threadIdx.x; s < PB_TAB; s += PB2_T) if (tab[s] != EMPTY) cheap_test(first_draw(value_of(s)), s);
+        }
+        __syncthreads();
+        GS_PSTAMP(2);
+        const uint32_t ns = s_ns < (uint32_t)PB_SVQ ? s_ns : (uint32_t)PB_SVQ;
+        if (pf) { atomicAdd(&L.prof[6], (unsigned long long)ns); atomicAdd(&L.prof[7], 1ull); atomicAdd(&L.prof[8], (unsigned long long)n); }
+        for (uint32_t i = threadIdx.x; i < ns; i += PB2_T) full_point(sv_s[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)wloc, o); wloc = y > wloc ? y : wloc; }
+        // (wmax starts at 1 for every genome of a bucketed chunk: the common all-unique bucket sends nothing; the read goes to the L2
+        // like the atomics do - a plain load may come from a stale L1 line and would let every wave of every bucket send an atomic to
+        // the same address)
+        if ((threadIdx.x & 63) == 0 && wloc > 1 && wloc > __hip_atomic_load(&wmax[gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&wmax[gl], wloc);
+        __syncthreads();
+        GS_PSTAMP(3);
+        const uint32_t nst = s_nc < (uint32_t)PB_CST ? s_nc : (uint32_t)PB_CST;
+        if (pf) atomicAdd(&L.prof[9], (unsigned long long)s_nc);
+        if (nst) {
+            if (my_nc + nst > seg) { if (threadIdx.x == 0) atomicMax(L.n_cand, 0xFFFFFFFFu); }       // segment full: the host redoes the chunk the sorted way
+            else {
+                const uint32_t cb = blockIdx.x * seg + my_nc;
+                for (uint32_t i = threadIdx.x; i < nst; i += PB2_T) { L.cand_v[cb + i] = sc_v[i]; L.cand_h[cb + i] = sc_h[i]; L.cand_gb[cb + i] = (uint64_t)gl * m + sc_b[i]; }
+                my_nc += nst;
+            }
+        }
+        GS_PSTAMP(4);
+#undef GS_PSTAMP
+    }
+    if (threadIdx.x == 0) L.seg_n[blockIdx.x] = my_nc;
+}
+__global__ void k_prob_claim_list(const uint64_t *__restrict__ cand_v, const uint64_t *__restrict__ cand_h, const uint64_t *__restrict__ cand_gb, const uint32_t *__restrict__ seg_n,
+                                  uint32_t seg, uint32_t nseg, uint32_t cand_cap, const uint32_t *__restrict__ n_ovf, uint32_t ovf_cap, const uint64_t *__restrict__ q,
+                                  uint64_t *__restrict__ sigpass)
+{
+    // one workgroup per segment (the bucket kernel's workgroups each filled their own), then the shared overflow region
+    for (uint32_t sgm = blockIdx.x; sgm <= nseg; sgm += gridDim.x) {
+        const bool ov = sgm == nseg;
+        const uint32_t base = ov ? cand_cap : sgm * seg;
+        uint32_t n = ov ? *n_ovf : seg_n[sgm];
+        if (ov && n > ovf_cap) n = ovf_cap;
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const uint64_t gb = cand_gb[base + e];
+            if (cand_h[base + e] == q[gb]) atomicMin((unsigned long long *)&sigpass[gb], (unsigned long long)cand_v[base + e]);
+        }
+    }
+}
+// passes >= 2 over the active list (generator state carried from point to point)
+__global__ void k_prob_point_act(const uint64_t *__restrict__ akey, const uint32_t *__restrict__ agl, const uint32_t *__restrict__ acnt, uint32_t na, uint32_t cap, uint32_t m,
+                                 uint64_t zone, ProbConst pc, uint32_t it, const double *__restrict__ qmax, uint64_t *__restrict__ q, uint64_t *__restrict__ astate,
+                                 uint64_t *__restrict__ cand_h, uint32_t *__restrict__ cand_b)
+{
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < na; e += gridDim.x * blockDim.x) {
+        const uint32_t gl = agl[e];
+        const double winv = 1.0 / (double)acnt[e];
+        const double base = winv * (double)(it - 1);
+        uint32_t b = 0xFFFFFFFFu; uint64_t hb = 0;
+        if (!(base > qmax[gl])) {
+            Rng rg; rg.s0 = astate[e]; rg.s1 = astate[(uint64_t)cap + e]; rg.s2 = astate[2 * (uint64_t)cap + e]; rg.s3 = astate[3 * (uint64_t)cap + e];
+            const double x = texp_sample(pc, rg);
+            b = (uint32_t)rng_uint(rg, (uint64_t)m, zone);
+            astate[e] = rg.s0; astate[(uint64_t)cap + e] = rg.s1; astate[2 * (uint64_t)cap + e] = rg.s2; astate[3 * (uint64_t)cap + e] = rg.s3;
+            const double h = base + winv * x;
+            hb = (uint64_t)__double_as_longlong(h);
+            uint64_t *slot = q + (uint64_t)gl * m + b;
+            if (hb < *slot) atomicMin((unsigned long long *)slot, (unsigned long long)hb);
+        }
+        cand_b[e] = b; cand_h[e] = hb;
+    }
+}
+__global__ void k_prob_claim_act(const uint64_t *__restrict__ akey, const uint32_t *__restrict__ agl, uint32_t na, uint32_t m, const uint64_t *__restrict__ q,
+                                 const uint64_t *__restrict__ cand_h, const uint32_t *__restrict__ cand_b, uint64_t *__restrict__ sigpass)
+{
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < na; e += gridDim.x * blockDim.x) {
+        const uint32_t b = cand_b[e];
+        if (b == 0xFFFFFFFFu) continue;
+        const uint64_t gb = (uint64_t)agl[e] * m + b;
+        if (cand_h[e] == q[gb]) atomicMin((unsigned long long *)&sigpass[gb], (unsigned long long)akey[e]);
+    }
+}
+
+static int run_prob_sorted(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, uint64_t seq_bytes, const uint64_t *rec_start, const uint64_t *rec_len,
+                           uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out);
+
+// one chunk of genomes [g0, g0 + ng) through the bucketed form; hk = k-mers per genome (host). *redo (ng flags, host) marks genomes that
+// must be redone by the sorted form; returns GS_OK with every flag set when a list overflowed.
+static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *upre,
+                            const uint64_t *genome_rec_off, const uint64_t *gunits, uint64_t g0, uint32_t ng, const uint64_t *hk, const ProbConst &pc, void *sig_rows,
+                            std::vector<uint8_t> &redo)
+{
+    const uint32_t m = p->sketch_size, k = p->k;
+    const bool aa = p->data_t == GS_DATA_AA;
+    const int sigbits = gs_value_bits(p);
+    const uint64_t zone = uint_zone(m);
+    int rc;
+    // host plan: buckets per genome, flat bucket offsets, value offsets
+    const uint32_t vbits = aa ? 5 * k : 2 * k;
+    std::vector<uint32_t> sh(ng), boff(ng + 1); std::vector<uint64_t> vbase(ng);
+    uint64_t T = 0, maxk = 0; uint32_t nbmax = 1, nbt = 0, shmax = 0;
+    for (uint32_t i = 0; i < ng; i++) {
+        uint32_t lg = 0; while (((uint64_t)PB_AVG << lg) < hk[i] && lg < vbits) lg++;
+        sh[i] = vbits - lg; shmax = std::max(shmax, sh[i]); boff[i] = nbt; nbt += 1u << lg; nbmax = std::max(nbmax, 1u << lg);
+        vbase[i] = T; T += hk[i]; maxk = std::max(maxk, hk[i]);
+    }
+    const bool id32 = shmax <= 31 && !getenv("GS_PROB_ID64");       // every genome's in-bucket id fits 4 bytes (with ~0 left over for "empty")
+    boff[ng] = nbt;
+    const uint64_t avg_units = maxk / 32 + 1;
+    const uint32_t parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(avg_units / ((uint64_t)PBK_T * PBK_WPL) + 1, std::max<uint64_t>(1, (2 * (uint64_t)c->n_cu + ng - 1) / ng)));
+    PoolBuf dsh(c, 0), dboff(c, 1), dvb(c, 2), hist(c, 3), bst(c, 4), bsz(c, 5), bgn(c, 6), vals(c, 8), q(c, 9), qprev(c, 10), sig(c, 11), sigpass(c, 12), thr(c, 13), wmax(c, 14),
+        qmax(c, 15), ctr(c, 7);
+    PoolBuf cv(c, 16), chh(c, 17), cgb(c, 18), akey(c, 19), agl(c, 24), acnt(c, 25), astate(c, 26), ph(c, 27), pb(c, 37), ovf(c, 38);
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)ng * m * 16 + 65536, (uint64_t)1 << 30), ovf_cap = cand_cap / 4, act_cap = 1u << 24;
+    PoolBuf segn(c, 28);
+    if ((rc = dsh.alloc(4 * (size_t)ng)) || (rc = dboff.alloc(4 * (size_t)(ng + 1))) || (rc = dvb.alloc(8 * (size_t)ng)) || (rc = hist.alloc((size_t)4 * nbt * parts)) ||
+        (rc = bst.alloc((size_t)4 * nbt)) || (rc = bsz.alloc((size_t)4 * nbt)) || (rc = bgn.alloc((size_t)4 * nbt)) || (rc = vals.alloc(8 * (size_t)T + 64)) ||
+        (rc = q.alloc((size_t)8 * ng * m)) || (rc = qprev.alloc((size_t)8 * ng * m)) || (rc = sig.alloc((size_t)8 * ng * m)) || (rc = sigpass.alloc((size_t)8 * ng * m)) ||
+        (rc = thr.alloc(8 * (size_t)ng)) || (rc = wmax.alloc(4 * (size_t)ng)) || (rc = qmax.alloc(8 * (size_t)ng)) || (rc = ctr.alloc(64)) ||
+        (rc = cv.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = chh.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = cgb.alloc((size_t)8 * (cand_cap + ovf_cap))) ||
+        (rc = ovf.alloc(4 * (size_t)ng)) || (rc = segn.alloc((size_t)4 * c->n_cu * 8)))
+        return rc;
+    GS_HIP_CHECK(hipMemcpyAsync(dsh.p, sh.data(), 4 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dboff.p, boff.data(), 4 * (size_t)(ng + 1), hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dvb.p, vbase.data(), 8 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_prob_init, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), ng * (uint64_t)m);
+    {
+        std::vector<uint32_t> ones(ng, 1u);                        // every genome of this chunk has k-mers (>= 64 per slot)
+        GS_HIP_CHECK(hipMemcpyAsync(wmax.p, ones.data(), 4 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    GS_HIP_CHECK(hipMemsetAsync(ovf.p, 0, 4 * (size_t)ng, c->stream));
+    GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));          // [0..1] work counter, [2] n_cand, [3] n_act, [4] n_active genomes
+    uint32_t *ctr32 = ctr.as<uint32_t>();
+    size_t lds = (size_t)4 * nbmax;
+    if (getenv("GS_PROB_LDS_PAD")) lds = std::max<size_t>(lds, (size_t)atoi(getenv("GS_PROB_LDS_PAD")) * 1024);     // experiment: fewer resident scatter workgroups
+    {
+        ProfScope ps(c, FAM_SKETCH);
+        dim3 grid(parts, ng), block(PBK_T);
+#define GS_LAUNCH_PBP(AAV, MODE)                                                                                              \
+    do {                                                                                                                      \
+        auto kern = k_prob_partition<AAV, MODE>;                                                                              \
+        if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, block, lds, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, k, vbits, dsh.as<uint32_t>(), dboff.as<uint32_t>(), parts, \
+                           hist.as<uint32_t>(), q.as<uint64_t>(), m, zone, pc, vals.as<uint64_t>(), dvb.as<uint64_t>());      \
+    } while (0)
+        if (aa) GS_LAUNCH_PBP(true, 0); else GS_LAUNCH_PBP(false, 0);
+        hipLaunchKernelGGL(k_prob_scan, dim3(ng), dim3(1024), 0, c->stream, vbits, dsh.as<uint32_t>(), dboff.as<uint32_t>(), parts, hist.as<uint32_t>(), bst.as<uint32_t>(), bsz.as<uint32_t>(),
+                           bgn.as<uint32_t>(), q.as<uint64_t>(), m, thr.as<uint64_t>());
+        if (aa) GS_LAUNCH_PBP(true, 1); else GS_LAUNCH_PBP(false, 1);
+#undef GS_LAUNCH_PBP
+        GS_HIP_CHECK(hipGetLastError());
+        if ((rc = akey.alloc((size_t)8 * act_cap)) || (rc = agl.alloc((size_t)4 * act_cap)) || (rc = acnt.alloc((size_t)4 * act_cap)) || (rc = astate.alloc((size_t)32 * act_cap))) return rc;
+        PbLists L{cv.as<uint64_t>(), chh.as<uint64_t>(), cgb.as<uint64_t>(), cand_cap, ovf_cap, ctr32 + 2, segn.as<uint32_t>(), akey.as<uint64_t>(), agl.as<uint32_t>(), acnt.as<uint32_t>(),
+                  astate.as<uint64_t>(), act_cap, ctr32 + 3, nullptr};
+        DevBuf profbuf;
+        if (getenv("GS_PROB_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); L.prof = profbuf.as<unsigned long long>(); }
+        int per_cu = 3;
+        if (id32) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_prob_buckets<uint32_t>, PB2_T, 0);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_prob_buckets<uint64_t>, PB2_T, 0);
+        uint32_t lg_max = 0; while ((1u << lg_max) < nbmax) lg_max++;
+        const uint32_t wgs = (uint32_t)std::min<uint64_t>((uint64_t)ng << lg_max, (uint64_t)c->n_cu * std::min(std::max(per_cu, 1), 8));     // resident workgroups only: the items are dealt statically
+#define GS_LAUNCH_PBB(KT)                                                                                                     \
+        hipLaunchKernelGGL(k_prob_buckets<KT>, dim3(wgs), dim3(PB2_T), 0, c->stream, vals.as<uint64_t>(), dvb.as<uint64_t>(), bst.as<uint32_t>(), bsz.as<uint32_t>(), vbits, \
+                           dsh.as<uint32_t>(), dboff.as<uint32_t>(), ng, lg_max, m, zone, pc, q.as<uint64_t>(), thr.as<uint64_t>(), wmax.as<uint32_t>(), L, ovf.as<uint32_t>())
+        if (id32) GS_LAUNCH_PBB(uint32_t); else GS_LAUNCH_PBB(uint64_t);
+#undef GS_LAUNCH_PBB
+        if (L.prof) {
+            unsigned long long h[16];
+            GS_HIP_CHECK(hipMemcpyAsync(h, L.prof, 128, hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            const double it = (double)std::max<unsigned long long>(h[7], 1);
+            fprintf(stderr, "[GS_PROB_PROFILE] workgroup 0 of %u (%d per CU): %llu buckets, keys/bucket %.0f, queued %.0f, candidates %.1f | cycles per bucket: zero+thr %.0f, insert %.0f, cheap test %.0f, full points %.0f, flush %.0f\n",
+                    wgs, per_cu, h[7], h[8] / it, h[6] / it, h[9] / it, h[0] / it, h[1] / it, h[2] / it, h[3] / it, h[4] / it);
+        }
+        hipLaunchKernelGGL(k_prob_claim_list, dim3(wgs + 1), dim3(256), 0, c->stream, cv.as<uint64_t>(), chh.as<uint64_t>(), cgb.as<uint64_t>(), segn.as<uint32_t>(), cand_cap / wgs, wgs,
+                           cand_cap, ctr32 + 2, ovf_cap, q.as<uint64_t>(), sigpass.as<uint64_t>());
+        hipLaunchKernelGGL(k_prob_fold, dim3(ng), dim3(256), 0, c->stream, m, 1u, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), wmax.as<uint32_t>(),
+                           qmax.as<double>(), ctr32 + 4);
+        GS_HIP_CHECK(hipGetLastError());
+    }
+    uint32_t hc[8]; std::vector<uint32_t> hovf(ng);
+    GS_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, 32, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(hovf.data(), ovf.p, 4 * (size_t)ng, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));               // the one host round trip of a chunk whose genomes finish in pass 1
+    redo.assign(ng, 0);
+    if (hc[2] > ovf_cap || hc[3] > act_cap) { redo.assign(ng, 1); return GS_OK; }      // a list overflowed: the whole chunk goes the sorted way
+    for (uint32_t i = 0; i < ng; i++) redo[i] = hovf[i] ? 1 : 0;
+    uint32_t na = hc[4];
+    const uint32_t n_list = hc[3];
+    if (na && n_list) {
+        if ((rc = ph.alloc((size_t)8 * n_list)) || (rc = pb.alloc((size_t)4 * n_list))) return rc;
+        const uint32_t lg = std::max<uint32_t>(1, std::min<uint32_t>((n_list + 255) / 256, (uint32_t)c->n_cu * 16));
+        for (uint32_t it = 2; na; it++) {
+            GS_HIP_CHECK(hipMemsetAsync(ctr32 + 4, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_prob_point_act, dim3(lg), dim3(256), 0, c->stream, akey.as<uint64_t>(), agl.as<uint32_t>(), acnt.as<uint32_t>(), n_list, act_cap, m, zone, pc, it,
+                               qmax.as<double>(), q.as<uint64_t>(), astate.as<uint64_t>(), ph.as<uint64_t>(), pb.as<uint32_t>());
+            hipLaunchKernelGGL(k_prob_claim_act, dim3(lg), dim3(256), 0, c->stream, akey.as<uint64_t>(), agl.as<uint32_t>(), n_list, m, q.as<uint64_t>(), ph.as<uint64_t>(), pb.as<uint32_t>(),
+                               sigpass.as<uint64_t>());
+            hipLaunchKernelGGL(k_prob_fold, dim3(ng), dim3(256), 0, c->stream, m, it, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), wmax.as<uint32_t>(),
+                               qmax.as<double>(), ctr32 + 4);
+            GS_HIP_CHECK(hipGetLastError());
+            GS_HIP_CHECK(hipMemcpyAsync(&na, ctr32 + 4, 4, hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+    }
+    if (sigbits == 32) hipLaunchKernelGGL(k_prob_write<uint32_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint32_t *)sig_rows);
+    else hipLaunchKernelGGL(k_prob_write<uint64_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint64_t *)sig_rows);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+// prob driver: runs of genomes the bucketed form suits go through it in chunks, the rest (and what it flags) through the sorted form
 static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, uint64_t seq_bytes, const uint64_t *rec_start, const uint64_t *rec_len,
                     uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out)
+{
+    const uint32_t m = p->sketch_size, k = p->k;
+    const char *e = getenv("GS_PROB_IMPL");
+    if (e && !strcmp(e, "sort")) return run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off, n_genomes, sig_out);
+    ProbConst pc;
+    pc.lambda = log((double)m / (double)(m - 1));
+    pc.c1 = expm1(pc.lambda) / pc.lambda;
+    pc.c2 = log(2.0 / (1.0 + exp(-pc.lambda))) / pc.lambda;
+    pc.c3 = (1.0 - exp(-pc.lambda)) / pc.lambda;
+    int rc;
+    DevBuf upre, gunits, kpre, gkm;              // (own allocations: the sorted form called below uses the scratch-pool slots of the same names)
+    if ((rc = upre.alloc(8 * (n_rec + 1))) || (rc = gunits.alloc(8 * n_genomes)) || (rc = kpre.alloc(8 * (n_rec + 1))) || (rc = gkm.alloc(8 * n_genomes))) return rc;
+    const uint32_t gb = (uint32_t)((n_genomes + 3) / 4);
+    hipLaunchKernelGGL(k_unit_prefix, dim3(gb), dim3(256), 0, c->stream, rec_start, rec_len, genome_rec_off, n_genomes, k, upre.as<uint64_t>(), gunits.as<uint64_t>());
+    hipLaunchKernelGGL(k_kmer_prefix, dim3(gb), dim3(256), 0, c->stream, rec_len, genome_rec_off, n_genomes, k, kpre.as<uint64_t>(), gkm.as<uint64_t>());
+    GS_HIP_CHECK(hipGetLastError());
+    std::vector<uint64_t> hk(n_genomes);
+    GS_HIP_CHECK(hipMemcpyAsync(hk.data(), gkm.p, 8 * n_genomes, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const size_t row = (size_t)m * (gs_value_bits(p) / 8);
+    auto suits = [&](uint64_t g) { return hk[g] >= (uint64_t)64 * m && hk[g] <= (uint64_t)PB_NBMAX * PB_AVG; };
+    const uint64_t max_items = (uint64_t)3 << 29;                 // ~1.6e9 k-mers per chunk (12.9 GB of bucketed values)
+    for (uint64_t g0 = 0; g0 < n_genomes;) {
+        uint64_t g1 = g0 + 1;
+        if (!suits(g0)) {
+            while (g1 < n_genomes && !suits(g1)) g1++;
+            if ((rc = run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off + g0, g1 - g0, (uint8_t *)sig_out + row * g0))) return rc;
+            g0 = g1;
+            continue;
+        }
+        uint64_t T = hk[g0];
+        while (g1 < n_genomes && suits(g1) && g1 - g0 < 65535 && T + hk[g1] <= max_items) { T += hk[g1]; g1++; }
+        std::vector<uint8_t> redo;
+        if ((rc = run_prob_buckets(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, pc,
+                                   (uint8_t *)sig_out + row * g0, redo))) return rc;
+        for (uint64_t g = g0; g < g1;) {                          // flagged genomes, in runs
+            if (!redo[g - g0]) { g++; continue; }
+            uint64_t h = g + 1;
+            while (h < g1 && redo[h - g0]) h++;
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if ((rc = run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off + g, h - g, (uint8_t *)sig_out + row * g))) return rc;
+            g = h;
+        }
+        g0 = g1;
+    }
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+static int run_prob_sorted(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, uint64_t seq_bytes, const uint64_t *rec_start, const uint64_t *rec_len,
+                           uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out)
 {
     const uint32_t m = p->sketch_size, k = p->k;
     const bool aa = p->data_t == GS_DATA_AA;

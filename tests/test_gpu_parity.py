@@ -334,6 +334,39 @@ def test_sketch_prob_matches_oracle(gpu_ctx, k, m, data):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("k,m,data,length", [(21, 1000, "dna", 200000), (16, 512, "dna", 90000), (32, 700, "dna", 120000), (7, 600, "aa", 100000), (21, 18000, "dna", 1600000)])
+@pytest.mark.parametrize("impl", ["buckets", "sort"])
+def test_sketch_prob_bucketed_form_matches_oracle(gpu_ctx, monkeypatch, k, m, data, length, impl):
+    """ProbMinHash3a on genomes with >= 64 k-mers per slot, which take the bucketed form (partition by hash bits -> LDS hash -> (value,
+    multiplicity) -> first points under a running rejection threshold): repeats of multiplicity 2..40 (pass 2 and later over the active
+    list), a genome in two parts workgroups split, multi-record genomes, and small genomes in the same batch (sorted form) - bit-exact
+    against the oracle, and the sorted form (GS_PROB_IMPL=sort) gives the same signatures"""
+    import gsearch_amd as G
+    if impl == "sort":
+        monkeypatch.setenv("GS_PROB_IMPL", "sort")
+    rng = np.random.default_rng(k * 131 + m)
+    if data == "dna":
+        fam = H.family(rng, length, [0.01, 0.05])
+        asc = [H.dna_ascii(g) for g in fam]
+        rep = asc[0][:400] * 40                                   # multiplicities up to 40: alive in pass 2 and beyond
+        genomes = [[a] for a in asc]
+        genomes.append([asc[0][: length // 2] + rep, b"ACGTNN", asc[1][1000: length // 2], rep, asc[2][: length // 3]])
+        genomes.append([asc[1][:5000]])                           # a small genome between big ones: sorted form
+        genomes.append([asc[2] + asc[2][: length // 4]])          # a quarter of the k-mers twice
+        genomes.append([b"ACG"])
+    else:
+        fam = H.family(rng, length, [0.02], alphabet=20)
+        asc = [H.aa_ascii(g) for g in fam]
+        rep = asc[0][:150] * 30
+        genomes = [[a] for a in asc] + [[asc[0][: length // 2] + rep + b"*", rep, asc[1][: length // 2]], [b"MKV"], [asc[1] + asc[1][: length // 5]]]
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "prob", data))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(k, m, "prob", genomes, data)
+    assert got.dtype == ref.dtype
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert len(bad) == 0, ("genomes differing", bad.tolist(), [int((got[i] != ref[i]).sum()) for i in bad])
+
+
 def test_index_dump_and_reload(gpu_ctx, tmp_path):
     """file_dump / load round trip (own format): identical graph, data and answers; `add` continues on the reloaded index"""
     import gsearch_amd as G
