@@ -612,7 +612,7 @@ class Hnsw:
         check(self.ctx.L.gs_index_search_stats(self.h, _p(out), int(reset)))
         pops = int(out[1])
         return {"join_atomics": int(out[0]), "pops": pops, "accepting_pops": int(out[2]), "wg_in_flight": int(out[3]),
-                "adj_bytes": pops * int(out[4])}
+                "adj_bytes": pops * int(out[4]), "pops_phase1": int(out[5]), "pops_phase2": int(out[6])}
 
     def file_dump_hnswrs(self, basename, truncate_255=False):
         """Hnsw::file_dump(dir, "hnswdump") in hnsw_rs' own format: <basename>.hnsw.graph + <basename>.hnsw.data (dumpload.rs:26-31).

@@ -479,6 +479,73 @@ __device__ __forceinline__ uint32_t dense_merge_T(uint64_t *keys, uint32_t n, co
     return tot < keep ? tot : keep;
 }
 
+// tau = the efs-th smallest mismatch count of the query over ALL n nodes (INF_CNT when n < efs): a lower bound of the worst count a full R
+// can ever reach - fewer than efs nodes of the whole database lie below it. Once dmax == tau the accept rule is "count < tau" for good and
+// the rest of the traversal does not depend on the order of the pops any more (phase 2 below). One scan of the query's count row (16-byte
+// loads, 8 counts per lane): counts are binned 64 to a bin (`coarse`, nb bins) and, for the bin that holds m itself - where the flood
+// regime puts the answer - one by one (`fine`); the four largest values (m .. m-3: ~99 % of the nodes of an unrelated database) are
+// tallied with ballots instead of LDS atomics on one address. A second scan only when the answer lies in another bin.
+__device__ __forceinline__ uint32_t dense_row_tau(const uint16_t *__restrict__ matrow, uint64_t n, uint32_t m, uint32_t efs, uint32_t *coarse, uint32_t *fine, uint32_t *res)
+{
+    if (n < efs) return INF_CNT;
+    const uint32_t nb = dense_nblocks(m), lane = threadIdx.x & 63;
+    const uint4 *row16 = (const uint4 *)matrow;
+    const uint32_t n16 = (uint32_t)((n + 7) / 8);
+    uint32_t target = m / HB;
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t i = threadIdx.x; i < nb; i += DT) coarse[i] = 0;
+        if (threadIdx.x < (uint32_t)HB) fine[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t top[4] = {0, 0, 0, 0};                       // wave-level tallies of m, m-1, m-2, m-3 (lane 0 holds them)
+        for (uint32_t i0 = 0; i0 < n16; i0 += DT) {
+            const uint32_t i = i0 + threadIdx.x;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < n16) v = row16[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const uint32_t c = (w[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                const bool valid = i < n16 && (uint64_t)i * 8 + h < n;
+                const uint32_t d = m - c;                      // 0 for c == m; "negative" (huge) never happens: c <= m
+                const bool t0 = valid && d == 0, t1 = valid && d == 1, t2 = valid && d == 2, t3 = valid && d == 3;
+                top[0] += (uint32_t)__popcll(__ballot(t0)); top[1] += (uint32_t)__popcll(__ballot(t1));
+                top[2] += (uint32_t)__popcll(__ballot(t2)); top[3] += (uint32_t)__popcll(__ballot(t3));
+                if (valid && d > 3) { atomicAdd(&coarse[c / HB], 1u); if (c / HB == target) atomicAdd(&fine[c % HB], 1u); }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (top[t] && m >= (uint32_t)t) { const uint32_t c = m - t; atomicAdd(&coarse[c / HB], top[t]); if (c / HB == target) atomicAdd(&fine[c % HB], top[t]); }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                               // one wave: the bin where the running total reaches efs
+            uint32_t run = 0, found = 0xFFFFFFFFu, before = 0;
+            for (uint32_t b0 = 0; b0 < nb && found == 0xFFFFFFFFu; b0 += 64) {
+                const uint32_t x = b0 + lane < nb ? coarse[b0 + lane] : 0;
+                uint32_t inc = x;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+                const uint64_t hit = __ballot(run + inc >= efs);
+                if (hit) { const uint32_t l = (uint32_t)__ffsll((long long)hit) - 1; found = b0 + l; before = run + __shfl(inc, l) - __shfl(x, l); }
+                run += __shfl(inc, 63);
+            }
+            if (lane == 0) { res[0] = found; res[1] = before; }
+        }
+        __syncthreads();
+        const uint32_t bin = res[0], before = res[1];
+        if (bin == target) {
+            if (threadIdx.x == 0) { uint32_t run = before, f = 0; for (; f < (uint32_t)HB; f++) { run += fine[f]; if (run >= efs) break; } res[2] = bin * HB + f; }
+            __syncthreads();
+            const uint32_t tau = res[2];
+            __syncthreads();
+            return tau;
+        }
+        target = bin;                                          // rare: the answer is not near m - tally that bin one by one in a second scan
+        __syncthreads();
+    }
+    return INF_CNT;                                            // (not reached: the second pass always finds its bin)
+}
+
 // a wave-uniform value the compiler cannot prove uniform (it came through LDS): pin it to an SGPR
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // ONEG: max_nb_conn > 128 (adjacency rows of up to 512 ids): all 512 lanes form ONE group that expands a candidate, then does the visited
@@ -498,7 +565,8 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t efs = ef > knbn ? ef : knbn;
     const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
-    uint32_t st_pops = 0, st_acc = 0;                            // work counters (workgroup-uniform): pops / accepting pops of this workgroup (< 2^32)
+    uint32_t st_pops = 0, st_acc = 0, st_p1 = 0, st_p2 = 0;                 // work counters (workgroup-uniform): pops / accepting pops / pops before dmax reached tau, of this workgroup (< 2^32)
+    constexpr bool PHASE2 = VLDS && !WLOG && !PROF;
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;         // capacity of N: >= 2M (an empty N takes a whole expansion), one key per lane in its merge
@@ -529,6 +597,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         uint64_t *wl = WLOG ? wlog + (uint64_t)blockIdx.x * cap_log : nullptr;
         uint32_t nlog = 1;
         const uint16_t *matrow = mat + qi * mat_ld;
+        const uint32_t tau = PHASE2 ? dense_row_tau(matrow, ix.n, ix.m, efs, S.H1, S.hist, S.wsum) : 0u;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
         for (uint32_t w = threadIdx.x; w < hwords; w += DT) hs.Hf[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb * (HB / HG / 2); w += DT) S.H2[w] = 0;
@@ -585,7 +654,9 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         bool pclr = false;
         uint64_t nk = ~(uint64_t)0;                              // ONEG: row fetched for the candidate after next (no hint, no lookups yet)
         uint32_t nid = 0, ndeg = 0;
+        bool phase2 = false;
         for (;;) {
+            if (PHASE2 && dmax == tau && !(cap_log & 1u)) { phase2 = true; break; }       // R holds efs keys <= tau (or n < efs): the rest is order-free
             if (headG < nG && headG - wbase >= wn) {                 // refill the LDS window of G
                 __syncthreads();
                 wbase = headG; wn = nG - headG < (uint32_t)DWIN ? nG - headG : (uint32_t)DWIN;
@@ -677,6 +748,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             const long long p3 = PROF ? clock64() : 0;
             if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { t_a += p1 - p0; t_b += p2 - p1; t_c += p3 - p2; n_pop++; }
             st_pops++;
+            if (PHASE2 && dmax != tau) st_p1++;
             if (ne == 0) continue;
             evals += ne;
             // closed-form accept rule: e_i is accepted iff #{x in R: c(x) <= c_i} + #{j<i: c_j <= c_i} < ef (and c_i < dmax once R is
@@ -873,6 +945,109 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const long long q4 = clock64(); t_e += q4 - p4; tq1 += q1 - p4; tq2 += q2 - q1; tq3 += q3 - q2; tq4 += q4 - q3; tna += na; }
         }
         __syncthreads();
+        if (PHASE2 && phase2) {
+            // ================= phase 2: the order-free rest of search_layer =================
+            // dmax == tau, the efs-th smallest count of the whole database: fewer than efs nodes lie below it, so dmax can never drop
+            // again, the accept rule is "count < tau" from here on, every accepted key stays and is popped, and so is every candidate
+            // already waiting with count <= tau. The set of nodes that get evaluated - hence ids, distances AND the evaluation count -
+            // is the closure of the waiting candidates under "neighbours with count < tau", whatever the order of the pops. So the
+            // candidates become a plain work list that the eight wavefronts drain independently, one adjacency row per wavefront and
+            // step, with one barrier per generation instead of several per pop; the 2-byte count look-up (an HBM sector each) is only
+            // made for neighbours that pass a Bloom filter of the < efs nodes below tau, built from one scan of the query's count row
+            // in LDS that phase 1 no longer needs.
+            uint32_t *s_cnt = (uint32_t *)&S.scal[4];                // [0] work-list tail, [1] keys for T, [2] evaluations
+            uint32_t *WL = (uint32_t *)Cb[cur ^ 1];                  // node ids to expand (capacity 2 * capC >= waiting + < efs accepted)
+            uint64_t *TA = Cb[cur];                                  // accepted keys that may enter T (the old G array: consumed below first)
+            if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+            __syncthreads();
+            {   // waiting candidates with count <= tau: live G (global, sorted) and live N (LDS)
+                const uint64_t *src = Cb[cur] + headG;
+                const uint32_t liveG = nG - headG, liveN = nN - headN;
+                for (uint32_t i = threadIdx.x; i < liveG; i += DT) { const uint64_t k = src[i]; if (KCNT(k) <= tau) WL[atomicAdd(&s_cnt[0], 1u)] = KID(k); }
+                for (uint32_t i = threadIdx.x; i < liveN; i += DT) { const uint64_t k = S.N[headN + i]; if (KCNT(k) <= tau) WL[atomicAdd(&s_cnt[0], 1u)] = KID(k); }
+            }
+            __syncthreads();
+            // Bloom filter of {node : count < tau} in two dead LDS regions (A + G window + N, and Eid .. fold histogram), one hash each
+            uint32_t *bfA = (uint32_t *)S.A, *bfB = S.Eid;
+            const uint32_t bytesA = 8 * maxdeg + 8 * (DWIN + 4) + 8 * (CN + 4), bytesB = (uint32_t)((uint8_t *)S.wsum - (uint8_t *)S.Eid);
+            uint32_t lgA = 5, lgB = 5;
+            while ((2u << lgA) <= 8 * bytesA) lgA++;
+            while ((2u << lgB) <= 8 * bytesB) lgB++;
+            for (uint32_t w = threadIdx.x; w < (1u << (lgA - 5)); w += DT) bfA[w] = 0;
+            for (uint32_t w = threadIdx.x; w < (1u << (lgB - 5)); w += DT) bfB[w] = 0;
+            __syncthreads();
+            {
+                const uint4 *row16 = (const uint4 *)matrow;
+                const uint32_t n16 = (uint32_t)((ix.n + 7) / 8);
+                for (uint32_t i = threadIdx.x; i < n16; i += DT) {
+                    const uint4 v = row16[i];
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int h = 0; h < 8; h++) {
+                        const uint32_t cc = (w4[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu, id = i * 8 + h;
+                        if (cc < tau && id < ix.n) {
+                            const uint32_t ha = (id * 0x9E3779B1u) >> (32 - lgA), hb = (id * 0x85EBCA77u) >> (32 - lgB);
+                            atomicOr(&bfA[ha >> 5], 1u << (ha & 31)); atomicOr(&bfB[hb >> 5], 1u << (hb & 31));
+                        }
+                    }
+                }
+            }
+            const bool t_open = nT < knbn;                           // T not full: every accepted key is a candidate for it
+            const uint64_t t_max = Tmax;
+            uint32_t nev = 0, head = 0;
+            const uint32_t nrow = (maxdeg + 63) / 64;
+            for (;;) {
+                __syncthreads();
+                const uint32_t tail = s_cnt[0];
+                if (head >= tail) break;
+                for (uint32_t itx = head + wv; itx < tail; itx += DT / 64) {
+                    const uint32_t node = uni32(WL[itx]);
+                    const uint32_t deg = ix.deg0[node];
+                    const uint32_t *row = ix.nbr0 + (uint64_t)node * maxdeg;
+                    for (uint32_t j = 0; j < nrow; j++) {
+                        const uint32_t idx = lane + 64 * j;
+                        if (idx >= deg) continue;
+                        const uint32_t id = row[idx];
+                        const uint32_t bit = 1u << (id & 31);
+                        const uint32_t old = atomicOr(&vis[id >> 5], bit);
+                        if (old & bit) continue;
+                        nev++;
+                        const uint32_t ha = (id * 0x9E3779B1u) >> (32 - lgA), hb = (id * 0x85EBCA77u) >> (32 - lgB);
+                        if (!((bfA[ha >> 5] >> (ha & 31)) & (bfB[hb >> 5] >> (hb & 31)) & 1u)) continue;      // certainly not below tau
+                        const uint32_t cc = matrow[id];
+                        if (cc >= tau) continue;
+                        WL[atomicAdd(&s_cnt[0], 1u)] = id;           // accepted: expanded in the next generation
+                        const uint64_t key = KEY(cc, id);
+                        if (t_open || key < t_max) TA[atomicAdd(&s_cnt[1], 1u)] = key;
+                    }
+                }
+                st_p2 += tail - head;
+                head = tail;
+            }
+            st_pops += head;
+            if (nev) atomicAdd(&s_cnt[2], nev);
+            __syncthreads();
+            evals += s_cnt[2];
+            // T <- knbn smallest of T u TA, in chunks the existing merge takes (sorted A of at most maxdeg keys; A's region is free again)
+            const uint32_t nta = s_cnt[1];
+            const uint32_t CHK = maxdeg < (uint32_t)DT ? maxdeg : (uint32_t)DT;
+            for (uint32_t c0 = 0; c0 < nta; c0 += CHK) {
+                const uint32_t na = nta - c0 < CHK ? nta - c0 : CHK;
+                __syncthreads();
+                if (threadIdx.x < na) S.As[threadIdx.x] = TA[c0 + threadIdx.x];
+                __syncthreads();
+                if (threadIdx.x < na) {
+                    const uint64_t k = S.As[threadIdx.x];
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < na; j++) rank += (S.As[j] < k);
+                    S.A[rank] = k;
+                }
+                __syncthreads();
+                const SmallA sa = load_small_a(S.A, na);
+                nT = dense_merge_T(S.T, nT, S.A, na, knbn, sa);
+            }
+            __syncthreads();
+        }
         if (ids_out) for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
             if (i < nT) { ids_out[qi * knbn + i] = KID(S.T[i]); dist_out[qi * knbn + i] = (float)KCNT(S.T[i]) / (float)ix.m; }
             else { ids_out[qi * knbn + i] = ~(uint64_t)0; dist_out[qi * knbn + i] = INFINITY; }
@@ -917,7 +1092,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     }
 #undef GS_DROW
 #undef GS_DROWX
-    if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], (unsigned long long)st_pops); atomicAdd(&stats[2], (unsigned long long)st_acc); }
+    if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], (unsigned long long)st_pops); atomicAdd(&stats[2], (unsigned long long)st_acc); atomicAdd(&stats[5], (unsigned long long)st_p1); atomicAdd(&stats[6], (unsigned long long)st_p2); }
     if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
         atomicAdd(&prof[3], (unsigned long long)t_d); atomicAdd(&prof[4], (unsigned long long)t_e); atomicAdd(&prof[5], (unsigned long long)n_pop); atomicAdd(&prof[6], (unsigned long long)n_merge);
@@ -1641,6 +1816,8 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     if ((rc = ix->cbuf.ensure((size_t)16 * capC * c->n_cu * 3))) return rc;
     GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
     IndexDev d = index_dev(ix);
+    // (without an accepted-key log the cap_log argument is free: its low bit switches the order-free phase 2 off, GS_DENSE_PHASE2=0, for A/B runs)
+    const uint32_t p2_off = (getenv("GS_DENSE_PHASE2") && !atoi(getenv("GS_DENSE_PHASE2"))) ? 1u : 0u;
     unsigned long long *prof = nullptr;
     DevBuf profbuf;
     if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); prof = profbuf.as<unsigned long long>(); }
@@ -1652,7 +1829,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
                            ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof, ix->stats.as<unsigned long long>(),  \
-                           (uint64_t *)nullptr, 0u, 0u, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);  \
+                           (uint64_t *)nullptr, p2_off, 0u, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);  \
     } while (0)
     if (oneg) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4, true); else GS_LAUNCH_DSEARCH(false, false, 4, true); }
     else if (prof) { if (vlds) GS_LAUNCH_DSEARCH(true, true, 4, false); else GS_LAUNCH_DSEARCH(false, true, 4, false); }
@@ -1829,7 +2006,7 @@ int gs_index_search_stats(gs_index *ix, uint64_t out[8], int reset)
         GS_HIP_CHECK(hipMemcpyAsync(h, ix->stats.p, 64, hipMemcpyDeviceToHost, c->stream));
         if (reset) GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 64, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+        out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[5] = h[5]; out[6] = h[6];
     }
     out[3] = ix->stat_wg_in_flight; out[4] = ix->stat_adj_row_bytes;
     return GS_OK;

@@ -89,8 +89,8 @@ for v in a.variants:
                                                                                          np.array_equal(res[3], base[3]), int((res[0] != base[0]).any(axis=1).sum())))
     if base is None:
         base = res
-    print("%-40s traversal %8.2f ms (%d launches)  join %8.2f ms  call %8.1f ms  pops/q %.0f acc/q %.0f wg %d  same_as_first=%s" %
-          (v or "(defaults)", srch[0], srch[1], join[0], dt * 1e3, st["pops"] / a.nq, st["accepting_pops"] / a.nq, st["wg_in_flight"], same), flush=True)
+    print("%-40s traversal %8.2f ms (%d launches)  join %8.2f ms  call %8.1f ms  pops/q %.0f (before dmax=tau %.0f, order-free %.0f) acc/q %.0f wg %d  same_as_first=%s" %
+          (v or "(defaults)", srch[0], srch[1], join[0], dt * 1e3, st["pops"] / a.nq, st["pops_phase1"] / a.nq, st["pops_phase2"] / a.nq, st["accepting_pops"] / a.nq, st["wg_in_flight"], same), flush=True)
     for k, old in saved.items():
         if old is None:
             os.environ.pop(k, None)
