@@ -490,28 +490,32 @@ __device__ __forceinline__ uint32_t dense_row_tau(const uint16_t *__restrict__ m
     if (n < efs) return INF_CNT;
     const uint32_t nb = dense_nblocks(m), lane = threadIdx.x & 63;
     const uint4 *row16 = (const uint4 *)matrow;
-    const uint32_t n16 = (uint32_t)((n + 7) / 8);
     uint32_t target = m / HB;
     for (int pass = 0; pass < 2; pass++) {
         for (uint32_t i = threadIdx.x; i < nb; i += DT) coarse[i] = 0;
         if (threadIdx.x < (uint32_t)HB) fine[threadIdx.x] = 0;
         __syncthreads();
-        uint32_t top[4] = {0, 0, 0, 0};                       // wave-level tallies of m, m-1, m-2, m-3 (lane 0 holds them)
-        for (uint32_t i0 = 0; i0 < n16; i0 += DT) {
-            const uint32_t i = i0 + threadIdx.x;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i < n16) v = row16[i];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        // per lane: byte-wide tallies of m, m-1, m-2, m-3 packed in one register (flushed every 16 loads: 128 counts < 256), anything
+        // lower goes to the LDS bins one by one (~1 % of an unrelated database)
+        uint32_t top[4] = {0, 0, 0, 0}, acc = 0, since = 0;
+        auto tally = [&](uint32_t c) {
+            const uint32_t d = m - c;                          // c <= m always
+            acc += d <= 3 ? (1u << (8 * d)) : 0u;
+            if (d > 3) { atomicAdd(&coarse[c / HB], 1u); if (c / HB == target) atomicAdd(&fine[c % HB], 1u); }
+        };
+        const uint32_t nfull = (uint32_t)(n / 8);              // groups of 8 counts that lie entirely inside the row
+        for (uint32_t i = threadIdx.x; i < nfull; i += DT) {
+            const uint4 v = row16[i];
+            tally(v.x & 0xFFFFu); tally(v.x >> 16); tally(v.y & 0xFFFFu); tally(v.y >> 16);
+            tally(v.z & 0xFFFFu); tally(v.z >> 16); tally(v.w & 0xFFFFu); tally(v.w >> 16);
+            if (++since == 16) { top[0] += acc & 255u; top[1] += (acc >> 8) & 255u; top[2] += (acc >> 16) & 255u; top[3] += acc >> 24; acc = 0; since = 0; }
+        }
+        if (threadIdx.x == 0) for (uint64_t e = (uint64_t)nfull * 8; e < n; e++) tally(matrow[e]);      // (the padding behind the row is not data)
+        top[0] += acc & 255u; top[1] += (acc >> 8) & 255u; top[2] += (acc >> 16) & 255u; top[3] += acc >> 24;
 #pragma unroll
-            for (int h = 0; h < 8; h++) {
-                const uint32_t c = (w[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                const bool valid = i < n16 && (uint64_t)i * 8 + h < n;
-                const uint32_t d = m - c;                      // 0 for c == m; "negative" (huge) never happens: c <= m
-                const bool t0 = valid && d == 0, t1 = valid && d == 1, t2 = valid && d == 2, t3 = valid && d == 3;
-                top[0] += (uint32_t)__popcll(__ballot(t0)); top[1] += (uint32_t)__popcll(__ballot(t1));
-                top[2] += (uint32_t)__popcll(__ballot(t2)); top[3] += (uint32_t)__popcll(__ballot(t3));
-                if (valid && d > 3) { atomicAdd(&coarse[c / HB], 1u); if (c / HB == target) atomicAdd(&fine[c % HB], 1u); }
-            }
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) top[t] += __shfl_xor(top[t], o);
         }
         if (lane == 0) {
 #pragma unroll
@@ -548,6 +552,139 @@ __device__ __forceinline__ uint32_t dense_row_tau(const uint16_t *__restrict__ m
 
 // a wave-uniform value the compiler cannot prove uniform (it came through LDS): pin it to an SGPR
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// ================= phase 2: the order-free rest of search_layer =================
+// dmax == tau, the efs-th smallest count of the whole database: fewer than efs nodes lie below it, so dmax can never drop
+// again, the accept rule is "count < tau" from here on, every accepted key stays and is popped, and so is every candidate
+// already waiting with count <= tau. The set of nodes that get evaluated - hence ids, distances AND the evaluation count -
+// is the closure of the waiting candidates under "neighbours with count < tau", whatever the order of the pops. So the
+// candidates become a plain work list that the eight wavefronts drain independently, one adjacency row per wavefront and
+// step, with one barrier per generation instead of several per pop; the 2-byte count look-up (an HBM sector each) is only
+// made for neighbours that pass a Bloom filter of the < efs nodes below tau, built from one scan of the query's count row
+// in LDS that phase 1 no longer needs.
+// (kept as a function for readability; making it a real call - noinline - was tried: the whole kernel then pays for a stack, 124 -> 490 ms)
+
+struct Phase2IO { uint32_t nT, evals, pops; };
+template <bool ONEG>
+__device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds &S, uint32_t *vis, const uint16_t *__restrict__ matrow, uint32_t tau, uint32_t knbn,
+                                                       uint64_t *Gold, uint64_t *Gnew, uint32_t headG, uint32_t nG, uint32_t headN, uint32_t nN, uint64_t Tmax, Phase2IO &io)
+{
+    const uint32_t maxdeg = 2 * ix.M;
+    constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t nT = io.nT, st_p2 = 0;
+    uint32_t *s_cnt = (uint32_t *)&S.scal[4];                // [0] work-list tail, [1] keys for T, [2] evaluations
+    uint32_t *WL = (uint32_t *)Gnew;                  // node ids to expand (capacity 2 * capC >= waiting + < efs accepted)
+    uint64_t *TA = Gold;                                  // accepted keys that may enter T (the old G array: consumed below first)
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    {   // waiting candidates with count <= tau: live G (global, sorted) and live N (LDS)
+        const uint64_t *src = Gold + headG;
+        const uint32_t liveG = nG - headG, liveN = nN - headN;
+        for (uint32_t i = threadIdx.x; i < liveG; i += DT) { const uint64_t k = src[i]; if (KCNT(k) <= tau) WL[atomicAdd(&s_cnt[0], 1u)] = KID(k); }
+        for (uint32_t i = threadIdx.x; i < liveN; i += DT) { const uint64_t k = S.N[headN + i]; if (KCNT(k) <= tau) WL[atomicAdd(&s_cnt[0], 1u)] = KID(k); }
+    }
+    __syncthreads();
+    // Bloom filter of {node : count < tau} in two dead LDS regions (A + G window + N, and Eid .. fold histogram), one hash each
+    uint32_t *bfA = (uint32_t *)S.A, *bfB = S.Eid;
+    const uint32_t bytesA = 8 * maxdeg + 8 * (DWIN + 4) + 8 * (CN + 4), bytesB = (uint32_t)((uint8_t *)S.wsum - (uint8_t *)S.Eid);
+    uint32_t lgA = 5, lgB = 5;
+    while ((2u << lgA) <= 8 * bytesA) lgA++;
+    while ((2u << lgB) <= 8 * bytesB) lgB++;
+    for (uint32_t w = threadIdx.x; w < (1u << (lgA - 5)); w += DT) bfA[w] = 0;
+    for (uint32_t w = threadIdx.x; w < (1u << (lgB - 5)); w += DT) bfB[w] = 0;
+    __syncthreads();
+    {
+        const uint4 *row16 = (const uint4 *)matrow;
+        const uint32_t n16 = (uint32_t)((ix.n + 7) / 8);
+        for (uint32_t i = threadIdx.x; i < n16; i += DT) {
+            const uint4 v = row16[i];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const uint32_t cc = (w4[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu, id = i * 8 + h;
+                if (cc < tau && id < ix.n) {
+                    const uint32_t ha = (id * 0x9E3779B1u) >> (32 - lgA), hb = (id * 0x85EBCA77u) >> (32 - lgB);
+                    atomicOr(&bfA[ha >> 5], 1u << (ha & 31)); atomicOr(&bfB[hb >> 5], 1u << (hb & 31));
+                }
+            }
+        }
+    }
+    const bool t_open = nT < knbn;                           // T not full: every accepted key is a candidate for it
+    const uint64_t t_max = Tmax;
+    uint32_t nev = 0, head = 0;
+    constexpr int NR = ONEG ? 8 : 4;                         // adjacency ids per lane: 64 * NR >= maxdeg
+    // one adjacency row per wavefront and step, software-pipelined three deep: the node id of the item after next, the row of
+    // the next item and the work on this one are all in flight together (items are independent: order does not matter here)
+    auto expand = [&](const uint32_t (&rid)[NR], uint32_t deg) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const uint32_t idx = lane + 64 * j;
+            if (idx >= deg) continue;
+            const uint32_t id = rid[j];
+            const uint32_t bit = 1u << (id & 31);
+            const uint32_t old = atomicOr(&vis[id >> 5], bit);
+            if (old & bit) continue;
+            nev++;
+            const uint32_t ha = (id * 0x9E3779B1u) >> (32 - lgA), hb = (id * 0x85EBCA77u) >> (32 - lgB);
+            if (!((bfA[ha >> 5] >> (ha & 31)) & (bfB[hb >> 5] >> (hb & 31)) & 1u)) continue;      // certainly not below tau
+            const uint32_t cc = matrow[id];
+            if (cc >= tau) continue;
+            WL[atomicAdd(&s_cnt[0], 1u)] = id;               // accepted: expanded in the next generation
+            const uint64_t key = KEY(cc, id);
+            if (t_open || key < t_max) TA[atomicAdd(&s_cnt[1], 1u)] = key;
+        }
+    };
+    auto fetch_row = [&](uint32_t node, uint32_t (&rid)[NR], uint32_t &deg) {
+        deg = ix.deg0[node];
+        const uint32_t *row = ix.nbr0 + (uint64_t)node * maxdeg;
+#pragma unroll
+        for (int j = 0; j < NR; j++) { const uint32_t idx = lane + 64 * j; rid[j] = idx < maxdeg ? row[idx] : 0u; }
+    };
+    constexpr uint32_t WS = DT / 64;
+    for (;;) {
+        __syncthreads();
+        const uint32_t tail = s_cnt[0];
+        if (head >= tail) break;
+        uint32_t itx = head + wv;
+        uint32_t rowB[NR], degB = 0, nodeA = 0;
+        if (itx < tail) fetch_row(uni32(WL[itx]), rowB, degB);
+        if (itx + WS < tail) nodeA = WL[itx + WS];
+        for (; itx < tail; itx += WS) {
+            uint32_t rowC[NR], degC = degB;
+#pragma unroll
+            for (int j = 0; j < NR; j++) rowC[j] = rowB[j];
+            const uint32_t nn = uni32(nodeA);
+            if (itx + WS < tail) fetch_row(nn, rowB, degB);
+            if (itx + 2 * WS < tail) nodeA = WL[itx + 2 * WS];
+            expand(rowC, degC);
+        }
+        st_p2 += tail - head;
+        head = tail;
+    }
+    if (nev) atomicAdd(&s_cnt[2], nev);
+    __syncthreads();
+    // T <- knbn smallest of T u TA, in chunks the existing merge takes (sorted A of at most maxdeg keys; A's region is free again)
+    const uint32_t nta = s_cnt[1];
+    const uint32_t CHK = maxdeg < (uint32_t)DT ? maxdeg : (uint32_t)DT;
+    for (uint32_t c0 = 0; c0 < nta; c0 += CHK) {
+        const uint32_t na = nta - c0 < CHK ? nta - c0 : CHK;
+        __syncthreads();
+        if (threadIdx.x < na) S.As[threadIdx.x] = TA[c0 + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < na) {
+            const uint64_t k = S.As[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < na; j++) rank += (S.As[j] < k);
+            S.A[rank] = k;
+        }
+        __syncthreads();
+        const SmallA sa = load_small_a(S.A, na);
+        nT = dense_merge_T(S.T, nT, S.A, na, knbn, sa);
+    }
+    __syncthreads();
+    io.nT = nT; io.evals += s_cnt[2]; io.pops = st_p2;
+}
+
 // ONEG: max_nb_conn > 128 (adjacency rows of up to 512 ids): all 512 lanes form ONE group that expands a candidate, then does the visited
 // hint + lookups of the next one and fetches the row of the one after - the three stages the two 256-lane halves otherwise share out
 // WLOG (insert-time pre-pass): every accepted key is also appended to a per-workgroup log; R is always "the ef smallest
@@ -946,107 +1083,9 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         }
         __syncthreads();
         if (PHASE2 && phase2) {
-            // ================= phase 2: the order-free rest of search_layer =================
-            // dmax == tau, the efs-th smallest count of the whole database: fewer than efs nodes lie below it, so dmax can never drop
-            // again, the accept rule is "count < tau" from here on, every accepted key stays and is popped, and so is every candidate
-            // already waiting with count <= tau. The set of nodes that get evaluated - hence ids, distances AND the evaluation count -
-            // is the closure of the waiting candidates under "neighbours with count < tau", whatever the order of the pops. So the
-            // candidates become a plain work list that the eight wavefronts drain independently, one adjacency row per wavefront and
-            // step, with one barrier per generation instead of several per pop; the 2-byte count look-up (an HBM sector each) is only
-            // made for neighbours that pass a Bloom filter of the < efs nodes below tau, built from one scan of the query's count row
-            // in LDS that phase 1 no longer needs.
-            uint32_t *s_cnt = (uint32_t *)&S.scal[4];                // [0] work-list tail, [1] keys for T, [2] evaluations
-            uint32_t *WL = (uint32_t *)Cb[cur ^ 1];                  // node ids to expand (capacity 2 * capC >= waiting + < efs accepted)
-            uint64_t *TA = Cb[cur];                                  // accepted keys that may enter T (the old G array: consumed below first)
-            if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
-            __syncthreads();
-            {   // waiting candidates with count <= tau: live G (global, sorted) and live N (LDS)
-                const uint64_t *src = Cb[cur] + headG;
-                const uint32_t liveG = nG - headG, liveN = nN - headN;
-                for (uint32_t i = threadIdx.x; i < liveG; i += DT) { const uint64_t k = src[i]; if (KCNT(k) <= tau) WL[atomicAdd(&s_cnt[0], 1u)] = KID(k); }
-                for (uint32_t i = threadIdx.x; i < liveN; i += DT) { const uint64_t k = S.N[headN + i]; if (KCNT(k) <= tau) WL[atomicAdd(&s_cnt[0], 1u)] = KID(k); }
-            }
-            __syncthreads();
-            // Bloom filter of {node : count < tau} in two dead LDS regions (A + G window + N, and Eid .. fold histogram), one hash each
-            uint32_t *bfA = (uint32_t *)S.A, *bfB = S.Eid;
-            const uint32_t bytesA = 8 * maxdeg + 8 * (DWIN + 4) + 8 * (CN + 4), bytesB = (uint32_t)((uint8_t *)S.wsum - (uint8_t *)S.Eid);
-            uint32_t lgA = 5, lgB = 5;
-            while ((2u << lgA) <= 8 * bytesA) lgA++;
-            while ((2u << lgB) <= 8 * bytesB) lgB++;
-            for (uint32_t w = threadIdx.x; w < (1u << (lgA - 5)); w += DT) bfA[w] = 0;
-            for (uint32_t w = threadIdx.x; w < (1u << (lgB - 5)); w += DT) bfB[w] = 0;
-            __syncthreads();
-            {
-                const uint4 *row16 = (const uint4 *)matrow;
-                const uint32_t n16 = (uint32_t)((ix.n + 7) / 8);
-                for (uint32_t i = threadIdx.x; i < n16; i += DT) {
-                    const uint4 v = row16[i];
-                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int h = 0; h < 8; h++) {
-                        const uint32_t cc = (w4[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu, id = i * 8 + h;
-                        if (cc < tau && id < ix.n) {
-                            const uint32_t ha = (id * 0x9E3779B1u) >> (32 - lgA), hb = (id * 0x85EBCA77u) >> (32 - lgB);
-                            atomicOr(&bfA[ha >> 5], 1u << (ha & 31)); atomicOr(&bfB[hb >> 5], 1u << (hb & 31));
-                        }
-                    }
-                }
-            }
-            const bool t_open = nT < knbn;                           // T not full: every accepted key is a candidate for it
-            const uint64_t t_max = Tmax;
-            uint32_t nev = 0, head = 0;
-            const uint32_t nrow = (maxdeg + 63) / 64;
-            for (;;) {
-                __syncthreads();
-                const uint32_t tail = s_cnt[0];
-                if (head >= tail) break;
-                for (uint32_t itx = head + wv; itx < tail; itx += DT / 64) {
-                    const uint32_t node = uni32(WL[itx]);
-                    const uint32_t deg = ix.deg0[node];
-                    const uint32_t *row = ix.nbr0 + (uint64_t)node * maxdeg;
-                    for (uint32_t j = 0; j < nrow; j++) {
-                        const uint32_t idx = lane + 64 * j;
-                        if (idx >= deg) continue;
-                        const uint32_t id = row[idx];
-                        const uint32_t bit = 1u << (id & 31);
-                        const uint32_t old = atomicOr(&vis[id >> 5], bit);
-                        if (old & bit) continue;
-                        nev++;
-                        const uint32_t ha = (id * 0x9E3779B1u) >> (32 - lgA), hb = (id * 0x85EBCA77u) >> (32 - lgB);
-                        if (!((bfA[ha >> 5] >> (ha & 31)) & (bfB[hb >> 5] >> (hb & 31)) & 1u)) continue;      // certainly not below tau
-                        const uint32_t cc = matrow[id];
-                        if (cc >= tau) continue;
-                        WL[atomicAdd(&s_cnt[0], 1u)] = id;           // accepted: expanded in the next generation
-                        const uint64_t key = KEY(cc, id);
-                        if (t_open || key < t_max) TA[atomicAdd(&s_cnt[1], 1u)] = key;
-                    }
-                }
-                st_p2 += tail - head;
-                head = tail;
-            }
-            st_pops += head;
-            if (nev) atomicAdd(&s_cnt[2], nev);
-            __syncthreads();
-            evals += s_cnt[2];
-            // T <- knbn smallest of T u TA, in chunks the existing merge takes (sorted A of at most maxdeg keys; A's region is free again)
-            const uint32_t nta = s_cnt[1];
-            const uint32_t CHK = maxdeg < (uint32_t)DT ? maxdeg : (uint32_t)DT;
-            for (uint32_t c0 = 0; c0 < nta; c0 += CHK) {
-                const uint32_t na = nta - c0 < CHK ? nta - c0 : CHK;
-                __syncthreads();
-                if (threadIdx.x < na) S.As[threadIdx.x] = TA[c0 + threadIdx.x];
-                __syncthreads();
-                if (threadIdx.x < na) {
-                    const uint64_t k = S.As[threadIdx.x];
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < na; j++) rank += (S.As[j] < k);
-                    S.A[rank] = k;
-                }
-                __syncthreads();
-                const SmallA sa = load_small_a(S.A, na);
-                nT = dense_merge_T(S.T, nT, S.A, na, knbn, sa);
-            }
-            __syncthreads();
+            Phase2IO io{nT, evals, 0u};
+            dense_phase2<ONEG>(ix, S, vis, matrow, tau, knbn, Cb[cur], Cb[cur ^ 1], headG, nG, headN, nN, Tmax, io);
+            nT = io.nT; evals = io.evals; st_pops += io.pops; st_p2 += io.pops;
         }
         if (ids_out) for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
             if (i < nT) { ids_out[qi * knbn + i] = KID(S.T[i]); dist_out[qi * knbn + i] = (float)KCNT(S.T[i]) / (float)ix.m; }
