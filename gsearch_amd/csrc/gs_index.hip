@@ -563,7 +563,7 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__built
 // in LDS that phase 1 no longer needs.
 // (kept as a function for readability; making it a real call - noinline - was tried: the whole kernel then pays for a stack, 124 -> 490 ms)
 
-struct Phase2IO { uint32_t nT, evals, pops; };
+struct Phase2IO { uint32_t nT, evals, pops; bool tm; long long c_build, c_drain; };
 template <bool ONEG>
 __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds &S, uint32_t *vis, const uint16_t *__restrict__ matrow, uint32_t tau, uint32_t knbn,
                                                        uint64_t *Gold, uint64_t *Gnew, uint32_t headG, uint32_t nG, uint32_t headN, uint32_t nN, uint64_t Tmax, Phase2IO &io)
@@ -609,6 +609,7 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
             }
         }
     }
+    const long long pt0 = io.tm ? clock64() : 0;
     const bool t_open = nT < knbn;                           // T not full: every accepted key is a candidate for it
     const uint64_t t_max = Tmax;
     uint32_t nev = 0, head = 0;
@@ -661,6 +662,7 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
         st_p2 += tail - head;
         head = tail;
     }
+    if (io.tm) { io.c_build = pt0; io.c_drain = clock64(); }
     if (nev) atomicAdd(&s_cnt[2], nev);
     __syncthreads();
     // T <- knbn smallest of T u TA, in chunks the existing merge takes (sorted A of at most maxdeg keys; A's region is free again)
@@ -734,7 +736,10 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         uint64_t *wl = WLOG ? wlog + (uint64_t)blockIdx.x * cap_log : nullptr;
         uint32_t nlog = 1;
         const uint16_t *matrow = mat + qi * mat_ld;
+        const bool tm = PHASE2 && stats && blockIdx.x == 0 && threadIdx.x == 0;
+        const long long tm0 = tm ? clock64() : 0;
         const uint32_t tau = PHASE2 ? dense_row_tau(matrow, ix.n, ix.m, efs, S.H1, S.hist, S.wsum) : 0u;
+        const long long tm1 = tm ? clock64() : 0;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
         for (uint32_t w = threadIdx.x; w < hwords; w += DT) hs.Hf[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb * (HB / HG / 2); w += DT) S.H2[w] = 0;
@@ -1082,16 +1087,23 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const long long q4 = clock64(); t_e += q4 - p4; tq1 += q1 - p4; tq2 += q2 - q1; tq3 += q3 - q2; tq4 += q4 - q3; tna += na; }
         }
         __syncthreads();
+        const long long tm2 = tm ? clock64() : 0;
         if (PHASE2 && phase2) {
-            Phase2IO io{nT, evals, 0u};
+            Phase2IO io{nT, evals, 0u, tm, 0, 0};
             dense_phase2<ONEG>(ix, S, vis, matrow, tau, knbn, Cb[cur], Cb[cur ^ 1], headG, nG, headN, nN, Tmax, io);
             nT = io.nT; evals = io.evals; st_pops += io.pops; st_p2 += io.pops;
+            if (tm) { atomicAdd(&stats[13], (unsigned long long)(io.c_build - tm2)); atomicAdd(&stats[14], (unsigned long long)(io.c_drain - io.c_build)); }
         }
+        const long long tm3 = tm ? clock64() : 0;
         if (ids_out) for (uint32_t i = threadIdx.x; i < knbn; i += DT) {
             if (i < nT) { ids_out[qi * knbn + i] = KID(S.T[i]); dist_out[qi * knbn + i] = (float)KCNT(S.T[i]) / (float)ix.m; }
             else { ids_out[qi * knbn + i] = ~(uint64_t)0; dist_out[qi * knbn + i] = INFINITY; }
         }
         if (threadIdx.x == 0) { if (count_out) count_out[qi] = nT; if (evals_out) evals_out[qi] = evals; }
+        if (tm) {
+            atomicAdd(&stats[8], (unsigned long long)(tm1 - tm0)); atomicAdd(&stats[9], (unsigned long long)(tm2 - tm1)); atomicAdd(&stats[10], (unsigned long long)(tm3 - tm2));
+            atomicAdd(&stats[11], (unsigned long long)(clock64() - tm3)); atomicAdd(&stats[12], 1ull);
+        }
         if (WLOG) {
             // W = the efs smallest keys of the log: cut it at dmax (INF_CNT while R never filled), sort what is left in LDS (the search
             // arrays are dead), keep the first efs. Anything that does not fit is flagged and redone by the caller the slow way.
@@ -1791,9 +1803,9 @@ static int ensure_cols(gs_index *ix, uint64_t upto)
 static int ensure_stats(gs_index *ix)
 {
     if (ix->stats.p) return GS_OK;
-    int rc = ix->stats.alloc(64);
+    int rc = ix->stats.alloc(128);
     if (rc) return rc;
-    GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 64, ix->ctx->stream));
+    GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 128, ix->ctx->stream));
     return GS_OK;
 }
 // counts of nq padded query rows against nodes [0, n): out16[q * ld + e]
@@ -2041,11 +2053,16 @@ int gs_index_search_stats(gs_index *ix, uint64_t out[8], int reset)
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (ix->stats.p) {
         GS_HIP_CHECK(hipSetDevice(c->device));
-        unsigned long long h[8];
-        GS_HIP_CHECK(hipMemcpyAsync(h, ix->stats.p, 64, hipMemcpyDeviceToHost, c->stream));
-        if (reset) GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 64, c->stream));
+        unsigned long long h[16];
+        GS_HIP_CHECK(hipMemcpyAsync(h, ix->stats.p, 128, hipMemcpyDeviceToHost, c->stream));
+        if (reset) GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 128, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[5] = h[5]; out[6] = h[6];
+        if (getenv("GS_TRAV_PHASES") && h[12])      // shader-clock cycles of workgroup 0 per query: tau scan, phase 1, phase 2 (list + Bloom build, drain, T merge)
+            fprintf(stderr, "[GS_TRAV_PHASES] workgroup 0, %llu queries: cycles per query tau scan %.0f, phase 1 %.0f, phase 2 %.0f, output %.0f\n", h[12],
+                    (double)h[8] / h[12], (double)h[9] / h[12], (double)h[10] / h[12], (double)h[11] / h[12]),
+            fprintf(stderr, "[GS_TRAV_PHASES]   inside phase 2: work list + Bloom build %.0f, drain %.0f, merge into T %.0f\n", (double)h[13] / h[12], (double)h[14] / h[12],
+                    ((double)h[10] - (double)h[13] - (double)h[14]) / h[12]);
     }
     out[3] = ix->stat_wg_in_flight; out[4] = ix->stat_adj_row_bytes;
     return GS_OK;
