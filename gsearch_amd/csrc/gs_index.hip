@@ -563,8 +563,8 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__built
 // in LDS that phase 1 no longer needs.
 // (kept as a function for readability; making it a real call - noinline - was tried: the whole kernel then pays for a stack, 124 -> 490 ms)
 
-struct Phase2IO { uint32_t nT, evals, pops; bool tm; long long c_build, c_drain; };
-template <bool ONEG>
+struct Phase2IO { uint32_t nT, evals, pops; bool tm; long long c_build, c_drain; uint64_t *wl; uint32_t cap_log, nlog; };
+template <bool ONEG, bool WLOG>
 __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds &S, uint32_t *vis, const uint16_t *__restrict__ matrow, uint32_t tau, uint32_t knbn,
                                                        uint64_t *Gold, uint64_t *Gnew, uint32_t headG, uint32_t nG, uint32_t headN, uint32_t nN, uint64_t Tmax, Phase2IO &io)
 {
@@ -572,10 +572,10 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
     constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t nT = io.nT, st_p2 = 0;
-    uint32_t *s_cnt = (uint32_t *)&S.scal[4];                // [0] work-list tail, [1] keys for T, [2] evaluations
+    uint32_t *s_cnt = (uint32_t *)&S.scal[4];                // [0] work-list tail, [1] keys for T, [2] evaluations, [3] log length
     uint32_t *WL = (uint32_t *)Gnew;                  // node ids to expand (capacity 2 * capC >= waiting + < efs accepted)
     uint64_t *TA = Gold;                                  // accepted keys that may enter T (the old G array: consumed below first)
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = threadIdx.x == 3 ? io.nlog : 0u;      // [3] WLOG: length of the accepted-key log
     __syncthreads();
     {   // waiting candidates with count <= tau: live G (global, sorted) and live N (LDS)
         const uint64_t *src = Gold + headG;
@@ -633,6 +633,7 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
             WL[atomicAdd(&s_cnt[0], 1u)] = id;               // accepted: expanded in the next generation
             const uint64_t key = KEY(cc, id);
             if (t_open || key < t_max) TA[atomicAdd(&s_cnt[1], 1u)] = key;
+            if (WLOG) { const uint32_t lp = atomicAdd(&s_cnt[3], 1u); if (lp < io.cap_log) io.wl[lp] = key; }      // the insert pre-pass wants every accepted key
         }
     };
     auto fetch_row = [&](uint32_t node, uint32_t (&rid)[NR], uint32_t &deg) {
@@ -684,7 +685,7 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
         nT = dense_merge_T(S.T, nT, S.A, na, knbn, sa);
     }
     __syncthreads();
-    io.nT = nT; io.evals += s_cnt[2]; io.pops = st_p2;
+    io.nT = nT; io.evals += s_cnt[2]; io.pops = st_p2; io.nlog = s_cnt[3];
 }
 
 // ONEG: max_nb_conn > 128 (adjacency rows of up to 512 ids): all 512 lanes form ONE group that expands a candidate, then does the visited
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     const uint32_t efs = ef > knbn ? ef : knbn;
     const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
     uint32_t st_pops = 0, st_acc = 0, st_p1 = 0, st_p2 = 0;                 // work counters (workgroup-uniform): pops / accepting pops / pops before dmax reached tau, of this workgroup (< 2^32)
-    constexpr bool PHASE2 = VLDS && !WLOG && !PROF;
+    constexpr bool PHASE2 = VLDS;
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;         // capacity of N: >= 2M (an empty N takes a whole expansion), one key per lane in its merge
@@ -1089,9 +1090,9 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         __syncthreads();
         const long long tm2 = tm ? clock64() : 0;
         if (PHASE2 && phase2) {
-            Phase2IO io{nT, evals, 0u, tm, 0, 0};
-            dense_phase2<ONEG>(ix, S, vis, matrow, tau, knbn, Cb[cur], Cb[cur ^ 1], headG, nG, headN, nN, Tmax, io);
-            nT = io.nT; evals = io.evals; st_pops += io.pops; st_p2 += io.pops;
+            Phase2IO io{nT, evals, 0u, tm, 0, 0, wl, cap_log, nlog};
+            dense_phase2<ONEG, WLOG>(ix, S, vis, matrow, tau, knbn, Cb[cur], Cb[cur ^ 1], headG, nG, headN, nN, Tmax, io);
+            nT = io.nT; evals = io.evals; st_pops += io.pops; st_p2 += io.pops; nlog = io.nlog;
             if (tm) { atomicAdd(&stats[13], (unsigned long long)(io.c_build - tm2)); atomicAdd(&stats[14], (unsigned long long)(io.c_drain - io.c_build)); }
         }
         const long long tm3 = tm ? clock64() : 0;
@@ -2242,7 +2243,8 @@ static int plan_prepass(gs_index *ix, uint32_t nb, uint32_t efc, const uint16_t 
     const size_t granted = round_up(lds, 1280);
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / granted));
     const uint32_t scratch_words = dense_nblocks(ix->prm.m) * (HB / 2);
-    const uint32_t capC = 2 * efc + 2 * (uint32_t)DCN + maxdeg + 64, cap_log = 16 * efc;
+    const uint32_t capC = 2 * efc + 2 * (uint32_t)DCN + maxdeg + 64,
+                   cap_log = 16 * efc + ((getenv("GS_DENSE_PHASE2") && !atoi(getenv("GS_DENSE_PHASE2"))) ? 1u : 0u);      // (odd = order-free phase 2 off, A/B)
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nb, (uint64_t)c->n_cu * per_cu);
     int rc;
     if ((rc = ensure_stats(ix))) return rc;

@@ -17,9 +17,10 @@ for d in (fetch_dir, write_dir):
                     vals[(name, r["Counter_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
                     rows.append([name, r["Kernel_Name"].split("(")[0][:80], r["Grid_Size"], r["Counter_Name"], r["Counter_Value"], r.get("Dispatch_Id", "")])
                     break
-out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_bench.sh) over `python bench.py --steps 1 --warmup 1`; counter "
+out = {"_head": os.environ.get("GS_HEAD", ""), "_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_bench.sh) over `python bench.py --steps 1 --warmup 1`; counter "
                "values are KB; per kernel the launches of the LARGEST grid (the timed request step; smaller grids are build-time launches) are averaged; FETCH_SIZE is doubled as "
-               "MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (scattered 2-byte lookups and atomics are uncalibrated: treat those as a lower bound x2 upper bound)",
+               "MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; bench.py applies the per-pattern calibration of profiles/r03_fetchcal.txt to the RAW values kept here "
+               "(coalesced streams x2, scattered 2-byte look-ups 64 B each as counted, atomics 32 B of WRITE_SIZE each)",
        "kernels": {}}
 for name in KERNELS:
     f, w = vals.get((name, "FETCH_SIZE")), vals.get((name, "WRITE_SIZE"))
