@@ -1611,9 +1611,34 @@ template <bool COLD, bool GTAB>
 struct HllEmit {
     HllShared S; uint32_t m; uint64_t zone_m; double inv_lnb, am;
     uint32_t *q, *perm; uint32_t *stamp; bool walk;
-    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const
+    // warm instantiation: per-wave LDS queue of the element hashes that pass the cheap cut (round 3, the MinEmitF scheme). ~3 % of the k-mers
+    // go on to the logarithm / walk; left in place, nearly every wave iteration had a lane or two in that branch and all 64 paid for it
+    // (rocprofv3: 733 VALU wave-instructions per 64 k-mers, 8x the OPH sketch). Queued, the slow part runs on full wavefronts.
+    uint64_t *sq; uint32_t lane; mutable uint32_t qn; mutable uint64_t cutr;
+    __device__ __forceinline__ void refresh() const { cutr = ((uint64_t)S.ctl[5] << 32) | S.ctl[4]; }
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { process(elem_hash<ALGO_HLL, 64>(v)); }
+    __device__ __forceinline__ void full(uint64_t v) const
     {
-        Rng g; g.seed(elem_hash<ALGO_HLL, 64>(v));
+        const uint64_t h = elem_hash<ALGO_HLL, 64>(v);
+        const uint64_t s0 = splitmix_mix(h + GS_GAMMA), s3 = splitmix_mix(h + 4 * GS_GAMMA);       // the first output needs two of the four state words
+        const bool pass = ((rotl64(s0 + s3, 23) + s0) >> 12) <= cutr;
+        const uint64_t bal = __ballot(pass);
+        if (bal) {
+            if (pass) sq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = h;
+            qn += (uint32_t)__popcll(bal);
+            if (qn >= 64) {
+                process(sq[lane]);
+                const uint32_t rest = qn - 64;
+                const uint64_t mv = sq[64 + lane];
+                if (lane < rest) sq[lane] = mv;
+                qn = rest;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish() const { if (sq && lane < qn) process(sq[lane]); qn = 0; }
+    __device__ __forceinline__ void process(uint64_t h) const
+    {
+        Rng g; g.seed(h);
         const uint64_t u52 = g.next64() >> 12;
         const uint64_t cut = ((uint64_t)S.ctl[5] << 32) | S.ctl[4];
         if (u52 > cut) return;                                    // its first point cannot reach the lower bound: nor can any later one
@@ -1671,12 +1696,14 @@ struct HllEmit {
         atomicMax(&S.tab[t], k);
     }
 };
+template <bool GTAB> __device__ __forceinline__ void emit_full_wave(const HllEmit<false, GTAB> &e, uint64_t v, uint64_t r, uint64_t p) { if (e.sq) e.full(v); else e(v, r, p); }
+template <bool GTAB> __device__ __forceinline__ void emit_finish(const HllEmit<false, GTAB> &e) { e.finish(); }
 template <bool AA, bool COLD, bool GTAB>
 __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
         const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off,
         const uint64_t *__restrict__ gen_units, const uint32_t *__restrict__ list, uint32_t n_items, uint32_t k, uint32_t m, double inv_lnb,
         const uint64_t *__restrict__ ucut, uint32_t *__restrict__ lane_q, uint32_t *__restrict__ lane_perm, unsigned long long *__restrict__ counter,
-        uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig, uint32_t *__restrict__ gtab, int use_filter)
+        uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig, uint32_t *__restrict__ gtab, int use_filter, uint32_t queue_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_hll[];
     HllShared S;
@@ -1701,8 +1728,11 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         const uint32_t nchunks = (uint32_t)std::max<uint64_t>(1, units / ((uint64_t)T * 8));
         bool outgrown = false;                                    // workgroup-uniform: some warm lane's walk outgrew its registers
         for (int pass = 0; pass < 2 && !outgrown; pass++) {
-            HllEmit<COLD, GTAB> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1};
+            // (queue_off != 0: the warm instantiation has room in LDS for its survivor queues, 128 hashes per wave)
+            uint64_t *sq = (!COLD && queue_off) ? (uint64_t *)(s_hll + queue_off) + (threadIdx.x >> 6) * 128 : nullptr;
+            HllEmit<COLD, GTAB> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1, sq, threadIdx.x & 63, 0u, ~(uint64_t)0};
             for (uint32_t ch = 0; ch < nchunks; ch++) {
+                emit.refresh();
                 walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, ch, nchunks, emit);
                 if (pass == 0 || ch + 1 == nchunks) {
                     // refresh the lower bound: minimum register (pass A: running, between chunks; after pass A: exact)
@@ -1761,7 +1791,12 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     const size_t lds_cap = 160 * 1024 - 256;
     const bool gtab = 4 * ((size_t)m + 8) > lds_cap;
     const int use_filter = gtab && 32 + 2 * (size_t)m <= lds_cap;
-    const size_t lds = !gtab ? 4 * ((size_t)m + 8) : (use_filter ? 32 + 2 * (size_t)m : 32);
+    const size_t lds0 = !gtab ? 4 * ((size_t)m + 8) : (use_filter ? 32 + 2 * (size_t)m : 32);
+    // survivor queues of the warm kernel (8 kB): only where they do not cost a resident workgroup
+    const size_t lds_q = ((lds0 + 15) & ~(size_t)15) + (size_t)(HL_T / 64) * 128 * 8, half_cu = (160 * 1024) / 2 / 1280 * 1280;
+    const bool use_q = !(getenv("GS_HLL_QUEUE") && !atoi(getenv("GS_HLL_QUEUE"))) && (lds_q <= half_cu || (lds0 > half_cu && lds_q <= lds_cap));
+    const uint32_t queue_off = use_q ? (uint32_t)((lds0 + 15) & ~(size_t)15) : 0u;
+    const size_t lds = use_q ? lds_q : lds0;
     const uint32_t wgs = (uint32_t)std::min<uint64_t>(n_genomes, (uint64_t)c->n_cu * 2);
     PoolBuf gt(c, 19);
     if (gtab && (rc = gt.alloc((size_t)4 * m * std::max<uint32_t>(wgs, (uint32_t)c->n_cu)))) return rc;
@@ -1773,7 +1808,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(HL_T), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, (const uint32_t *)nullptr, \
                            (uint32_t)n_genomes, p->k, m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
-                           gt.as<uint32_t>(), use_filter);                                                                     \
+                           gt.as<uint32_t>(), use_filter, queue_off);                                                          \
     } while (0)
         if (aa) { if (gtab) GS_LAUNCH_HLL(true, true); else GS_LAUNCH_HLL(true, false); }
         else { if (gtab) GS_LAUNCH_HLL(false, true); else GS_LAUNCH_HLL(false, false); }
@@ -1802,7 +1837,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(cw), dim3(HL_CT), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, p->k, m, \
                            inv_lnb, dcut.as<uint64_t>(), lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
-                           gt.as<uint32_t>(), use_filter);                                                                     \
+                           gt.as<uint32_t>(), use_filter, 0u);                                                                 \
     } while (0)
     if (aa) { if (gtab) GS_LAUNCH_HLLC(true, true); else GS_LAUNCH_HLLC(true, false); }
     else { if (gtab) GS_LAUNCH_HLLC(false, true); else GS_LAUNCH_HLLC(false, false); }
