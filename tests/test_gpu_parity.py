@@ -701,6 +701,25 @@ def test_insert_prepass_builds_the_oracle_graph(gpu_ctx, monkeypatch, dtype, M, 
     assert (og["levels"][4096:] > 0).sum() >= 3
 
 
+def test_insert_with_join_on_second_stream(gpu_ctx, monkeypatch):
+    """GS_INSERT_OVERLAP=1: the match-join of insert batch i+1 runs on a second stream under the plan / link kernels of batch i - same graph"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_INSERT_OVERLAP", "1")
+    for dtype, m, M, efc, B in ((np.uint64, 120, 16, 20, 64), (np.float32, 200, 8, 40, 32)):
+        db = H.synth_sig_db(30, 30, m, 8, dtype=dtype, jlo=0.05, jhi=0.95)
+        oix = O.Index(dtype, m, M, efc, scale_modify=0.5, seed=3)
+        hn = G.Hnsw.new(M, 10000, 16, efc, G.DistHamming(), dtype=dtype, seed=3, insert_batch=B)
+        hn.modify_level_scale(0.5); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+        for part in (db[:500], db[500:]):
+            oix.parallel_insert(part, batch=B); hn.parallel_insert(part)
+        g, og = hn.export_graph(), oix.export()
+        assert np.array_equal(g["deg0"], og["deg0"]) and np.array_equal(g["levels"], og["levels"])
+        for i in range(len(db)):
+            d = int(og["deg0"][i])
+            assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]) and np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d]), i
+
+
 def test_insert_with_global_visited_bitmap(gpu_ctx, monkeypatch):
     """k_hnsw_plan keeps its visited bitmap in LDS when it fits; the global-memory fallback (large n) must build the same graph"""
     import gsearch_amd as G
