@@ -367,6 +367,20 @@ def test_sketch_prob_bucketed_form_matches_oracle(gpu_ctx, monkeypatch, k, m, da
     assert len(bad) == 0, ("genomes differing", bad.tolist(), [int((got[i] != ref[i]).sum()) for i in bad])
 
 
+def test_sketch_prob_bucketed_form_hands_flagged_genomes_to_the_sorted_form(gpu_ctx):
+    """a k-mer repeated more than 65 536 times wraps the bucket kernel's 16-bit duplicate count: the genome is flagged on the device and redone by
+    the sorted form, its neighbours in the batch are not disturbed - bit-exact against the oracle either way"""
+    import gsearch_amd as G
+    rng = np.random.default_rng(77)
+    k, m = 21, 1000
+    a = H.dna_ascii(H.rand_dna(rng, 150000)); b = H.dna_ascii(H.rand_dna(rng, 120000))
+    genomes = [[a], [b[:60000] + b"A" * 90000 + b[60000:]], [b], [b"ACGT" * 40000 + a[:30000]]]       # 2nd: poly-A run; 4th: 4 k-mers 40 000 times each
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "prob", "dna"))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(k, m, "prob", genomes, "dna")
+    assert np.array_equal(got, ref), np.nonzero((got != ref).any(axis=1))[0].tolist()
+
+
 def test_index_dump_and_reload(gpu_ctx, tmp_path):
     """file_dump / load round trip (own format): identical graph, data and answers; `add` continues on the reloaded index"""
     import gsearch_amd as G
