@@ -1024,10 +1024,12 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             const SmallA sa = load_small_a(S.A, na);
             // T <- knbn smallest of T u A (only when A reaches into it)
             if (nT < knbn || S.A[0] < Tmax) {
+                if (PROF && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&prof[13], 1ull);
                 nT = dense_merge_T(S.T, nT, S.A, na, knbn, sa);
                 if (nT == knbn) Tmax = S.T[knbn - 1];
             }
             // ---- N full? fold its live part into G first (rare): G' = live G u live N, dead tail dropped
+            if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && nN - headN + na > CN) atomicAdd(&prof[14], 1ull);
             if (nN - headN + na > CN) {
                 const uint32_t liveN = nN - headN, liveG = nG - headG;
                 const uint64_t *NL = S.N + headN;
@@ -1904,6 +1906,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         fprintf(stderr, "[GS_TRAV_PROFILE] workgroup 0: pops %llu merges %llu | cycles/pop: loads+atomics issue->ballot %.0f, sync1 %.0f, compaction+sync2 %.0f, accept rule+count %.0f | merge cycles/merge %.0f\n",
                 h[5], h[6], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], h[6] ? (double)h[4] / h[6] : 0.0);
+        if (h[6]) fprintf(stderr, "[GS_TRAV_PROFILE] of %llu accepting pops: %llu merged into T, %llu folded N into G\n", h[6], h[13], h[14]);
         if (h[6]) fprintf(stderr, "[GS_TRAV_PROFILE] per accepting pop: compaction+sort %.0f, prefetch+trim %.0f, T %.0f, fold+N merge %.0f cycles; accepted keys %.2f\n",
                           (double)h[8] / h[6], (double)h[9] / h[6], (double)h[10] / h[6], (double)h[11] / h[6], (double)h[12] / h[6]);
     }
