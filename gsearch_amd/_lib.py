@@ -67,6 +67,7 @@ SYMBOLS = {
     "gs_host_free": (None, [_vp]),
     "gs_list_fasta_files": (_i, [C.c_char_p, _i, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "gs_sketch_files": (_i, [_vp, _PP, C.POINTER(C.c_char_p), _u64, _i, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "gs_gunzip_batch": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "gs_pack_dna": (_u64, [_vp, _u64, _vp, _u64]),
     "gs_filter_aa": (_u64, [_vp, _u64, _vp]),
     "gs_hamming_qxc": (_i, [_vp, _i, _u32, _vp, _u64, _vp, _u64, _vp]),

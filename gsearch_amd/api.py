@@ -289,6 +289,26 @@ def read_fasta_file(path):
         L.gs_host_free(p)
 
 
+def gunzip_batch(ctx, members, out_caps=None):
+    """gzip members (bytes objects, one single-member file each) inflated on the device (gs_inflate.hip): list of (status, text bytes).
+    status 0 = the deflate data, ISIZE and CRC-32 all check; see gs_gunzip_batch in include/gsearch_amd.h for the others."""
+    n = len(members)
+    if n == 0:
+        return []
+    ins = [np.frombuffer(m, dtype=np.uint8) if len(m) else np.zeros(1, np.uint8) for m in members]
+    caps = [int(c) for c in out_caps] if out_caps is not None else [
+        (int.from_bytes(m[-4:], "little") if len(m) >= 18 else 0) for m in members]
+    outs = [np.empty(max(c, 1) + 64, dtype=np.uint8) for c in caps]
+    pin = (C.c_void_p * n)(*[a.ctypes.data for a in ins])
+    pout = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+    lin = (C.c_uint64 * n)(*[len(m) for m in members])
+    cap = (C.c_uint64 * n)(*caps)
+    lout = (C.c_uint64 * n)()
+    st = (C.c_int * n)()
+    check(ctx.L.gs_gunzip_batch(ctx.h, pin, lin, n, pout, cap, lout, st))
+    return [(int(st[i]), outs[i][:lout[i]].tobytes()) for i in range(n)]
+
+
 def list_fasta_files(directory, data_t="dna"):
     """recursive directory walk of process_dir (files.rs:148-215): accepted files in name order"""
     L = _lib.load()

@@ -47,12 +47,14 @@ int gs_ctx_create(gs_ctx **out, int device_id, void *stream)
 void gs_ctx_destroy(gs_ctx *c)
 {
     if (!c) return;
+    if (c->child) { gs_ctx_destroy(c->child); c->child = nullptr; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->prof) for (auto &p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     delete (gs::ScratchPool *)c->scratch_pool;
+    delete (gs::PinnedPool *)c->pinned_pool;
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -64,6 +66,9 @@ int gs_ctx_release_scratch(gs_ctx *c)
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     delete (gs::ScratchPool *)c->scratch_pool;
     c->scratch_pool = nullptr;
+    delete (gs::PinnedPool *)c->pinned_pool;
+    c->pinned_pool = nullptr;
+    if (c->child) return gs_ctx_release_scratch(c->child);
     return GS_OK;
 }
 int gs_ctx_sync(gs_ctx *c)

@@ -24,6 +24,9 @@
 #include <thread>
 #include <vector>
 #include "gs_internal.hpp"
+#include <condition_variable>
+#include <deque>
+#include "gs_inflate.hpp"
 
 namespace gs {
 int ingest_records_dev(gs_ctx *c, bool aa, bool contiguous, const void *text_dev, uint64_t n_bytes, const uint64_t *seq_begin, const uint64_t *seq_end,
@@ -235,6 +238,9 @@ struct FileBlob {       // one file after the host stage
     Bytes text;                           // decompressed text of a compressed file (plain files are read straight into the pinned buffer)
     uint8_t *dst = nullptr; size_t dst_cap = 0, dst_len = 0;    // where a plain file goes (pinned) and how much of it was filled
     uint8_t *src = nullptr; size_t src_cap = 0;                 // .gz: where the compressed bytes are read to (a per-slot buffer: no per-file allocation)
+    // .gz inflated ON the device (gs_inflate.hip): the member goes to the pinned compressed buffer (src), its text will be produced at
+    // g_off of the group's device-text region; gz_dev is set by the host stage when the member is one the device path takes
+    bool want_dev = false, gz_dev = false; size_t gz_hdr = 0, gz_len = 0; uint64_t g_off = 0, g_cap = 0;
     std::vector<uint64_t> sb, se; int rc = GS_OK; std::string err; double read_s = 0;
 };
 static bool has_compressed_suffix(const char *path)
@@ -265,7 +271,24 @@ static void host_stage(const char *path, FileBlob *b)
     b->rc = GS_OK; b->dst_len = 0; b->text.n = 0;
     const uint8_t *text = nullptr; size_t n = 0;
     bool direct = b->dst != nullptr;
-    if (direct && has_compressed_suffix(path)) {                   // .gz sized from its trailer: inflate straight into the pinned buffer
+    b->gz_dev = false;
+    if (b->want_dev && b->src) {                                   // single-member .gz for the device: read the member, check its header, done
+        size_t got = 0;
+        FILE *f = fopen(path, "rb");
+        if (f) {
+            for (;;) { const size_t r = fread(b->src + got, 1, b->src_cap - got, f); got += r; if (r == 0 || got == b->src_cap) break; }
+            const bool more = got == b->src_cap && fgetc(f) != EOF;
+            fclose(f);
+            const size_t h = more ? 0 : gzip_header_len(b->src, got);
+            if (h) {
+                const uint8_t *t = b->src + got - 4;
+                const uint64_t isize = (uint64_t)t[0] | (uint64_t)t[1] << 8 | (uint64_t)t[2] << 16 | (uint64_t)t[3] << 24;
+                if (isize == b->g_cap) { b->gz_dev = true; b->gz_hdr = h; b->gz_len = got; }
+            }
+        }
+        if (b->gz_dev) { b->read_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); return; }
+        direct = false;                                             // the file changed under us or is not plain gzip: the general path below
+    } else if (direct && has_compressed_suffix(path)) {                   // .gz sized from its trailer: inflate straight into the pinned buffer
         size_t produced = 0, got = 0;
         direct = false;
         if (b->src) {
@@ -374,8 +397,27 @@ int gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t c
  * residues that reached the sketcher. stats_out (optional, 4 doubles): host seconds spent reading+decompressing+scanning (summed over
  * threads), seconds the caller waited for PCIe copies, seconds in device pack + sketch, wall seconds of the call.
  */
-int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
-                    void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out)
+// The .gz files of a call are dealt between two pipelines as they go (see gs_sketch_files): the host pipeline claims them from the front of
+// the list, the device pipeline from the back, group by group, until the two meet.
+// The device pipeline takes a group only as large as lets both finish together: with rates ra, rb (files/s, measured once 256 files are
+// done, priors before), files claimed but unfinished pa, pb and R unclaimed, (pb + k) / rb = (R - k + pa) / ra.
+struct GzDeal {
+    std::mutex m; uint64_t n_gz = 0, front = 0, back = 0, done_front = 0, done_back = 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double rate(bool back_side) const
+    {
+        const uint64_t d = back_side ? done_back : done_front;
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return d >= 256 && el > 0 ? (double)d / el : (back_side ? 2000.0 : 2500.0);
+    }
+};
+
+// dev_gzip: single-member .gz files are inflated on the device (gs_inflate.hip); members it does not take or that fail their trailer check are
+// collected in `redo` (file indices) with zero records, for the caller to run through the host decoders
+static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
+                             void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out, bool dev_gzip, std::vector<uint64_t> *redo,
+                             const uint64_t *out_index /* row of file f in the outputs; NULL: f */, int lookahead /* groups read ahead; 0: default */,
+                             GzDeal *deal /* optional */, bool from_back, uint64_t n_free /* leading files of the list that need no claim */)
 {
     int rc = gs_check_params(p);
     if (rc) return rc;
@@ -385,29 +427,71 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     GS_HIP_CHECK(hipSetDevice(c->device));
     const auto t_call = std::chrono::steady_clock::now();
     const bool aa = p->data_t == GS_DATA_AA;
-    if (pio == 0) pio = 32;          // small groups overlap best (measured: 32 files per group 3200 genomes/s, 64: 2400, 256: 900)
+    if (pio == 0) {                  // small groups overlap best on the host path (measured: 32 files per group 3200 genomes/s, 64: 2400, 256: 900);
+        pio = 32;                    // the device inflates one member per wave, 4 waves per CU: it wants a thousand members per group
+        if (dev_gzip) {
+            uint64_t ngz = 0;
+            for (uint64_t f = 0; f < n_files; f++) ngz += gs::ends_with(paths[f], ".gz");
+            if (2 * ngz > n_files) pio = (uint32_t)std::max(32, 4 * c->n_cu);
+        }
+    }
     if (n_threads == 0) n_threads = gs::usable_cpus();
     const uint64_t n_groups = (n_files + pio - 1) / pio;
+    std::vector<uint64_t> claimed_gz(n_groups, 0);
+    uint64_t n_groups_eff = n_groups;                              // fewer when the other pipeline took the rest of the .gz files
     const size_t esz = gs_sig_elem_bytes(p), m = p->sketch_size;
     std::vector<std::vector<gs::FileBlob>> blobs(n_groups);
-    std::vector<std::future<void>> pending(n_groups);
+    // host stage: ONE team of n_threads workers takes the files of the started groups in order (files.rs:327 par_iter over a group). A team per
+    // group - the round-2 form - put (look-ahead x n_threads) threads on the cores at once: deeper look-ahead only made them contend.
+    struct HostTeam {
+        std::mutex m; std::condition_variable work, done;
+        std::deque<std::pair<uint64_t, uint64_t>> q;          // (group, file of the group)
+        std::vector<uint64_t> left;                           // per group: files not finished yet
+        bool stop = false; std::vector<std::thread> th;
+    } team;
+    team.left.assign(n_groups, 0);
     // LA groups are being read ahead while group g copies and g-1 is on the device: LA + 2 pinned staging buffers
     constexpr int LA_MAX = 14;
     int LA = 2;                        // (measured: 2 -> 3100-3400 genomes/s plain, 980 gz; 6 -> 2400 / 850; 12 -> 1650 / 840: more host threads only contend)
+    if (lookahead > 0) LA = std::min(LA_MAX, lookahead);
     if (getenv("GS_INGEST_LOOKAHEAD")) LA = std::max(1, std::min(LA_MAX, atoi(getenv("GS_INGEST_LOOKAHEAD"))));
     const int NSLOT = LA + 2;
+    // pinned staging buffers live in the context (gs::PinnedPool): they outlast the call, gs_ctx_release_scratch / gs_ctx_destroy free them
+    gs::PinnedPool *pool = gs::pinned_pool(c);
+    static_assert(LA_MAX + 2 <= 16, "text slots 0-15, compressed slots 16-31 of the pinned pool");
     void *pinned[LA_MAX + 2] = {}; size_t pinned_cap[LA_MAX + 2] = {};
+    for (int i = 0; i < NSLOT; i++) { pinned[i] = pool->p[i]; pinned_cap[i] = pool->cap[i]; }
     std::vector<uint64_t> plain_total(n_groups, 0);
     gs::Bytes cbuf[LA_MAX + 2];                               // per slot: the compressed bytes of the group's .gz files
+    void *cpin[LA_MAX + 2] = {}; size_t cpin_cap[LA_MAX + 2] = {};       // per slot, pinned: the members the DEVICE inflates
+    for (int i = 0; i < NSLOT; i++) { cpin[i] = pool->p[16 + i]; cpin_cap[i] = pool->cap[16 + i]; }
+    std::vector<uint64_t> dev_ctot(n_groups, 0), dev_gtot(n_groups, 0);    // per group: bytes of those members / of their texts
     int start_rc = GS_OK;
     // host stage of a group: its files are spread over n_threads threads (files.rs:327 par_iter over the group)
     auto start_group = [&](uint64_t g) {
-        const uint64_t f0 = g * pio, f1 = std::min<uint64_t>(n_files, f0 + pio);
+        const uint64_t f0 = g * pio;
+        uint64_t f1 = std::min<uint64_t>(n_files, f0 + pio);
+        if (deal) {                                                // take what is left of the .gz files for this group; a short group is the last one
+            const uint64_t cnt = f1 - std::max(f0, std::min(n_free, f1));
+            std::lock_guard<std::mutex> lk(deal->m);
+            const uint64_t avail = deal->n_gz - deal->front - deal->back;
+            uint64_t take = std::min(cnt, avail);
+            if (from_back) {
+                const double ra = deal->rate(false), rb = deal->rate(true);
+                const double pa = (double)(deal->front - deal->done_front), pb = (double)(deal->back - deal->done_back);
+                const double k = (rb * ((double)avail + pa) - ra * pb) / (ra + rb);
+                take = k < 128 ? 0 : std::min<uint64_t>(take, (uint64_t)k);          // a launch costs the same ~0.4 s for 100 members as for 1000
+            }
+            (from_back ? deal->back : deal->front) += take;
+            claimed_gz[g] = take;
+            if (take < cnt) { f1 -= cnt - take; n_groups_eff = std::min<uint64_t>(n_groups_eff, f1 > f0 ? g + 1 : g); }
+        }
         blobs[g].resize(f1 - f0);
+        if (f1 == f0) return;
         {   // size the plain files and give each its place in this group's pinned buffer (its previous user, group g-4, is long done)
             const int sl = (int)(g % NSLOT);
-            std::vector<uint64_t> off(f1 - f0, 0), cap(f1 - f0, 0), coff(f1 - f0, 0), ccap(f1 - f0, 0);
-            uint64_t tot = 0, ctot = 0;
+            std::vector<uint64_t> off(f1 - f0, 0), cap(f1 - f0, 0), coff(f1 - f0, 0), ccap(f1 - f0, 0), doff(f1 - f0, 0), dcap(f1 - f0, 0), goff(f1 - f0, 0);
+            uint64_t tot = 0, ctot = 0, dtot = 0, gtot = 0;
             for (uint64_t f = f0; f < f1; f++) {
                 struct stat st;
                 if (stat(paths[f], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) continue;
@@ -419,55 +503,91 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
                     if (fz && fseek(fz, -4, SEEK_END) == 0 && fread(t4, 1, 4, fz) == 4) want = (uint64_t)t4[0] | (uint64_t)t4[1] << 8 | (uint64_t)t4[2] << 16 | (uint64_t)t4[3] << 24;
                     if (fz) fclose(fz);
                     if (want < (uint64_t)st.st_size / 2 || want > (uint64_t)st.st_size * 64 || want >= (1u << 30)) want = 0;       // not a plausible single member
+                    if (want && dev_gzip) {          // the device's: member -> pinned compressed buffer, text -> the group's device-text region
+                        doff[f - f0] = dtot; dcap[f - f0] = (uint64_t)st.st_size; dtot += ((uint64_t)st.st_size + 63) / 64 * 64;
+                        goff[f - f0] = gtot; cap[f - f0] = want; gtot += (want + 63) / 64 * 64;
+                        continue;
+                    }
                     if (want) { coff[f - f0] = ctot; ccap[f - f0] = (uint64_t)st.st_size; ctot += ((uint64_t)st.st_size + 63) / 64 * 64; }
                 }
                 if (want) { off[f - f0] = tot; cap[f - f0] = want; tot += (want + 63) / 64 * 64; }
             }
             plain_total[g] = tot;
             if (tot + 64 > pinned_cap[sl]) {
-                if (pinned[sl]) (void)hipHostFree(pinned[sl]);
-                pinned[sl] = nullptr; pinned_cap[sl] = (tot + 64) * 5 / 4;
-                if (hipHostMalloc(&pinned[sl], pinned_cap[sl], hipHostMallocDefault) != hipSuccess) { pinned[sl] = nullptr; pinned_cap[sl] = 0; start_rc = GS_ERR_HIP; gs::set_error("hipHostMalloc of %zu bytes failed", (size_t)((tot + 64) * 5 / 4)); }
+                pinned[sl] = pool->ensure(sl, (tot + 64) * 5 / 4);
+                pinned_cap[sl] = pool->cap[sl];
+                if (!pinned[sl]) { pinned_cap[sl] = 0; start_rc = GS_ERR_HIP; gs::set_error("hipHostMalloc of %zu bytes failed", (size_t)((tot + 64) * 5 / 4)); }
+            }
+            dev_ctot[g] = dtot; dev_gtot[g] = gtot;
+            if (dtot + 64 > cpin_cap[sl]) {
+                cpin[sl] = pool->ensure(16 + sl, (dtot + 64) * 5 / 4);
+                cpin_cap[sl] = pool->cap[16 + sl];
+                if (!cpin[sl]) { cpin_cap[sl] = 0; start_rc = GS_ERR_HIP; gs::set_error("hipHostMalloc of %zu bytes failed", (size_t)((dtot + 64) * 5 / 4)); }
             }
             const bool have_c = ctot == 0 || cbuf[sl].reserve(ctot + 64);
             for (uint64_t f = f0; f < f1; f++) {
                 gs::FileBlob &fb = blobs[g][f - f0];
-                fb.dst = (cap[f - f0] && pinned[sl]) ? (uint8_t *)pinned[sl] + off[f - f0] : nullptr; fb.dst_cap = cap[f - f0];
+                fb.want_dev = dcap[f - f0] != 0 && cpin[sl] != nullptr;
+                if (fb.want_dev) {
+                    fb.dst = nullptr; fb.dst_cap = 0;
+                    fb.src = (uint8_t *)cpin[sl] + doff[f - f0]; fb.src_cap = dcap[f - f0]; fb.g_off = goff[f - f0]; fb.g_cap = cap[f - f0];
+                    continue;
+                }
+                fb.dst = (cap[f - f0] && pinned[sl] && !dcap[f - f0]) ? (uint8_t *)pinned[sl] + off[f - f0] : nullptr; fb.dst_cap = fb.dst ? cap[f - f0] : 0;
                 fb.src = (ccap[f - f0] && have_c) ? cbuf[sl].data() + coff[f - f0] : nullptr; fb.src_cap = ccap[f - f0];
             }
         }
-        pending[g] = std::async(std::launch::async, [&, g, f0, f1]() {
-            std::atomic<uint64_t> next{f0};
-            std::vector<std::thread> th;
-            const uint32_t nt = (uint32_t)std::min<uint64_t>(n_threads, f1 - f0);
-            for (uint32_t t = 0; t < nt; t++) th.emplace_back([&]() { for (;;) { const uint64_t f = next.fetch_add(1); if (f >= f1) break; gs::host_stage(paths[f], &blobs[g][f - f0]); } });
-            for (auto &x : th) x.join();
-        });
+        {
+            std::lock_guard<std::mutex> lk(team.m);
+            team.left[g] = f1 - f0;
+            for (uint64_t f = f0; f < f1; f++) team.q.emplace_back(g, f - f0);
+        }
+        team.work.notify_all();
     };
+    auto wait_group = [&](uint64_t g) { std::unique_lock<std::mutex> lk(team.m); team.done.wait(lk, [&] { return team.left[g] == 0; }); };
     hipStream_t copy_stream = nullptr;
     GS_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     hipEvent_t ev[2] = {nullptr, nullptr};
-    gs::DevBuf dtext[2], dout, drs, drl, dgo, dsig;
+    gs::DevBuf dtext[2], dcomp[2], dout, drs, drl, dgo, dsig;
+    std::vector<uint8_t> rows_tmp;
     double read_s = 0, copy_wait_s = 0, dev_s = 0;
-    struct Staged { uint64_t bytes = 0; std::vector<uint64_t> sb, se, frec; } staged[2];
+    // per staged group: text bytes (H2D part, then the device-inflated texts from gbase on), record ranges per file, then flattened
+    struct Staged { uint64_t bytes = 0, gbase = 0; std::vector<std::vector<uint64_t>> fsb, fse; std::vector<uint64_t> sb, se, frec; } staged[2];
     auto cleanup = [&]() {
-        for (auto &f : pending) if (f.valid()) f.wait();
+        { std::lock_guard<std::mutex> lk(team.m); team.stop = true; }      // the workers finish what is queued (it points into buffers freed below), then leave
+        team.work.notify_all();
+        for (auto &x : team.th) x.join();
+        team.th.clear();
         if (copy_stream) (void)hipStreamSynchronize(copy_stream);      // an H2D copy out of a pinned buffer may still be in flight on an error path
         (void)hipStreamSynchronize(c->stream);
-        for (int i = 0; i < NSLOT; i++) if (pinned[i]) (void)hipHostFree(pinned[i]);
         for (int i = 0; i < 2; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     };
 #define GS_FILES_FAIL(code) do { const int rc_ = (code); cleanup(); return rc_; } while (0)
     for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { gs::set_error("hipEventCreate failed"); GS_FILES_FAIL(GS_ERR_HIP); }
-    for (int g = 0; g < LA && (uint64_t)g < n_groups; g++) start_group((uint64_t)g);
+    for (uint32_t t = 0; t < std::max<uint32_t>(1, (uint32_t)std::min<uint64_t>(n_threads, n_files)); t++)
+        team.th.emplace_back([&]() {
+            for (;;) {
+                std::pair<uint64_t, uint64_t> job;
+                {
+                    std::unique_lock<std::mutex> lk(team.m);
+                    team.work.wait(lk, [&] { return team.stop || !team.q.empty(); });
+                    if (team.q.empty()) return;
+                    job = team.q.front(); team.q.pop_front();
+                }
+                gs::host_stage(paths[job.first * pio + job.second], &blobs[job.first][job.second]);
+                std::lock_guard<std::mutex> lk(team.m);
+                if (--team.left[job.first] == 0) team.done.notify_all();
+            }
+        });
+    for (int g = 0; g < LA && (uint64_t)g < n_groups_eff; g++) start_group((uint64_t)g);
     // stage group g: wait for its host tasks, lay the texts of its files end to end in pinned memory, start the H2D copy
     auto stage = [&](uint64_t g) -> int {
-        pending[g].wait();
+        wait_group(g);
         if (start_rc) return start_rc;
         const int b = (int)(g & 1), sl = (int)(g % NSLOT);
         Staged &S = staged[b];
-        S.sb.clear(); S.se.clear(); S.frec.assign(1, 0);
+        S.fsb.assign(blobs[g].size(), {}); S.fse.assign(blobs[g].size(), {});
         // plain files sit where start_group put them; the texts of decompressed files are appended behind them
         uint64_t total = plain_total[g];
         std::vector<uint64_t> base(blobs[g].size());
@@ -475,17 +595,19 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
             auto &fb = blobs[g][f];
             if (fb.rc) { gs::set_error("%s", fb.err.c_str()); return fb.rc; }
             read_s += fb.read_s;
+            if (fb.gz_dev) continue;                                 // its text does not exist yet
             if (fb.dst_len || fb.text.empty()) base[f] = fb.dst ? (uint64_t)(fb.dst - (uint8_t *)pinned[sl]) : 0;
             else { base[f] = total; total += (fb.text.size() + 63) / 64 * 64; }
-            for (size_t r = 0; r < fb.sb.size(); r++) { S.sb.push_back(base[f] + fb.sb[r]); S.se.push_back(base[f] + fb.se[r]); }
-            S.frec.push_back(S.sb.size());
+            for (size_t r = 0; r < fb.sb.size(); r++) { S.fsb[f].push_back(base[f] + fb.sb[r]); S.fse[f].push_back(base[f] + fb.se[r]); }
         }
-        S.bytes = total;
+        S.gbase = (total + 63) / 64 * 64;
+        S.bytes = dev_gtot[g] ? S.gbase + dev_gtot[g] : total;
         if (total + 64 > pinned_cap[sl]) {                          // decompressed texts do not fit behind the plain files: grow, keep what is there
             void *np = nullptr; const size_t ncap = (total + 64) * 5 / 4;
             GS_HIP_CHECK(hipHostMalloc(&np, ncap, hipHostMallocDefault));
             if (pinned[sl]) { memcpy(np, pinned[sl], plain_total[g]); (void)hipHostFree(pinned[sl]); }
             pinned[sl] = np; pinned_cap[sl] = ncap;
+            pool->p[sl] = np; pool->cap[sl] = ncap;
         }
         {   // a team of threads copies the decompressed texts in (one thread moves ~8 GB/s)
             std::atomic<size_t> next{0};
@@ -501,8 +623,12 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
             for (auto &x : team) x.join();
         }
         int rc2;
-        if ((rc2 = dtext[b].ensure(total + 64))) return rc2;
+        if ((rc2 = dtext[b].ensure(S.bytes + 64))) return rc2;
         if (total) GS_HIP_CHECK(hipMemcpyAsync(dtext[b].p, pinned[sl], total, hipMemcpyHostToDevice, copy_stream));
+        if (dev_ctot[g]) {
+            if ((rc2 = dcomp[b].ensure(dev_ctot[g] + 64))) return rc2;
+            GS_HIP_CHECK(hipMemcpyAsync(dcomp[b].p, cpin[sl], dev_ctot[g], hipMemcpyHostToDevice, copy_stream));
+        }
         GS_HIP_CHECK(hipEventRecord(ev[b], copy_stream));
         return GS_OK;
     };
@@ -510,12 +636,51 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     auto device_stage = [&](uint64_t g) -> int {
         const int b = (int)(g & 1);
         Staged &S = staged[b];
-        const uint64_t nf = blobs[g].size(), f0 = g * pio, nrec = S.sb.size();
+        const uint64_t nf = blobs[g].size(), f0 = g * pio;
         auto t0 = std::chrono::steady_clock::now();
         GS_HIP_CHECK(hipEventSynchronize(ev[b]));
         copy_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         t0 = std::chrono::steady_clock::now();
         int rc2;
+        if (dev_gtot[g]) {          // inflate the group's .gz members on the device, check them against their trailers, find their records
+            std::vector<gs::InflateStream> st; std::vector<uint64_t> who;
+            const int sl = (int)(g % NSLOT);
+            for (uint64_t f = 0; f < nf; f++) {
+                const auto &fb = blobs[g][f];
+                if (!fb.gz_dev) continue;
+                st.push_back({(uint64_t)(fb.src - (uint8_t *)cpin[sl]) + fb.gz_hdr, fb.gz_len - fb.gz_hdr, S.gbase + fb.g_off, fb.g_cap});
+                who.push_back(f);
+            }
+            std::vector<gs::InflateResult> res(st.size());
+            if ((rc2 = gs::inflate_streams_dev(c, dcomp[b].p, st.data(), (uint32_t)st.size(), dtext[b].p, res.data()))) return rc2;
+            std::vector<uint64_t> toff(st.size()), tlen(st.size());
+            for (size_t k = 0; k < st.size(); k++) {
+                const bool ok = res[k].status == 0 && res[k].in_used + 8 == st[k].in_len && res[k].out_len == st[k].out_cap;
+                toff[k] = st[k].out_off; tlen[k] = ok ? res[k].out_len : 0;
+                if (!ok) who[k] = ~(uint64_t)0 - who[k];            // marked: host path
+            }
+            std::vector<uint32_t> crc(st.size());
+            if ((rc2 = gs::crc32_texts_dev(c, dtext[b].p, toff.data(), tlen.data(), (uint32_t)st.size(), crc.data()))) return rc2;
+            for (size_t k = 0; k < st.size(); k++) {
+                const bool marked = who[k] > nf;
+                const uint64_t f = marked ? ~(uint64_t)0 - who[k] : who[k];
+                const uint8_t *t = blobs[g][f].src + blobs[g][f].gz_len - 8;
+                const uint32_t want = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+                if (marked || crc[k] != want) { tlen[k] = 0; if (redo) redo->push_back(f0 + f); }
+            }
+            std::vector<std::vector<uint64_t>> gsb, gse;
+            if ((rc2 = gs::fasta_scan_dev(c, dtext[b].p, toff.data(), tlen.data(), (uint32_t)st.size(), gsb, gse))) return rc2;
+            for (size_t k = 0; k < st.size(); k++) {
+                const uint64_t f = who[k] > nf ? ~(uint64_t)0 - who[k] : who[k];
+                S.fsb[f] = std::move(gsb[k]); S.fse[f] = std::move(gse[k]);
+            }
+        }
+        S.sb.clear(); S.se.clear(); S.frec.assign(1, 0);
+        for (uint64_t f = 0; f < nf; f++) {
+            S.sb.insert(S.sb.end(), S.fsb[f].begin(), S.fsb[f].end()); S.se.insert(S.se.end(), S.fse[f].begin(), S.fse[f].end());
+            S.frec.push_back(S.sb.size());
+        }
+        const uint64_t nrec = S.sb.size();
         const size_t out_bytes = (aa ? S.bytes : S.bytes / 4) + 8 * (nrec + nf) + 128;
         if ((rc2 = dout.ensure(out_bytes))) return rc2;
         GS_HIP_CHECK(hipMemsetAsync(dout.p, 0, out_bytes, c->stream));
@@ -544,27 +709,96 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
         }
         GS_HIP_CHECK(hipMemcpyAsync(dgo.p, goff.data(), 8 * (nf + 1), hipMemcpyHostToDevice, c->stream));
         if ((rc2 = gs_sketch_batch_dev(c, p, dout.p, out_bytes / 8 * 8, drs.as<uint64_t>(), drl.as<uint64_t>(), nr2, dgo.as<uint64_t>(), nf, dsig.p))) return rc2;
-        GS_HIP_CHECK(hipMemcpyAsync((uint8_t *)sig_out + f0 * m * esz, dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
+        if (out_index) {
+            rows_tmp.resize(nf * m * esz);
+            GS_HIP_CHECK(hipMemcpyAsync(rows_tmp.data(), dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
+        } else GS_HIP_CHECK(hipMemcpyAsync((uint8_t *)sig_out + f0 * m * esz, dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         for (uint64_t f = 0; f < nf; f++) {
             uint64_t sym = 0;
             if (!block_mode) for (uint64_t r = S.frec[f]; r < S.frec[f + 1]; r++) sym += rl[r]; else sym = rl2[f];
-            if (n_records_out) n_records_out[f0 + f] = S.frec[f + 1] - S.frec[f];
-            if (n_symbols_out) n_symbols_out[f0 + f] = sym;
+            const uint64_t row = out_index ? out_index[f0 + f] : f0 + f;
+            if (out_index) memcpy((uint8_t *)sig_out + row * m * esz, rows_tmp.data() + f * m * esz, m * esz);
+            if (n_records_out) n_records_out[row] = S.frec[f + 1] - S.frec[f];
+            if (n_symbols_out) n_symbols_out[row] = sym;
         }
         dev_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (deal) { std::lock_guard<std::mutex> lk(deal->m); (from_back ? deal->done_back : deal->done_front) += claimed_gz[g]; }
         return GS_OK;
     };
-    for (uint64_t g = 0; g < n_groups; g++) {
+    for (uint64_t g = 0; g < n_groups_eff; g++) {
         if ((rc = stage(g))) GS_FILES_FAIL(rc);                    // H2D of group g starts ...
-        if (g + LA < n_groups) start_group(g + LA);                // ... the host threads move on to group g+LA ...
+        if (g + LA < n_groups_eff) start_group(g + LA);            // ... the host threads move on to group g+LA ...
         if (g >= 1 && (rc = device_stage(g - 1))) GS_FILES_FAIL(rc);   // ... while the device packs and sketches group g-1
     }
-    if ((rc = device_stage(n_groups - 1))) GS_FILES_FAIL(rc);
+    if (n_groups_eff && (rc = device_stage(n_groups_eff - 1))) GS_FILES_FAIL(rc);
     cleanup();
 #undef GS_FILES_FAIL
     if (stats_out) {
         stats_out[0] = read_s; stats_out[1] = copy_wait_s; stats_out[2] = dev_s;
+        stats_out[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
+    }
+    return GS_OK;
+}
+
+int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
+                    void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out)
+{
+    GS_REQUIRE(c && (n_files == 0 || paths), GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
+    const auto t_call = std::chrono::steady_clock::now();
+    const char *e = getenv("GS_GZIP_DEVICE");                 // 0: every .gz through the host decoders (libdeflate / zlib), as in round 2
+    const bool dev_gzip = e ? atoi(e) != 0 : true;
+    // Two pipelines side by side. The device inflates a thousand members per launch (one wave each) in ~0.4 s whatever their number,
+    // with next to no host work; 16 host cores inflate ~2500 members/s through libdeflate and then only need the device for pack + sketch
+    // (~10 % of its time). Each pipeline runs on its own context (stream, scratch, pinned buffers) from its own thread; the .gz files are
+    // dealt as they go (GzDeal): the host pipeline - which also takes every other kind of file - claims them from the front of the list in
+    // groups of 64, the device pipeline from the back in groups of 4 x CUs, until the two meet.
+    std::vector<uint64_t> ia, ib;                             // the host pipeline's list / the device pipeline's list (file indices)
+    GzDeal deal;
+    uint64_t n_free = 0;
+    if (dev_gzip) {
+        for (uint64_t f = 0; f < n_files; f++) if (!gs::ends_with(paths[f], ".gz")) ia.push_back(f);
+        n_free = ia.size();
+        for (uint64_t f = n_files; f-- > 0;) if (gs::ends_with(paths[f], ".gz")) ib.push_back(f);
+        deal.n_gz = ib.size();
+        if (deal.n_gz >= 64) ia.insert(ia.end(), ib.rbegin(), ib.rend());     // a handful of files: all of them to the device
+    }
+    const bool dealing = dev_gzip && deal.n_gz >= 64;
+    double st_a[4] = {0, 0, 0, 0}, st_b[4] = {0, 0, 0, 0};
+    if (ib.empty()) {
+        int rc = sketch_files_impl(c, p, paths, n_files, block_mode, pio, n_threads, sig_out, n_records_out, n_symbols_out, stats_out, false, nullptr, nullptr, 0, nullptr, false, 0);
+        return rc;
+    }
+    std::vector<const char *> pa(ia.size()), pb(ib.size());
+    for (size_t i = 0; i < ia.size(); i++) pa[i] = paths[ia[i]];
+    for (size_t i = 0; i < ib.size(); i++) pb[i] = paths[ib[i]];
+    int rc_a = GS_OK; std::string err_a;
+    std::thread host_pipe;
+    if (!ia.empty()) {
+        if (!c->child) { int rc = gs_ctx_create(&c->child, c->device, nullptr); if (rc) return rc; }
+        host_pipe = std::thread([&]() {
+            rc_a = sketch_files_impl(c->child, p, pa.data(), pa.size(), block_mode, pio ? pio : 64, n_threads, sig_out, n_records_out, n_symbols_out, st_a, false, nullptr, ia.data(), 12, dealing ? &deal : nullptr, false, n_free);
+            if (rc_a) err_a = gs_last_error();
+        });
+    }
+    std::vector<uint64_t> redo;
+    // the device pipeline's host side only reads files: a few threads are plenty, the cores belong to the host pipeline's decoders
+    int rc = sketch_files_impl(c, p, pb.data(), pb.size(), block_mode, pio, ia.empty() ? n_threads : std::max(2u, std::min(8u, n_threads ? n_threads : 8u)), sig_out, n_records_out,
+                               n_symbols_out, st_b, true, &redo, ib.data(), 0, dealing ? &deal : nullptr, true, 0);
+    if (host_pipe.joinable()) host_pipe.join();
+    if (rc) return rc;
+    if (rc_a) { gs::set_error("%s", err_a.c_str()); return rc_a; }
+    if (!redo.empty()) {
+        // members the device path handed back (multi-member files, a trailer that does not check): the host decoders, results to their rows
+        std::vector<const char *> rp(redo.size()); std::vector<uint64_t> ri(redo.size());
+        for (size_t i = 0; i < redo.size(); i++) { ri[i] = ib[redo[i]]; rp[i] = paths[ri[i]]; }
+        double st2[4] = {0, 0, 0, 0};
+        if ((rc = sketch_files_impl(c, p, rp.data(), rp.size(), block_mode, 32, n_threads, sig_out, n_records_out, n_symbols_out, st2, false, nullptr, ri.data(), 0, nullptr, false, 0))) return rc;
+        for (int i = 0; i < 3; i++) st_b[i] += st2[i];
+    }
+    if (stats_out) {
+        for (int i = 0; i < 3; i++) stats_out[i] = st_a[i] + st_b[i];
         stats_out[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
     }
     return GS_OK;

@@ -50,6 +50,8 @@ struct gs_ctx {
     bool profile = false;
     gs::ProfSlot prof[gs::FAM_COUNT];
     void *scratch_pool = nullptr;      // gs::ScratchPool: grow-only device buffers reused by the calls of this context
+    gs_ctx *child = nullptr;           // second context (own stream, pools) on the same device: gs_sketch_files runs its host-decoded files on it
+    void *pinned_pool = nullptr;       // gs::PinnedPool: grow-only pinned host staging buffers of gs_sketch_files (hipHostMalloc costs ~0.3 s per GB)
     // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
     // and parallel_search through &self from many threads (dnasketch.rs:252,305,322): every entry point that touches the stream or the
     // pool takes this lock, so concurrent calls on one context are safe (they queue on the GPU anyway); recursive because entry
@@ -122,8 +124,28 @@ struct DevBuf {   // owning device allocation
 // Per-context scratch: a call's temporaries come from numbered grow-only slots instead of hipMalloc/hipFree (allocating and freeing
 // multi-GB buffers costs more than the kernels that use them). A context serves one call at a time (one stream), so slots are never
 // shared; gs_ctx_release_scratch / gs_ctx_destroy give the memory back.
-enum { SCRATCH_SLOTS = 40 };
+enum { SCRATCH_SLOTS = 48 };
 struct ScratchPool { DevBuf b[SCRATCH_SLOTS]; };
+enum { PINNED_SLOTS = 32 };
+struct PinnedPool {
+    void *p[PINNED_SLOTS] = {}; size_t cap[PINNED_SLOTS] = {};
+    ~PinnedPool() { for (int i = 0; i < PINNED_SLOTS; i++) if (p[i]) (void)hipHostFree(p[i]); }
+    // at least n bytes in slot i; the previous content is NOT kept. nullptr when the allocation fails
+    void *ensure(int i, size_t n)
+    {
+        if (p[i] && cap[i] >= n) return p[i];
+        if (p[i]) (void)hipHostFree(p[i]);
+        p[i] = nullptr; cap[i] = 0;
+        if (hipHostMalloc(&p[i], n, hipHostMallocDefault) != hipSuccess) { p[i] = nullptr; return nullptr; }
+        cap[i] = n;
+        return p[i];
+    }
+};
+inline PinnedPool *pinned_pool(gs_ctx *c)
+{
+    if (!c->pinned_pool) c->pinned_pool = new PinnedPool();
+    return (PinnedPool *)c->pinned_pool;
+}
 struct PoolBuf {    // same surface as DevBuf for the code that uses it
     gs_ctx *c; int slot; void *p = nullptr; size_t bytes = 0;
     PoolBuf(gs_ctx *ctx, int s) : c(ctx), slot(s) {}

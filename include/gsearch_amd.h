@@ -129,6 +129,13 @@ int  gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t 
  * seconds summed over threads, seconds waited for PCIe, seconds in device pack + sketch, wall seconds}. */
 int  gs_sketch_files(gs_ctx *, const gs_sketch_params *, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio,
                      uint32_t n_threads, void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out);
+/* gzip members inflated ON the device (gs_inflate.hip; the .gz path of gs_sketch_files, exposed for parity tests against zlib - the
+ * reference reads .gz through needletail's flate2 reader, files.rs:258-341). in[i]/in_len[i]: HOST bytes of one single-member gzip file;
+ * out[i]/out_cap[i]: HOST buffers for the text; out_len[i]: bytes produced; status[i]: 0 = ok (deflate data, ISIZE and CRC-32 all
+ * check), 1..8 = malformed deflate data, 100 = header not taken (not gzip, reserved flags), 101 = bytes after the member (multi-member
+ * file: host path), 102 = ISIZE mismatch, 103 = CRC mismatch, 104 = out_cap below the member's ISIZE. */
+int  gs_gunzip_batch(gs_ctx *, const uint8_t *const *in, const uint64_t *in_len, uint64_t n, uint8_t *const *out, const uint64_t *out_cap,
+                     uint64_t *out_len, int *status);
 /* ASCII helpers for hosts that do not pack themselves (Sequence::encode_and_add, dnafiles.rs:70-71) */
 uint64_t gs_pack_dna(const uint8_t *ascii, uint64_t n, uint8_t *packed_zeroed, uint64_t base_off);
 uint64_t gs_filter_aa(const uint8_t *ascii, uint64_t n, uint8_t *out);
