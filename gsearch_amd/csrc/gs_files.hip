@@ -408,7 +408,7 @@ struct GzDeal {
     {
         const uint64_t d = back_side ? done_back : done_front;
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return d >= 256 && el > 0 ? (double)d / el : (back_side ? 2000.0 : 2500.0);
+        return d >= 256 && el > 0 ? (double)d / el : (back_side ? 1200.0 : 2300.0);
     }
 };
 
