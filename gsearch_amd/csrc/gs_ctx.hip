@@ -53,6 +53,7 @@ void gs_ctx_destroy(gs_ctx *c)
     for (auto &s : c->prof) for (auto &p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     delete (gs::ScratchPool *)c->scratch_pool;
     delete (gs::PinnedPool *)c->pinned_pool;
     if (c->own_stream) (void)hipStreamDestroy(c->stream);

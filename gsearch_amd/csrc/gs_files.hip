@@ -408,7 +408,7 @@ struct GzDeal {
     {
         const uint64_t d = back_side ? done_back : done_front;
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return d >= 256 && el > 0 ? (double)d / el : (back_side ? 1200.0 : 2300.0);
+        return d >= 256 && el > 0 ? (double)d / el : (back_side ? 1500.0 : 2300.0);
     }
 };
 
@@ -428,11 +428,11 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
     const auto t_call = std::chrono::steady_clock::now();
     const bool aa = p->data_t == GS_DATA_AA;
     if (pio == 0) {                  // small groups overlap best on the host path (measured: 32 files per group 3200 genomes/s, 64: 2400, 256: 900);
-        pio = 32;                    // the device inflates one member per wave, 4 waves per CU: it wants a thousand members per group
+        pio = 32;                    // the device inflates one member per wave: it wants thousands of members per group
         if (dev_gzip) {
             uint64_t ngz = 0;
             for (uint64_t f = 0; f < n_files; f++) ngz += gs::ends_with(paths[f], ".gz");
-            if (2 * ngz > n_files) pio = (uint32_t)std::max(32, 4 * c->n_cu);
+            if (2 * ngz > n_files) pio = (uint32_t)std::max(32, 12 * c->n_cu);      // (beyond 4 per CU the launcher takes the window-less form of k_inflate)
         }
     }
     if (n_threads == 0) n_threads = gs::usable_cpus();
@@ -564,7 +564,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     };
 #define GS_FILES_FAIL(code) do { const int rc_ = (code); cleanup(); return rc_; } while (0)
-    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { gs::set_error("hipEventCreate failed"); GS_FILES_FAIL(GS_ERR_HIP); }
+    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { gs::set_error("hipEventCreate failed"); GS_FILES_FAIL(GS_ERR_HIP); }
     for (uint32_t t = 0; t < std::max<uint32_t>(1, (uint32_t)std::min<uint64_t>(n_threads, n_files)); t++)
         team.th.emplace_back([&]() {
             for (;;) {
@@ -713,7 +713,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
             rows_tmp.resize(nf * m * esz);
             GS_HIP_CHECK(hipMemcpyAsync(rows_tmp.data(), dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
         } else GS_HIP_CHECK(hipMemcpyAsync((uint8_t *)sig_out + f0 * m * esz, dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
-        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        GS_HIP_CHECK(gs::stream_wait(c));
         for (uint64_t f = 0; f < nf; f++) {
             uint64_t sym = 0;
             if (!block_mode) for (uint64_t r = S.frec[f]; r < S.frec[f + 1]; r++) sym += rl[r]; else sym = rl2[f];
@@ -785,7 +785,7 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     std::vector<uint64_t> redo;
     // the device pipeline's host side only reads files: a few threads are plenty, the cores belong to the host pipeline's decoders
     int rc = sketch_files_impl(c, p, pb.data(), pb.size(), block_mode, pio, ia.empty() ? n_threads : std::max(2u, std::min(8u, n_threads ? n_threads : 8u)), sig_out, n_records_out,
-                               n_symbols_out, st_b, true, &redo, ib.data(), 0, dealing ? &deal : nullptr, true, 0);
+                               n_symbols_out, st_b, true, &redo, ib.data(), 1, dealing ? &deal : nullptr, true, 0);
     if (host_pipe.joinable()) host_pipe.join();
     if (rc) return rc;
     if (rc_a) { gs::set_error("%s", err_a.c_str()); return rc_a; }

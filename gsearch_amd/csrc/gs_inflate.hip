@@ -52,12 +52,13 @@ template <int KIND> __device__ __forceinline__ uint32_t inf_entry(uint32_t s, ui
 // inlined five times into the decode loop it made one 45 KB instruction stream whose taken branches each cost the (only) wave of the SIMD a
 // fetch stall.
 struct InfLds {
-    uint8_t win[INF_WSIZE];                              // history window, circular
     uint32_t llut[1u << INF_LROOT], dlut[1u << INF_DROOT], clut[1u << INF_CROOT];
     uint8_t lens[320], clens[20];
     uint16_t lcnt[16], dcnt[16], ccnt[16], nextc[16], offs[16], lsorted[288], dsorted[32], csorted[20];
 };
 static __shared__ __attribute__((aligned(16))) InfLds g_inf;
+// history window of the LDS form, circular (the GWIN form of k_inflate reads its history back from the text it has written: no window)
+static __shared__ __attribute__((aligned(16))) uint8_t g_win[INF_WSIZE];
 
 // Canonical Huffman tables of one alphabet from its code lengths (RFC 1951 3.2.2): KIND 0 = literal/length (g_inf.lens[first ..]), 1 = distance,
 // 2 = code-length alphabet (g_inf.clens). Fills the root table (code length in bits 0-3, kind in 4-5, value from bit 8, extra-bit count from
@@ -194,13 +195,17 @@ __device__ __noinline__ InfBits inf_dynamic_header(InfBits B, const uint32_t *__
     return B;
 }
 
+// GWIN = false: the window in LDS (39.6 KB per member: four members per CU, ~1500 cycles per symbol). GWIN = true: no window - literals and
+// copies go straight to the text in HBM and a match reads its source back from there (through L2, past the non-coherent L1): ~2x the
+// latency per symbol, but 7.6 KB of LDS per member, so five times the members per CU interleave on the same issue slots.
+template <bool GWIN>
 __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ comp, const InflateStream *__restrict__ sts, uint32_t n, uint8_t *__restrict__ out_all,
                                                 InflateResult *__restrict__ res)
 {
     const uint32_t lane = threadIdx.x;
     const InflateStream st = sts[blockIdx.x];
     uint8_t *out = out_all + st.out_off;
-    uint8_t *win = g_inf.win;
+    uint8_t *win = g_win;
     const uint32_t cap = (uint32_t)st.out_cap;
     const uint64_t in_end = st.in_off + st.in_len;                       // absolute byte offsets into comp
     const uint32_t nwords = (uint32_t)((in_end + 3) >> 2);
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
     INF_TAKE(B, (uint32_t)(st.in_off & 3) * 8);
     uint32_t pos = 0, status = INF_OK, blocks = 0;
     auto flush_half = [&](uint32_t base) {
+        if (GWIN) return;
 #pragma unroll 4
         for (uint32_t k = 0; k < INF_HALF / 1024; k++) {
             const uint32_t off = k * 1024 + lane * 16;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
             if (len > cap - pos) { status = INF_E_OUTPUT; break; }
             for (uint32_t i = 0; i < len; i++) {
                 INF_REFILL(B);
-                if (lane == 0) win[pos & INF_WMASK] = (uint8_t)B.buf;
+                if (lane == 0) { if (GWIN) out[pos] = (uint8_t)B.buf; else win[pos & INF_WMASK] = (uint8_t)B.buf; }
                 INF_TAKE(B, 8);
                 pos++;
                 if ((pos & (INF_HALF - 1)) == 0) flush_half(pos - INF_HALF);
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
             const uint32_t kind = (e >> 4) & 3;
             if (kind == 0) {
                 if (pos >= cap) { status = INF_E_OUTPUT; break; }
-                if (lane == 0) win[pos & INF_WMASK] = (uint8_t)(e >> 8);
+                if (lane == 0) { if (GWIN) out[pos] = (uint8_t)(e >> 8); else win[pos & INF_WMASK] = (uint8_t)(e >> 8); }
                 pos++;
                 INF_REFILL(B);
                 e = inf_uni(g_inf.llut[(uint32_t)B.buf & ((1u << INF_LROOT) - 1)]);
@@ -292,7 +298,15 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
             INF_REFILL(B);
             const uint32_t e_next = g_inf.llut[(uint32_t)B.buf & ((1u << INF_LROOT) - 1)];      // in flight under the copy
             const uint32_t src0 = pos - dist;
-            if (dist >= len) {
+            if (GWIN) {
+                // the source may be bytes this wave stored a moment ago: a store is acknowledged (vmcnt) once L2 has it, and the load below
+                // goes to L2 (agent scope: not served by the CU's L1, which does not see L2 writes)
+                if (dist < 2048) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                for (uint32_t i = lane; i < len; i += 64) {
+                    const uint8_t b = __hip_atomic_load(out + src0 + (dist >= len ? i : i % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    out[pos + i] = b;
+                }
+            } else if (dist >= len) {
                 for (uint32_t i = lane; i < len; i += 64) win[(pos + i) & INF_WMASK] = win[(src0 + i) & INF_WMASK];
             } else {                                          // the source runs into the target: the last `dist` bytes repeat
                 for (uint32_t i = lane; i < len; i += 64) win[(pos + i) & INF_WMASK] = win[(src0 + i % dist) & INF_WMASK];
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
         }
     }
     // the tail of the text (the window half that never filled)
-    if (status == INF_OK) {
+    if (!GWIN && status == INF_OK) {
         const uint32_t base = pos & ~(INF_HALF - 1), rem = pos - base;
         for (uint32_t off = lane * 16; off < rem; off += 1024) *(uint4 *)(out + base + off) = *(const uint4 *)&win[(base + off) & INF_WMASK];
     }
@@ -381,10 +395,14 @@ int inflate_streams_dev(gs_ctx *c, const void *comp_dev, const InflateStream *st
     int rc;
     if ((rc = ds.alloc(sizeof(InflateStream) * n)) || (rc = dr.alloc(sizeof(InflateResult) * n))) return rc;
     GS_HIP_CHECK(hipMemcpyAsync(ds.p, streams, sizeof(InflateStream) * n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)comp_dev, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
+    // up to four members per CU: the LDS-window form (lowest latency); more: the window-less form, whose members interleave five times as densely
+    const char *w = getenv("GS_INFLATE_WINDOW");
+    const bool gwin = w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu;
+    if (gwin) hipLaunchKernelGGL(k_inflate<true>, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)comp_dev, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
+    else hipLaunchKernelGGL(k_inflate<false>, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)comp_dev, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
     GS_HIP_CHECK(hipGetLastError());
     GS_HIP_CHECK(hipMemcpyAsync(results, dr.p, sizeof(InflateResult) * n, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(gs::stream_wait(c));
     return GS_OK;
 }
 
@@ -409,7 +427,7 @@ int crc32_texts_dev(gs_ctx *c, const void *text_dev, const uint64_t *text_off, c
         hipLaunchKernelGGL(k_crc32_chunks, dim3((uint32_t)chunks.size()), dim3(CRC_T), 0, c->stream, (const uint8_t *)text_dev, dc.as<CrcChunk>(), dk.as<uint32_t>(), dout.as<uint32_t>());
         GS_HIP_CHECK(hipGetLastError());
         GS_HIP_CHECK(hipMemcpyAsync(raw.data(), dout.p, 4 * chunks.size(), hipMemcpyDeviceToHost, c->stream));
-        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        GS_HIP_CHECK(gs::stream_wait(c));
     }
     const uint32_t kchunk = crc_xpow8(CRC_CHUNK);
     for (uint32_t f = 0; f < n; f++) {
@@ -479,7 +497,7 @@ int fasta_scan_dev(gs_ctx *c, const void *text_dev, const uint64_t *off, const u
         hipLaunchKernelGGL(k_fasta_starts, dim3((uint32_t)chunks.size()), dim3(SC_T), 0, c->stream, (const uint8_t *)text_dev, dch.as<ScanChunk>(), dst.as<uint64_t>(), cap, dcn.as<uint32_t>());
         GS_HIP_CHECK(hipGetLastError());
         GS_HIP_CHECK(hipMemcpyAsync(&cnt, dcn.p, 4, hipMemcpyDeviceToHost, c->stream));
-        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        GS_HIP_CHECK(gs::stream_wait(c));
         if (cnt <= cap) break;
         cap = cnt;                                   // more records than guessed (short protein records): once more with room for all
     }
@@ -487,7 +505,7 @@ int fasta_scan_dev(gs_ctx *c, const void *text_dev, const uint64_t *off, const u
     std::vector<uint64_t> starts(cnt), fend(cnt), hend(cnt);
     std::vector<uint8_t> cap_flag(cnt);
     GS_HIP_CHECK(hipMemcpyAsync(starts.data(), dst.p, 8 * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(gs::stream_wait(c));
     std::sort(starts.begin(), starts.end());
     {   // the file of every record (texts are disjoint and in increasing offset order is NOT assumed: binary search over sorted file ranges)
         std::vector<uint32_t> order(n);
@@ -508,7 +526,7 @@ int fasta_scan_dev(gs_ctx *c, const void *text_dev, const uint64_t *off, const u
     GS_HIP_CHECK(hipGetLastError());
     GS_HIP_CHECK(hipMemcpyAsync(hend.data(), dhe.p, 8 * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(cap_flag.data(), dcf.p, cnt, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(gs::stream_wait(c));
     // records in text order per file
     std::vector<std::pair<uint64_t, uint32_t>> ranges(n);
     for (uint32_t f = 0; f < n; f++) ranges[f] = {off[f], f};
@@ -592,7 +610,7 @@ int gs_gunzip_batch(gs_ctx *c, const uint8_t *const *in, const uint64_t *in_len,
         out_len[i] = res[k].out_len;
         if (res[k].out_len) GS_HIP_CHECK(hipMemcpyAsync(out[i], (const uint8_t *)dtext.p + st[k].out_off, res[k].out_len, hipMemcpyDeviceToHost, c->stream));
     }
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(gs::stream_wait(c));
     return GS_OK;
 }
 

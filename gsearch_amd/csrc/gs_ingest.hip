@@ -162,7 +162,7 @@ int ingest_records_dev(gs_ctx *c, bool aa, bool contiguous, const void *text_dev
     GS_HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> cnt(nch);
     GS_HIP_CHECK(hipMemcpyAsync(cnt.data(), dcnt.p, 4 * nch, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(gs::stream_wait(c));
     std::vector<uint64_t> base(nch);
     uint64_t pos = out_base0;
     for (uint64_t r = 0; r < n_rec; r++) {
@@ -177,7 +177,7 @@ int ingest_records_dev(gs_ctx *c, bool aa, bool contiguous, const void *text_dev
     if (aa) hipLaunchKernelGGL(k_aa_write, dim3((uint32_t)nch), dim3(PK_T), 0, c->stream, (const uint8_t *)text_dev, dcb.as<uint64_t>(), dce.as<uint64_t>(), dbase.as<uint64_t>(), (uint8_t *)out_dev);
     else hipLaunchKernelGGL(k_pack_write, dim3((uint32_t)nch), dim3(PK_T), 0, c->stream, (const uint8_t *)text_dev, dcb.as<uint64_t>(), dce.as<uint64_t>(), dbase.as<uint64_t>(), (uint32_t *)out_dev);
     GS_HIP_CHECK(hipGetLastError());
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(gs::stream_wait(c));
     return GS_OK;
 }
 

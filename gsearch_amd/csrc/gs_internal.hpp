@@ -50,6 +50,7 @@ struct gs_ctx {
     bool profile = false;
     gs::ProfSlot prof[gs::FAM_COUNT];
     void *scratch_pool = nullptr;      // gs::ScratchPool: grow-only device buffers reused by the calls of this context
+    hipEvent_t sync_ev = nullptr;      // blocking-sync event of gs::stream_wait (a sleeping wait: the file pipelines leave the cores to the decoders)
     gs_ctx *child = nullptr;           // second context (own stream, pools) on the same device: gs_sketch_files runs its host-decoded files on it
     void *pinned_pool = nullptr;       // gs::PinnedPool: grow-only pinned host staging buffers of gs_sketch_files (hipHostMalloc costs ~0.3 s per GB)
     // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
@@ -63,6 +64,16 @@ struct gs_ctx {
 #define GS_CTX_LOCK(c) std::lock_guard<std::recursive_mutex> gs_ctx_lock_((c)->mu); (void)hipSetDevice((c)->device)
 
 namespace gs {
+
+// Wait for the context's stream WITHOUT spinning: hipStreamSynchronize busy-waits on a core, and the two pipelines of gs_sketch_files wait
+// for hundreds of milliseconds at a time (a k_inflate launch) while the host decoders want every core of the cgroup's quota.
+inline hipError_t stream_wait(gs_ctx *c)
+{
+    hipError_t e;
+    if (!c->sync_ev && (e = hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventRecord(c->sync_ev, c->stream)) != hipSuccess) return e;
+    return hipEventSynchronize(c->sync_ev);
+}
 
 // RAII-ish helpers -----------------------------------------------------------------------------
 struct ProfScope {   // brackets one kernel launch with events when profiling is on

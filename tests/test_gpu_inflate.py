@@ -51,8 +51,11 @@ def _cases():
     return cases
 
 
-def test_inflate_matches_zlib(gpu_ctx):
+@pytest.mark.parametrize("window", ["lds", "global"])
+def test_inflate_matches_zlib(gpu_ctx, monkeypatch, window):
+    """both forms of k_inflate: history window in LDS (up to four members per CU) / no window, history read back from the text in HBM"""
     import gsearch_amd as G
+    monkeypatch.setenv("GS_INFLATE_WINDOW", window)
     cases = _cases()
     names = list(cases)
     res = G.gunzip_batch(gpu_ctx, [cases[k] for k in names])
@@ -62,9 +65,12 @@ def test_inflate_matches_zlib(gpu_ctx):
         assert text == want, k
 
 
-def test_inflate_large_members_and_many_streams(gpu_ctx):
-    """more streams than the device holds at once (4 per CU), each several window wraps long"""
+@pytest.mark.parametrize("window", ["lds", "global", ""])
+def test_inflate_large_members_and_many_streams(gpu_ctx, monkeypatch, window):
+    """more streams than the device holds at once (4 per CU), each several window wraps long; "" = the launcher's own choice"""
     import gsearch_amd as G
+    if window:
+        monkeypatch.setenv("GS_INFLATE_WINDOW", window)
     rng = np.random.default_rng(5)
     members, wants = [], []
     for i in range(40):
@@ -79,8 +85,10 @@ def test_inflate_large_members_and_many_streams(gpu_ctx):
         assert text == wants[j % len(wants)], j
 
 
-def test_inflate_reports_damage(gpu_ctx):
+@pytest.mark.parametrize("window", ["lds", "global"])
+def test_inflate_reports_damage(gpu_ctx, monkeypatch, window):
     import gsearch_amd as G
+    monkeypatch.setenv("GS_INFLATE_WINDOW", window)
     rng = np.random.default_rng(9)
     t = _fasta(rng, 200_000)
     good = _gz(t, 6)
