@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
             if (e == INF_LONG) e = inf_uni(inf_walk<0>(B.buf));
             uint32_t nb = e & 15;
             if (!nb) { status = INF_E_CODE; break; }
+            if (B.wi > nwords + 2) { status = INF_E_INPUT; break; }      // past the end of the member: the zeros fed from there on may decode for ever
             INF_TAKE(B, nb);
             const uint32_t kind = (e >> 4) & 3;
             if (kind == 0) {

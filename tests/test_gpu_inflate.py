@@ -95,7 +95,8 @@ def test_inflate_reports_damage(gpu_ctx, monkeypatch, window):
     flipped = bytearray(good); flipped[len(good) // 2] ^= 0x10
     bad_crc = bytearray(good); bad_crc[-6] ^= 0xFF
     bad_isize = bytearray(good); bad_isize[-1] ^= 0x01
-    cases = [good, bytes(flipped), good[:len(good) // 2], bytes(bad_crc), good + good, b"not gzip at all, just text" * 4, bytes(bad_isize)]
+    cut = good[:len(good) // 2] + good[-8:]                   # half the deflate data, then a trailer that promises the whole text
+    cases = [good, bytes(flipped), good[:len(good) // 2], bytes(bad_crc), good + good, b"not gzip at all, just text" * 4, bytes(bad_isize), cut]
     caps = [len(t)] * len(cases)
     res = G.gunzip_batch(gpu_ctx, cases, out_caps=caps)
     st = [r[0] for r in res]
@@ -106,6 +107,7 @@ def test_inflate_reports_damage(gpu_ctx, monkeypatch, window):
     assert st[4] == 101 and res[4][1] == t      # a second member follows: the caller takes the host path for such files
     assert st[5] == 100
     assert st[6] in (102, 104)
+    assert st[7] != 0 and res[7][1] != t
     # out_cap below ISIZE is refused before anything is decoded
     res = G.gunzip_batch(gpu_ctx, [good], out_caps=[len(t) - 1])
     assert res[0][0] == 104
