@@ -154,14 +154,20 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
 #pragma unroll
         for (int it = 0; it < JN / JU; it++) {
             T v[JU]; uint32_t hs[JU]; uint32_t pend = 0;
+            // (the four bitmap words are read unconditionally and together: behind `&&` each read sat in its own branch with its own wait)
+            uint32_t bw[JU];
+#pragma unroll
+            for (int u = 0; u < JU; u++) {
+                v[u] = canon<KIND, T>(vn[u]);
+                hs[u] = join_hash(v[u]);
+                bw[u] = bm[hs[u] >> (32 - JB_LOG2 + 5)];
+            }
 #pragma unroll
             for (int u = 0; u < JU; u++) {
                 const uint64_t e = e0 + (uint64_t)(it * JU + u) * JT;
-                v[u] = canon<KIND, T>(vn[u]);
-                hs[u] = join_hash(v[u]);
                 const uint32_t bit = hs[u] >> (32 - JB_LOG2);
-                const bool pass = e < n && !never_equal<KIND, T>(vn[u]) && ((bm[bit >> 5] >> (bit & 31)) & 1u);
-                pend |= (uint32_t)pass << u;
+                const uint32_t pass = (uint32_t)(e < n) & (uint32_t)!never_equal<KIND, T>(vn[u]) & (bw[u] >> (bit & 31)) & 1u;
+                pend |= pass << u;
             }
             // next values: the following nodes of this slot, or the first nodes of the next slot
 #pragma unroll
