@@ -111,7 +111,11 @@ __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t
 // trip of the loop advances each lane by one table entry of whichever of its JU values is pending, so the wave pays for the
 // longest per-lane total, not for JU times the longest probe. Keys are canonical under the element type's `==` (f32: -0 -> +0,
 // NaN never inserted / never probed), so bitwise equality is the reference's equality.
-template <int KIND, typename T>
+// SR = slots per round: the workgroup clears, builds and probes the tables of SR consecutive slots between one set of barriers. With the 256
+// queries of an insert batch a table is 1024 entries and a slot's fixed work (three barriers, clearing 3 K words, 256 inserts on a quarter of
+// the lanes) weighs on its 8192 probes; four slots per round: -10.5 % of the join time of a 300 k build (tools/build_trace.sh). SR = 1 for
+// request batches, whose 72 KB tables fill the LDS.
+template <int KIND, typename T, int SR>
 __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
                                                     uint32_t m, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
                                                     unsigned long long *__restrict__ stats, int chunk_major)
@@ -119,9 +123,10 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
-    uint32_t *tag = (uint32_t *)s_raw;
-    uint32_t *bm = (uint32_t *)(s_raw + 4 * (size_t)P);
-    T *key = (T *)(s_raw + 4 * (size_t)P + ((size_t)1 << JB_LOG2) / 8);
+    constexpr uint32_t BMW = (1u << JB_LOG2) / 32;                // bitmap words per slot
+    uint32_t *tag = (uint32_t *)s_raw;                            // [SR][P]
+    uint32_t *bm = (uint32_t *)(s_raw + 4 * (size_t)P * SR);      // [SR][BMW]
+    T *key = (T *)(s_raw + (4 * (size_t)P + (size_t)BMW * 4) * SR);   // [SR][P]
     // chunk_major: consecutive workgroups sweep the slot blocks of ONE node chunk, so the counters being updated at any time are
     // those of a few chunks (a window of the count matrix that fits the 256 MB Infinity Cache) instead of all of them
     const uint32_t bchunk = chunk_major ? blockIdx.y : blockIdx.x, bslot = chunk_major ? blockIdx.x : blockIdx.y;
@@ -134,64 +139,69 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     T vn[JU];
 #pragma unroll
     for (int u = 0; u < JU; u++) { const uint64_t e = e0 + (uint64_t)u * JT; vn[u] = (e < n && s0 < s1) ? cols[(uint64_t)s0 * colcap + e] : (T)0; }
-    for (uint32_t s = s0; s < s1; s++) {
-        join_lds_barrier();                                       // the previous slot's probes are done
-        for (uint32_t i = threadIdx.x; i < P; i += JT) tag[i] = 0;
-        for (uint32_t i = threadIdx.x; i < (1u << JB_LOG2) / 32; i += JT) bm[i] = 0;
+    for (uint32_t sr = s0; sr < s1; sr += SR) {
+        const uint32_t nr = s1 - sr < (uint32_t)SR ? s1 - sr : (uint32_t)SR;       // slots of this round
+        join_lds_barrier();                                       // the previous round's probes are done
+        for (uint32_t i = threadIdx.x; i < P * SR; i += JT) tag[i] = 0;
+        for (uint32_t i = threadIdx.x; i < BMW * SR; i += JT) bm[i] = 0;
         join_lds_barrier();
-        for (uint32_t q = threadIdx.x; q < nq; q += JT) {
-            T k = qkey[(uint64_t)s * nq + q];
+        for (uint32_t i = threadIdx.x; i < nq * nr; i += JT) {
+            const uint32_t r = SR == 1 ? 0 : i / nq, q = SR == 1 ? i : i - r * nq;
+            T k = qkey[(uint64_t)(sr + r) * nq + q];
             if (never_equal<KIND, T>(k)) continue;
             k = canon<KIND, T>(k);
             const uint32_t hq = join_hash(k);
-            atomicOr(&bm[hq >> (32 - JB_LOG2 + 5)], 1u << ((hq >> (32 - JB_LOG2)) & 31));
+            atomicOr(&bm[r * BMW + (hq >> (32 - JB_LOG2 + 5))], 1u << ((hq >> (32 - JB_LOG2)) & 31));
             uint32_t h = hq >> sh;
-            while (atomicCAS(&tag[h], 0u, q + 1) != 0u) h = (h + 1) & mask;
-            key[h] = k;
+            while (atomicCAS(&tag[r * P + h], 0u, q + 1) != 0u) h = (h + 1) & mask;
+            key[r * P + h] = k;
         }
         join_lds_barrier();
-        const T *col = cols + (uint64_t)s * colcap;
+#pragma unroll 1
+        for (uint32_t r = 0; r < nr; r++) {
+            const uint32_t s = sr + r, tb = r * P, bb = r * BMW;
+            const T *col = cols + (uint64_t)s * colcap;
 #pragma unroll
-        for (int it = 0; it < JN / JU; it++) {
-            T v[JU]; uint32_t hs[JU]; uint32_t pend = 0;
-            // (the four bitmap words are read unconditionally and together: behind `&&` each read sat in its own branch with its own wait)
-            uint32_t bw[JU];
+            for (int it = 0; it < JN / JU; it++) {
+                // (the four bitmap words are read unconditionally and together: behind `&&` each read sat in its own branch with its own wait)
+                T v[JU]; uint32_t hs[JU]; uint32_t pend = 0; uint32_t bw[JU];
 #pragma unroll
-            for (int u = 0; u < JU; u++) {
-                v[u] = canon<KIND, T>(vn[u]);
-                hs[u] = join_hash(v[u]);
-                bw[u] = bm[hs[u] >> (32 - JB_LOG2 + 5)];
-            }
-#pragma unroll
-            for (int u = 0; u < JU; u++) {
-                const uint64_t e = e0 + (uint64_t)(it * JU + u) * JT;
-                const uint32_t bit = hs[u] >> (32 - JB_LOG2);
-                const uint32_t pass = (uint32_t)(e < n) & (uint32_t)!never_equal<KIND, T>(vn[u]) & (bw[u] >> (bit & 31)) & 1u;
-                pend |= pass << u;
-            }
-            // next values: the following nodes of this slot, or the first nodes of the next slot
-#pragma unroll
-            for (int u = 0; u < JU; u++) {
-                const bool wrap = it + 1 == JN / JU;
-                const uint64_t e = e0 + (uint64_t)((wrap ? 0 : (it + 1) * JU) + u) * JT;
-                const T *src = wrap ? col + colcap : col;
-                vn[u] = (e < n && (!wrap || s + 1 < s1)) ? src[e] : (T)0;
-            }
-            uint32_t hh = 0, uu = 0; T vv = 0; bool have = false;
-            for (;;) {
-                if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
-                if (!have) break;
-                const uint32_t t = tag[hh];
-                const T k = key[hh];
-                if (t == 0u) { have = false; continue; }
-                if (k == vv) {
-                    const uint64_t e = e0 + (uint64_t)(it * JU + uu) * JT;
-                    uint32_t st = GS_SEL4((sticky + it * JU), uu);
-                    GS_JOIN_HIT(st, t, e);
-#pragma unroll
-                    for (int u = 0; u < JU; u++) if (uu == (uint32_t)u) sticky[it * JU + u] = st;
+                for (int u = 0; u < JU; u++) {
+                    v[u] = canon<KIND, T>(vn[u]);
+                    hs[u] = join_hash(v[u]);
+                    bw[u] = bm[bb + (hs[u] >> (32 - JB_LOG2 + 5))];
                 }
-                hh = (hh + 1) & mask;
+#pragma unroll
+                for (int u = 0; u < JU; u++) {
+                    const uint64_t e = e0 + (uint64_t)(it * JU + u) * JT;
+                    const uint32_t bit = hs[u] >> (32 - JB_LOG2);
+                    const uint32_t pass = (uint32_t)(e < n) & (uint32_t)!never_equal<KIND, T>(vn[u]) & (bw[u] >> (bit & 31)) & 1u;
+                    pend |= pass << u;
+                }
+                // next values: the following nodes of this slot, or the first nodes of the next slot
+#pragma unroll
+                for (int u = 0; u < JU; u++) {
+                    const bool wrap = it + 1 == JN / JU;
+                    const uint64_t e = e0 + (uint64_t)((wrap ? 0 : (it + 1) * JU) + u) * JT;
+                    const T *src = wrap ? col + colcap : col;
+                    vn[u] = (e < n && (!wrap || s + 1 < s1)) ? src[e] : (T)0;
+                }
+                uint32_t hh = 0, uu = 0; T vv = 0; bool have = false;
+                for (;;) {
+                    if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
+                    if (!have) break;
+                    const uint32_t t = tag[tb + hh];
+                    const T k = key[tb + hh];
+                    if (t == 0u) { have = false; continue; }
+                    if (k == vv) {
+                        const uint64_t e = e0 + (uint64_t)(it * JU + uu) * JT;
+                        uint32_t st = GS_SEL4((sticky + it * JU), uu);
+                        GS_JOIN_HIT(st, t, e);
+#pragma unroll
+                        for (int u = 0; u < JU; u++) if (uu == (uint32_t)u) sticky[it * JU + u] = st;
+                    }
+                    hh = (hh + 1) & mask;
+                }
             }
         }
     }
@@ -313,10 +323,15 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     const int chunk_major = getenv("GS_JOIN_CHUNK_MAJOR") ? atoi(getenv("GS_JOIN_CHUNK_MAJOR")) : 0;
     const uint32_t nblk = (m + slots_per_wg - 1) / slots_per_wg;
     dim3 jg(chunk_major ? nblk : chunks, chunk_major ? chunks : nblk);
-    const size_t lds = (sizeof(T) + 4) * ((size_t)1 << log2p) + ((size_t)1 << JB_LOG2) / 8;
+    const size_t lds1 = (sizeof(T) + 4) * ((size_t)1 << log2p) + ((size_t)1 << JB_LOG2) / 8;
+    // small tables (an insert batch): several slots per barrier round while two workgroups still fit a CU
+    int sr = 1;
+    if (4 * lds1 <= 80 * 1024 && slots_per_wg >= 8) sr = 4; else if (2 * lds1 <= 80 * 1024 && slots_per_wg >= 4) sr = 2;
+    if (getenv("GS_JOIN_SLOTS_PER_ROUND")) { const int e = atoi(getenv("GS_JOIN_SLOTS_PER_ROUND")); if (e == 1 || (e == 2 && 2 * lds1 <= 80 * 1024) || (e == 4 && 4 * lds1 <= 80 * 1024)) sr = e; }
+    const size_t lds = lds1 * sr;
     {
         ProfScope ps(c, FAM_HAMMING);
-        auto kern = k_match_join<KIND, T>;
+        auto kern = sr == 4 ? k_match_join<KIND, T, 4> : sr == 2 ? k_match_join<KIND, T, 2> : k_match_join<KIND, T, 1>;
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats, chunk_major);
         GS_HIP_CHECK(hipGetLastError());
