@@ -1841,6 +1841,20 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
     return GS_OK;
 }
 
+// counts of nq rows against the nodes [node0, node0 + nn) only, into columns node0.. of rows whose counters were initialised (to m) by an earlier
+// dense_counts of the same rows: the join over those nodes' columns (a compare-tile launch this small - 256 x <= 1792 pairs - fills 28 of 256
+// CUs and takes 5 ms)
+static int dense_counts_range(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_t node0, uint64_t nn, uint16_t *out16, uint64_t ld)
+{
+    gs_ctx *c = ix->ctx;
+    int rc;
+    if ((rc = ensure_cols(ix, node0 + nn))) return rc;
+    if ((rc = ensure_stats(ix))) return rc;
+    GS_REQUIRE(nq <= match_join_max_queries(), GS_ERR_INVALID, "dense_counts_range: too many rows");
+    return match_join_counts(c, ix->ikind, ix->prm.m, qrows, ix->stride, nq, (const uint8_t *)ix->cols.p + node0 * ix->esz, ix->cols_cap, nn, out16, ld, ix->join_scratch,
+                             nullptr, ix->stats.as<unsigned long long>(), false, node0);
+}
+
 // placement for the dense traversal: visited bitmap in LDS when that still leaves >= 2 workgroups per CU (GS_DENSE_VIS=lds|global overrides)
 static bool dense_vis_in_lds(const gs_index *ix, uint32_t knbn, uint32_t maxdeg)
 {
@@ -2382,6 +2396,10 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         }
     }
     const uint64_t slab_ld = gs::round_up(first + n, 8);
+    // batches joined together (GS_INSERT_GROUP, default 8; 1 = every batch its own join): rows [grp_b0, grp_end) hold their counts against nodes [0, grp_b0)
+    uint32_t grp_n = overlap ? 1u : 8u;
+    if (const char *e = getenv("GS_INSERT_GROUP")) grp_n = overlap ? 1u : (uint32_t)std::max(1, std::min(12, atoi(e)));
+    uint64_t grp_b0 = 0, grp_end = 0;
     gs::DevBuf *slab = nullptr; uint64_t slab_first = 0;      // rows of this call's points, allocated at the first dense batch
     bool slab_tried = false;
     for (uint64_t b0 = first; b0 < first + n; b0 += B) {
@@ -2442,7 +2460,17 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             uint16_t *out16;
             if (slab) { out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld; mat_ld = slab_ld; }
             else { if (ix->mat.bytes < (size_t)2 * B * slab_ld && (rc = alloc_or_evict(ix, ix->mat, (size_t)2 * B * slab_ld))) return rc; out16 = ix->mat.as<uint16_t>(); mat_ld = slab_ld; }
-            if (slab && pf_have && pf_b0 == b0) {                    // its counts were produced on the second stream while the previous batch was planned
+            if (!slab) grp_b0 = grp_end = 0;
+            if (slab && grp_n > 1 && b0 >= grp_b0 && b0 < grp_end) {
+                // inside a group: this batch's counts against the nodes of the group's start are in the slab already; the nodes the earlier
+                // batches of the group added since (at most (grp_n - 1) * B of them) take a small join of their own (their columns only)
+                if (b0 > grp_b0 && (rc = gs::dense_counts_range(ix, rows, nb, grp_b0, b0 - grp_b0, out16, mat_ld))) return rc;
+            } else if (slab && grp_n > 1 && gs::use_join(ix)) {
+                // a group of batches: ONE join of all their points against the nodes present now - the columns (21.6 GB at 300 k nodes) are
+                // streamed once per group instead of once per batch
+                grp_b0 = b0; grp_end = std::min<uint64_t>(first + n, b0 + (uint64_t)grp_n * B);
+                if ((rc = gs::dense_counts(ix, rows, grp_end - grp_b0, b0, out16, mat_ld))) return rc;
+            } else if (slab && pf_have && pf_b0 == b0) {                    // its counts were produced on the second stream while the previous batch was planned
                 GS_HIP_CHECK(hipStreamWaitEvent(c->stream, ix->jev, 0));
                 pf_have = false;
             } else {

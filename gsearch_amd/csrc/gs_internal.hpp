@@ -104,10 +104,11 @@ int narrow_u16_rows(gs_ctx *c, const void *src_dev, uint64_t src_stride_bytes, u
 
 struct DevBuf;
 // match-join form of the dense count matrix (gs_join.hip): counts of nq strided query rows against the first n nodes of the
-// column-major database copy `cols` ([m][colcap]); out16[q * ld + e] = mismatch count. scratch: 5 reusable buffers.
+// column-major database copy `cols` ([m][colcap]); out16[q * ld + e] = mismatch count. scratch: 5 reusable buffers. init = false: the
+// counters already hold m (a sub-range of columns of rows initialised by an earlier call: the row-spanning memset would wipe their neighbours); col0: node e of the range is column col0 + e of the matrix.
 uint64_t match_join_max_queries();
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
-                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined = nullptr, unsigned long long *stats = nullptr);
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined = nullptr, unsigned long long *stats = nullptr, bool init = true, uint64_t col0 = 0);
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);
 
 inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }

@@ -118,7 +118,7 @@ __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t
 template <int KIND, typename T, int SR>
 __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
                                                     uint32_t m, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
-                                                    unsigned long long *__restrict__ stats, int chunk_major)
+                                                    unsigned long long *__restrict__ stats, int chunk_major, uint64_t col0)
 {
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                     const T k = key[tb + hh];
                     if (t == 0u) { have = false; continue; }
                     if (k == vv) {
-                        const uint64_t e = e0 + (uint64_t)(it * JU + uu) * JT;
+                        const uint64_t e = col0 + e0 + (uint64_t)(it * JU + uu) * JT;       // column of the count matrix (col0: the node range starts there)
                         uint32_t st = GS_SEL4((sticky + it * JU), uu);
                         GS_JOIN_HIT(st, t, e);
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
         }
     }
 #pragma unroll
-    for (int i = 0; i < JN; i++) if (sticky[i]) { join_flush(mm32, ld, sticky[i], e0 + (uint64_t)i * JT); natom++; }
+    for (int i = 0; i < JN; i++) if (sticky[i]) { join_flush(mm32, ld, sticky[i], col0 + e0 + (uint64_t)i * JT); natom++; }
     if (stats) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) natom += __shfl_down(natom, o);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(JT) void k_match_sample(const T *__restrict__ qkey,
 
 template <int KIND, typename T>
 static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstride, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint16_t *out16,
-                     uint64_t ld, DevBuf *scratch /* [5] reusable */, int *declined, unsigned long long *stats)
+                     uint64_t ld, DevBuf *scratch /* [5] reusable */, int *declined, unsigned long long *stats, bool init, uint64_t col0)
 {
     int rc;
     if (declined) *declined = 0;
@@ -280,7 +280,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     if ((rc = k0.ensure(sizeof(T) * items))) return rc;
     // every 16-bit counter starts at m and every match takes one off: the matrix leaves the join as mismatch counts, without the pass that
     // used to turn matches into mismatches (6 GB read + written per 10 000-query request)
-    GS_HIP_CHECK(hipMemsetD16Async((hipDeviceptr_t)out16, (unsigned short)m, (size_t)nq * ld, c->stream));
+    if (init) GS_HIP_CHECK(hipMemsetD16Async((hipDeviceptr_t)out16, (unsigned short)m, (size_t)nq * ld, c->stream));
     dim3 tg((nq + 31) / 32, (m + 31) / 32);
     hipLaunchKernelGGL((k_query_cols<KIND, T>), tg, dim3(256), 0, c->stream, qrows, qstride, nq, m, k0.as<T>());
     GS_HIP_CHECK(hipGetLastError());
@@ -333,7 +333,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         ProfScope ps(c, FAM_HAMMING);
         auto kern = sr == 4 ? k_match_join<KIND, T, 4> : sr == 2 ? k_match_join<KIND, T, 2> : k_match_join<KIND, T, 1>;
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats, chunk_major);
+        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats, chunk_major, col0);
         GS_HIP_CHECK(hipGetLastError());
     }
     return GS_OK;
@@ -344,13 +344,13 @@ uint64_t match_join_max_queries() { const char *e = getenv("GS_JOIN_MAXQ"); retu
 // `declined` (optional): set to 1 - and out16 is left at its initial value m - when the sampled match density says the compare tile kernel is the
 // cheaper producer for this batch (the caller then runs it)
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
-                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined, unsigned long long *stats)
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined, unsigned long long *stats, bool init, uint64_t col0)
 {
     GS_REQUIRE(nq >= 1 && nq <= 4094 && m <= 65535 && (ld % 2) == 0 && ((uintptr_t)out16 % 4) == 0, GS_ERR_INVALID, "match_join_counts: bad shape");
     GS_REQUIRE((uint64_t)m * nq < ((uint64_t)1 << 31), GS_ERR_INVALID, "match_join_counts: batch too large");
-    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
-    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
-    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats);
+    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0);
+    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0);
+    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0);
 }
 
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first)

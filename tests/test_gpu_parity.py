@@ -701,8 +701,14 @@ def test_insert_prepass_builds_the_oracle_graph(gpu_ctx, monkeypatch, dtype, M, 
     oix.parallel_insert(db, batch=256)
     og = oix.export()
     graphs = []
-    for pre in ("1", "0"):
+    # (GS_INSERT_GROUP: batches joined together - one match-join of the points of several batches against the nodes present at the group's start,
+    # the nodes the earlier batches of the group add come from the compare tile kernel; 1 = every batch its own join, default 8)
+    for pre, grp in (("1", None), ("0", None), ("1", "1"), ("1", "3")):
         monkeypatch.setenv("GS_PLAN_PREPASS", pre)
+        if grp is None:
+            monkeypatch.delenv("GS_INSERT_GROUP", raising=False)
+        else:
+            monkeypatch.setenv("GS_INSERT_GROUP", grp)
         hn = G.Hnsw.new(M, 100000, 16, efc, G.DistHamming(), seed=4, insert_batch=256)
         hn.modify_level_scale(scale); hn.set_extend_candidates(True)
         hn.parallel_insert(db)

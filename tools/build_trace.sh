@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(fn)))
 names = {}
 for r in rows:
     n = r['Kernel_Name']
-    key = 'join' if 'k_match_join' in n else 'sample' if 'k_match_sample' in n else 'dense' if 'k_hnsw_search_dense' in n else 'plan' if 'k_hnsw_plan' in n else 'merge' if 'k_link_merge' in n else None
+    key = 'join' if 'k_match_join' in n else 'sample' if 'k_match_sample' in n else 'dense' if 'k_hnsw_search_dense' in n else 'plan' if 'k_hnsw_plan' in n else 'merge' if 'k_link_merge' in n else 'tile' if 'k_hamming_qxc' in n else 'sketch' if 'k_sketch_min' in n else None
     if key: names.setdefault(key, []).append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
 for k, v in names.items():
     v.sort()
