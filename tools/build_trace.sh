@@ -8,8 +8,12 @@ rows = list(csv.DictReader(open(fn)))
 names = {}
 for r in rows:
     n = r['Kernel_Name']
-    key = 'join' if 'k_match_join' in n else 'sample' if 'k_match_sample' in n else 'dense' if 'k_hnsw_search_dense' in n else 'plan' if 'k_hnsw_plan' in n else 'merge' if 'k_link_merge' in n else 'tile' if 'k_hamming_qxc' in n else 'sketch' if 'k_sketch_min' in n else None
+    key = 'join' if 'k_match_join' in n else 'sample' if 'k_match_sample' in n else 'dense' if 'k_hnsw_search_dense' in n else 'plan' if 'k_hnsw_plan' in n else 'merge' if 'k_link_merge' in n else 'link' if 'k_link_' in n else 'cache' if 'k_cache_rows' in n else 'r2c' if 'k_rows_to_cols' in n else 'fill' if 'fillBuffer' in n else 'copy' if 'copyBuffer' in n else 'tile' if 'k_hamming_qxc' in n else 'sketch' if 'k_sketch_min' in n else None
     if key: names.setdefault(key, []).append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+if 'plan' in names:
+    v = sorted(names['plan'])
+    a = [x[1] / 1e6 for x in v[0::2]]; b = [x[1] / 1e6 for x in v[1::2]]
+    print('plan alternate launches (phase 1 / phase 2 once the pre-pass is on): %.0f ms / %.0f ms' % (sum(a), sum(b)))
 for k, v in names.items():
     v.sort()
     d = [x[1] / 1e6 for x in v]
