@@ -1245,7 +1245,7 @@ __device__ __forceinline__ bool select_check_rows(const IndexDev &ix, const Sear
 // cache the walk takes the candidates SEL_CH at a time: every lane that owns a kept key looks the chunk's candidates up at once (one
 // memory round trip and two barriers per chunk instead of per candidate); the chunk ends at its first accepted candidate - the ones
 // behind it have to see the new member - so the result is the sequential one.
-constexpr int SEL_CH = 8;
+constexpr int SEL_CH = 16;     // (8 -> 16: the walk is bound by its memory round trips per chunk, not by the sectors it fetches)
 template <int KIND>
 __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const SearchLds &S, uint32_t nW, uint32_t deg, bool heuristic, uint64_t &evals, uint32_t na0 = 0)
 {
@@ -1269,7 +1269,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
         uint32_t fr = 0;                                                  // c(x,e) = m: c(e,s) <= m for every s, always pruned
 #pragma unroll
         for (int j = 0; j < SEL_CH; j++) if ((uint32_t)j < nc && KCNT(S.R[i + j]) >= ix.m) fr |= 1u << j;
-        uint32_t cm = 0, pm = 0;                                          // cm: bit j = conflict with my kept key, bit 16 + j = that pair is not cached
+        uint32_t cm = 0, pm = 0, pbit = 0;                                // cm: bit j = conflict with my kept key, bit 16 + j = that pair is not cached
         if (threadIdx.x < na) {
             const uint32_t sid = KID(S.A[threadIdx.x]);
             const uint16_t *row[SEL_CH]; uint32_t lo[SEL_CH];
@@ -1287,6 +1287,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
 #pragma unroll
             for (int j = 0; j < SEL_CH; j++) if (row[j] && (uint32_t)row[j][lo[j]] <= KCNT(S.R[i + j])) cm |= 1u << j;
         } else if (threadIdx.x - na < (uint32_t)(SEL_CH * (SEL_CH - 1) / 2)) {
+            static_assert(SEL_CH <= 16, "cm: 16 conflict bits + 16 not-cached bits; pair bits in orw[1..4]");
             // the pairs INSIDE the chunk (j > k): candidate j must also clear the candidates of the chunk that are kept before it.
             // pm: bit (j * (j - 1) / 2 + k) = c(e_j, e_k) <= c(x, e_j); a pair that is not cached counts as "e_j not cached" (bit 16 + j)
             uint32_t t = threadIdx.x - na, j = 1;
@@ -1297,15 +1298,18 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
                 const uint32_t hi = ej > ek ? ej : ek, lo2 = ej > ek ? ek : ej;
                 const uint16_t *row = (const uint16_t *)ix.rowptr[hi];
                 if (!row) cm |= 1u << (16 + j);
-                else if ((uint32_t)row[lo2] <= KCNT(S.R[i + j])) pm |= 1u << (j * (j - 1) / 2 + k);
+                else if ((uint32_t)row[lo2] <= KCNT(S.R[i + j])) { pbit = j * (j - 1) / 2 + k; pm = 1; }
             }
         }
-        if (threadIdx.x == 0) { orw[0] = 0; orw[1] = 0; }
+        if (threadIdx.x < 6) orw[threadIdx.x] = 0;
         __syncthreads();
         if (cm) atomicOr(&orw[0], cm);
-        if (pm) atomicOr(&orw[1], pm);
+        if (pm) atomicOr(&orw[1 + (pbit >> 5)], 1u << (pbit & 31));
         __syncthreads();
-        const uint32_t v = orw[0], pv = orw[1];
+        const uint32_t v = orw[0];
+        uint32_t pw[5];
+#pragma unroll
+        for (int t = 0; t < 5; t++) pw[t] = orw[1 + t];
         // resolve the chunk in order (every lane does the same arithmetic)
         uint32_t kept = 0, j = 0, nacc = 0;
         bool slow = false;
@@ -1314,7 +1318,9 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
             if ((v >> (16 + j)) & 1u) { slow = true; break; }            // some pair of this candidate is not cached: check it the slow way
             evals += na + nacc;
             bool ok = !((v >> j) & 1u);
-            const uint32_t prow = (pv >> (j * (j - 1) / 2)) & ((1u << j) - 1u);       // conflicts of j with the earlier candidates of the chunk
+            const uint32_t pb = j * (j - 1) / 2, pwi = pb >> 5;                       // conflicts of j with the earlier candidates of the chunk: j bits from bit pb
+            const uint64_t two = (uint64_t)(pwi == 0 ? pw[0] : pwi == 1 ? pw[1] : pwi == 2 ? pw[2] : pw[3]) | (uint64_t)(pwi == 0 ? pw[1] : pwi == 1 ? pw[2] : pwi == 2 ? pw[3] : pw[4]) << 32;
+            const uint32_t prow = (uint32_t)(two >> (pb & 31)) & ((1u << j) - 1u);
             if (ok && (prow & kept)) ok = false;
             if (ok) { kept |= 1u << j; nacc++; }
         }
