@@ -1578,27 +1578,60 @@ __global__ __launch_bounds__(LM_T) void k_link_merge(GraphDev g, uint32_t inbox_
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < n; t += LM_T)
             keys[t] = t < d ? KEY(cnt[t], nbr[t]) : inbox[(uint64_t)list * inbox_cap + (t - d)];
-        __syncthreads();
-        // duplicates (the same undirected edge proposed from both ends inside one batch) have identical keys
-        for (uint32_t t = threadIdx.x; t < n; t += LM_T) {
-            const uint64_t k = keys[t]; uint32_t dup = 0;
-            for (uint32_t j = 0; j < t; j++) dup |= (keys[j] == k);
-            flag[t] = dup;
-        }
-        __syncthreads();
+        // The list as it stands is sorted (this kernel and k_link_own write keys at their rank) unless it came in through import_graph:
+        // then a key's rank is its position plus the inbox keys below it, and an inbox key's rank a binary search plus the inbox keys
+        // below it - O(d * ni) instead of the O(n^2) of ranking everything against everything (1.4 s of a 300 k build; ni is a handful).
+        bool unsorted = false;
+        for (uint32_t t = threadIdx.x + 1; t < d; t += LM_T) unsorted |= !(keys[t - 1] < keys[t]);
+        const bool general = __syncthreads_or(unsorted) != 0;
         uint32_t rk[LM_MAX / LM_T]; uint64_t kv[LM_MAX / LM_T];
-#pragma unroll
-        for (int it = 0; it < LM_MAX / LM_T; it++) {
-            const uint32_t t = threadIdx.x + it * LM_T;
-            rk[it] = 0xFFFFFFFFu; kv[it] = 0;
-            if (t < n && !flag[t]) {
-                const uint64_t k = keys[t]; uint32_t r = 0;
-                for (uint32_t j = 0; j < n; j++) r += (!flag[j] && keys[j] < k);
-                rk[it] = r; kv[it] = k;
-            }
-        }
         uint32_t ndup = 0;
-        for (uint32_t j = 0; j < n; j++) ndup += flag[j];
+        if (general) {
+            // duplicates (the same undirected edge proposed from both ends inside one batch) have identical keys
+            for (uint32_t t = threadIdx.x; t < n; t += LM_T) {
+                const uint64_t k = keys[t]; uint32_t dup = 0;
+                for (uint32_t j = 0; j < t; j++) dup |= (keys[j] == k);
+                flag[t] = dup;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < LM_MAX / LM_T; it++) {
+                const uint32_t t = threadIdx.x + it * LM_T;
+                rk[it] = 0xFFFFFFFFu; kv[it] = 0;
+                if (t < n && !flag[t]) {
+                    const uint64_t k = keys[t]; uint32_t r = 0;
+                    for (uint32_t j = 0; j < n; j++) r += (!flag[j] && keys[j] < k);
+                    rk[it] = r; kv[it] = k;
+                }
+            }
+            for (uint32_t j = 0; j < n; j++) ndup += flag[j];
+        } else {
+            // an inbox key is a duplicate when the list holds it already or an earlier inbox entry equals it; flag[d + u] = dup | (lower bound << 1)
+            for (uint32_t u = threadIdx.x; u < ni; u += LM_T) {
+                const uint64_t k = keys[d + u];
+                uint32_t lo = 0, hi = d;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < k) lo = mid + 1; else hi = mid; }
+                uint32_t dup = lo < d && keys[lo] == k;
+                for (uint32_t v = 0; v < u; v++) dup |= (keys[d + v] == k);
+                flag[d + u] = dup | (lo << 1);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < LM_MAX / LM_T; it++) {
+                const uint32_t t = threadIdx.x + it * LM_T;
+                rk[it] = 0xFFFFFFFFu; kv[it] = 0;
+                if (t < d) {
+                    const uint64_t k = keys[t]; uint32_t r = t;
+                    for (uint32_t v = 0; v < ni; v++) r += (!(flag[d + v] & 1u) && keys[d + v] < k);
+                    rk[it] = r; kv[it] = k;
+                } else if (t < n && !(flag[t] & 1u)) {
+                    const uint64_t k = keys[t]; uint32_t r = flag[t] >> 1;
+                    for (uint32_t v = 0; v < ni; v++) r += (!(flag[d + v] & 1u) && keys[d + v] < k);
+                    rk[it] = r; kv[it] = k;
+                }
+            }
+            for (uint32_t v = 0; v < ni; v++) ndup += flag[d + v] & 1u;
+        }
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < LM_MAX / LM_T; it++) if (rk[it] < cap) { nbr[rk[it]] = KID(kv[it]); cnt[rk[it]] = KCNT(kv[it]); }
