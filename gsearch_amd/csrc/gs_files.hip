@@ -545,9 +545,13 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         team.work.notify_all();
     };
     auto wait_group = [&](uint64_t g) { std::unique_lock<std::mutex> lk(team.m); team.done.wait(lk, [&] { return team.left[g] == 0; }); };
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, inflate_stream = nullptr;
     GS_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (dev_gzip && hipStreamCreateWithFlags(&inflate_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(copy_stream); gs::set_error("hipStreamCreate failed"); return GS_ERR_HIP; }
+    hipEvent_t ev[2] = {nullptr, nullptr}, iev[2] = {nullptr, nullptr};
+    // the device's .gz members of group g are inflated on their own stream as soon as they are on the device - under the crc / scan / pack / sketch
+    // of group g - 1; per buffer parity: descriptors, the files they belong to, device copies, pinned results
+    std::vector<gs::InflateStream> ist[2]; std::vector<uint64_t> iwho[2]; gs::DevBuf ids[2], idr[2]; bool ilaunched[2] = {false, false};
     gs::DevBuf dtext[2], dcomp[2], dout, drs, drl, dgo, dsig;
     std::vector<uint8_t> rows_tmp;
     double read_s = 0, copy_wait_s = 0, dev_s = 0;
@@ -560,11 +564,14 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         team.th.clear();
         if (copy_stream) (void)hipStreamSynchronize(copy_stream);      // an H2D copy out of a pinned buffer may still be in flight on an error path
         (void)hipStreamSynchronize(c->stream);
-        for (int i = 0; i < 2; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (inflate_stream) (void)hipStreamSynchronize(inflate_stream);
+        for (int i = 0; i < 2; i++) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (iev[i]) (void)hipEventDestroy(iev[i]); }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (inflate_stream) (void)hipStreamDestroy(inflate_stream);
     };
 #define GS_FILES_FAIL(code) do { const int rc_ = (code); cleanup(); return rc_; } while (0)
-    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { gs::set_error("hipEventCreate failed"); GS_FILES_FAIL(GS_ERR_HIP); }
+    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
+                                    hipEventCreateWithFlags(&iev[i], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { gs::set_error("hipEventCreate failed"); GS_FILES_FAIL(GS_ERR_HIP); }
     for (uint32_t t = 0; t < std::max<uint32_t>(1, (uint32_t)std::min<uint64_t>(n_threads, n_files)); t++)
         team.th.emplace_back([&]() {
             for (;;) {
@@ -632,6 +639,33 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         GS_HIP_CHECK(hipEventRecord(ev[b], copy_stream));
         return GS_OK;
     };
+    // start the inflate of group g's members (behind its H2D copies), on the inflate stream
+    auto inflate_launch = [&](uint64_t g) -> int {
+        const int b = (int)(g & 1), sl = (int)(g % NSLOT);
+        ilaunched[b] = false;
+        if (!dev_gtot[g]) return GS_OK;
+        Staged &S = staged[b];
+        ist[b].clear(); iwho[b].clear();
+        for (uint64_t f = 0; f < blobs[g].size(); f++) {
+            const auto &fb = blobs[g][f];
+            if (!fb.gz_dev) continue;
+            ist[b].push_back({(uint64_t)(fb.src - (uint8_t *)cpin[sl]) + fb.gz_hdr, fb.gz_len - fb.gz_hdr, S.gbase + fb.g_off, fb.g_cap});
+            iwho[b].push_back(f);
+        }
+        const size_t ns = ist[b].size();
+        if (!ns) return GS_OK;
+        int rc2;
+        uint8_t *pin = (uint8_t *)pool->ensure(32 + b, (sizeof(gs::InflateStream) + sizeof(gs::InflateResult)) * ns + 64);
+        if (!pin) { gs::set_error("hipHostMalloc failed"); return GS_ERR_HIP; }
+        memcpy(pin, ist[b].data(), sizeof(gs::InflateStream) * ns);
+        if ((rc2 = ids[b].ensure(sizeof(gs::InflateStream) * ns)) || (rc2 = idr[b].ensure(sizeof(gs::InflateResult) * ns))) return rc2;
+        GS_HIP_CHECK(hipStreamWaitEvent(inflate_stream, ev[b], 0));
+        if ((rc2 = gs::inflate_streams_launch(c, inflate_stream, dcomp[b].p, (const gs::InflateStream *)pin, (uint32_t)ns, dtext[b].p, ids[b].p, idr[b].p,
+                                              (gs::InflateResult *)(pin + sizeof(gs::InflateStream) * ns)))) return rc2;
+        GS_HIP_CHECK(hipEventRecord(iev[b], inflate_stream));
+        ilaunched[b] = true;
+        return GS_OK;
+    };
     // device stage of group g (its text is, or soon will be, in dtext[g & 1])
     auto device_stage = [&](uint64_t g) -> int {
         const int b = (int)(g & 1);
@@ -643,16 +677,13 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         t0 = std::chrono::steady_clock::now();
         int rc2;
         if (dev_gtot[g]) {          // inflate the group's .gz members on the device, check them against their trailers, find their records
-            std::vector<gs::InflateStream> st; std::vector<uint64_t> who;
-            const int sl = (int)(g % NSLOT);
-            for (uint64_t f = 0; f < nf; f++) {
-                const auto &fb = blobs[g][f];
-                if (!fb.gz_dev) continue;
-                st.push_back({(uint64_t)(fb.src - (uint8_t *)cpin[sl]) + fb.gz_hdr, fb.gz_len - fb.gz_hdr, S.gbase + fb.g_off, fb.g_cap});
-                who.push_back(f);
-            }
+            std::vector<gs::InflateStream> &st = ist[b]; std::vector<uint64_t> who = iwho[b];
             std::vector<gs::InflateResult> res(st.size());
-            if ((rc2 = gs::inflate_streams_dev(c, dcomp[b].p, st.data(), (uint32_t)st.size(), dtext[b].p, res.data()))) return rc2;
+            if (ilaunched[b]) {
+                GS_HIP_CHECK(hipEventSynchronize(iev[b]));
+                memcpy(res.data(), (const uint8_t *)pool->p[32 + b] + sizeof(gs::InflateStream) * st.size(), sizeof(gs::InflateResult) * st.size());
+                ilaunched[b] = false;
+            }
             std::vector<uint64_t> toff(st.size()), tlen(st.size());
             for (size_t k = 0; k < st.size(); k++) {
                 const bool ok = res[k].status == 0 && res[k].in_used + 8 == st[k].in_len && res[k].out_len == st[k].out_cap;
@@ -726,13 +757,24 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         if (deal) { std::lock_guard<std::mutex> lk(deal->m); (from_back ? deal->done_back : deal->done_front) += claimed_gz[g]; }
         return GS_OK;
     };
+    double tsec[5] = {0, 0, 0, 0, 0};      // GS_INGEST_TIMES=1: wall seconds in stage / inflate launch / start_group / device stage / cleanup
+    auto tick = [&](int k, std::chrono::steady_clock::time_point t0) { tsec[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     for (uint64_t g = 0; g < n_groups_eff; g++) {
+        auto t0 = std::chrono::steady_clock::now();
         if ((rc = stage(g))) GS_FILES_FAIL(rc);                    // H2D of group g starts ...
+        tick(0, t0); t0 = std::chrono::steady_clock::now();
+        if ((rc = inflate_launch(g))) GS_FILES_FAIL(rc);           // ... its .gz members inflate behind it ...
+        tick(1, t0); t0 = std::chrono::steady_clock::now();
         if (g + LA < n_groups_eff) start_group(g + LA);            // ... the host threads move on to group g+LA ...
+        tick(2, t0); t0 = std::chrono::steady_clock::now();
         if (g >= 1 && (rc = device_stage(g - 1))) GS_FILES_FAIL(rc);   // ... while the device packs and sketches group g-1
+        tick(3, t0);
     }
-    if (n_groups_eff && (rc = device_stage(n_groups_eff - 1))) GS_FILES_FAIL(rc);
-    cleanup();
+    { auto t0 = std::chrono::steady_clock::now(); if (n_groups_eff && (rc = device_stage(n_groups_eff - 1))) GS_FILES_FAIL(rc); tick(3, t0); }
+    { auto t0 = std::chrono::steady_clock::now(); cleanup(); tick(4, t0); }
+    if (getenv("GS_INGEST_TIMES"))
+        fprintf(stderr, "[GS_INGEST_TIMES] %s pipeline, %llu groups: stage %.3f s, inflate launch %.3f, start_group %.3f, device stage %.3f, cleanup %.3f\n", dev_gzip ? "device" : "host",
+                (unsigned long long)n_groups_eff, tsec[0], tsec[1], tsec[2], tsec[3], tsec[4]);
 #undef GS_FILES_FAIL
     if (stats_out) {
         stats_out[0] = read_s; stats_out[1] = copy_wait_s; stats_out[2] = dev_s;
@@ -762,9 +804,10 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
         n_free = ia.size();
         for (uint64_t f = n_files; f-- > 0;) if (gs::ends_with(paths[f], ".gz")) ib.push_back(f);
         deal.n_gz = ib.size();
-        if (deal.n_gz >= 64) ia.insert(ia.end(), ib.rbegin(), ib.rend());     // a handful of files: all of them to the device
+        const char *only = getenv("GS_GZIP_DEVICE_ONLY");                       // measurement aid: 1 = every .gz to the device pipeline, the host pipeline idle
+        if (deal.n_gz >= 64 && !(only && atoi(only))) ia.insert(ia.end(), ib.rbegin(), ib.rend());     // a handful of files: all of them to the device
     }
-    const bool dealing = dev_gzip && deal.n_gz >= 64;
+    const bool dealing = dev_gzip && deal.n_gz >= 64 && ia.size() > n_free;
     double st_a[4] = {0, 0, 0, 0}, st_b[4] = {0, 0, 0, 0};
     if (ib.empty()) {
         int rc = sketch_files_impl(c, p, paths, n_files, block_mode, pio, n_threads, sig_out, n_records_out, n_symbols_out, stats_out, false, nullptr, nullptr, 0, nullptr, false, 0);

@@ -407,6 +407,22 @@ int inflate_streams_dev(gs_ctx *c, const void *comp_dev, const InflateStream *st
     return GS_OK;
 }
 
+// the same launch, asynchronous on `stream`: descriptors and results live in PINNED host memory (a copy from / to pageable memory would make the
+// call wait for the stream), nothing is waited for - the caller records an event behind it
+int inflate_streams_launch(gs_ctx *c, hipStream_t stream, const void *comp_dev, const InflateStream *streams_pinned, uint32_t n, void *out_dev, void *ds_dev, void *dr_dev,
+                           InflateResult *results_pinned)
+{
+    if (n == 0) return GS_OK;
+    GS_HIP_CHECK(hipMemcpyAsync(ds_dev, streams_pinned, sizeof(InflateStream) * n, hipMemcpyHostToDevice, stream));
+    const char *w = getenv("GS_INFLATE_WINDOW");
+    const bool gwin = w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu;
+    if (gwin) hipLaunchKernelGGL(k_inflate<true>, dim3(n), dim3(64), 0, stream, (const uint32_t *)comp_dev, (const InflateStream *)ds_dev, n, (uint8_t *)out_dev, (InflateResult *)dr_dev);
+    else hipLaunchKernelGGL(k_inflate<false>, dim3(n), dim3(64), 0, stream, (const uint32_t *)comp_dev, (const InflateStream *)ds_dev, n, (uint8_t *)out_dev, (InflateResult *)dr_dev);
+    GS_HIP_CHECK(hipGetLastError());
+    GS_HIP_CHECK(hipMemcpyAsync(results_pinned, dr_dev, sizeof(InflateResult) * n, hipMemcpyDeviceToHost, stream));
+    return GS_OK;
+}
+
 int crc32_texts_dev(gs_ctx *c, const void *text_dev, const uint64_t *text_off, const uint64_t *text_len, uint32_t n, uint32_t *crc_out)
 {
     std::vector<CrcChunk> chunks; std::vector<uint64_t> first_chunk(n + 1);

@@ -138,7 +138,7 @@ struct DevBuf {   // owning device allocation
 // shared; gs_ctx_release_scratch / gs_ctx_destroy give the memory back.
 enum { SCRATCH_SLOTS = 48 };
 struct ScratchPool { DevBuf b[SCRATCH_SLOTS]; };
-enum { PINNED_SLOTS = 32 };
+enum { PINNED_SLOTS = 36 };      // 0-15 text, 16-31 compressed members, 32-33 inflate descriptors / results
 struct PinnedPool {
     void *p[PINNED_SLOTS] = {}; size_t cap[PINNED_SLOTS] = {};
     ~PinnedPool() { for (int i = 0; i < PINNED_SLOTS; i++) if (p[i]) (void)hipHostFree(p[i]); }
