@@ -399,16 +399,25 @@ int gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t c
  */
 // The .gz files of a call are dealt between two pipelines as they go (see gs_sketch_files): the host pipeline claims them from the front of
 // the list, the device pipeline from the back, group by group, until the two meet.
-// The device pipeline takes a group only as large as lets both finish together: with rates ra, rb (files/s, measured once 256 files are
-// done, priors before), files claimed but unfinished pa, pb and R unclaimed, (pb + k) / rb = (R - k + pa) / ra.
+// The device pipeline takes a group only as large as lets both finish together. Host pipeline: rate ra (files/s, measured once 256 files are
+// done, a prior before). Device pipeline: a start-up latency (reading, copying and inflating its first group: nothing is done before) and a
+// rate rb behind it. With pa, pb files claimed but unfinished and R unclaimed: lat + (pb + k) / rb = (R - k + pa) / ra.
 struct GzDeal {
     std::mutex m; uint64_t n_gz = 0, front = 0, back = 0, done_front = 0, done_back = 0;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    static constexpr double LAT = 0.45;
     double rate(bool back_side) const
     {
         const uint64_t d = back_side ? done_back : done_front;
-        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return d >= 256 && el > 0 ? (double)d / el : (back_side ? 1500.0 : 2300.0);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - (back_side ? LAT : 0.0);
+        return d >= 256 && el > 0.05 ? (double)d / el : (back_side ? 3500.0 : 2300.0);
+    }
+    // members the device pipeline should take now out of `avail`
+    double device_share(uint64_t avail) const
+    {
+        const double ra = rate(false), rb = rate(true);
+        const double pa = (double)(front - done_front), pb = (double)(back - done_back);
+        return (((double)avail + pa) / ra - pb / rb - (done_back ? 0.0 : LAT)) / (1.0 / rb + 1.0 / ra);
     }
 };
 
@@ -427,12 +436,16 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
     GS_HIP_CHECK(hipSetDevice(c->device));
     const auto t_call = std::chrono::steady_clock::now();
     const bool aa = p->data_t == GS_DATA_AA;
+    struct WaitMode { gs_ctx *c; bool prev; ~WaitMode() { c->wait_sleeping = prev; } } wait_mode{c, c->wait_sleeping};
+    c->wait_sleeping = dev_gzip;     // the device pipeline waits for hundreds of milliseconds at a time: asleep; the host pipeline: spinning
     if (pio == 0) {                  // small groups overlap best on the host path (measured: 32 files per group 3200 genomes/s, 64: 2400, 256: 900);
         pio = 32;                    // the device inflates one member per wave: it wants thousands of members per group
         if (dev_gzip) {
             uint64_t ngz = 0;
             for (uint64_t f = 0; f < n_files; f++) ngz += gs::ends_with(paths[f], ".gz");
-            if (2 * ngz > n_files) pio = (uint32_t)std::max(32, 12 * c->n_cu);      // (beyond 4 per CU the launcher takes the window-less form of k_inflate)
+            // (beyond 4 per CU the launcher takes the window-less form of k_inflate. Six members per CU: the host pipeline's pack / sketch launches run
+            // beside them almost unhindered - 41 ms against 34 alone for 64 genomes, 105 ms beside twelve per CU: tools/inflate_corun.py)
+            if (2 * ngz > n_files) { const char *e = getenv("GS_GZIP_GROUP"); pio = (uint32_t)std::max(32, e ? atoi(e) : 6 * c->n_cu); }
         }
     }
     if (n_threads == 0) n_threads = gs::usable_cpus();
@@ -477,9 +490,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
             const uint64_t avail = deal->n_gz - deal->front - deal->back;
             uint64_t take = std::min(cnt, avail);
             if (from_back) {
-                const double ra = deal->rate(false), rb = deal->rate(true);
-                const double pa = (double)(deal->front - deal->done_front), pb = (double)(deal->back - deal->done_back);
-                const double k = (rb * ((double)avail + pa) - ra * pb) / (ra + rb);
+                const double k = deal->device_share(avail);
                 take = k < 128 ? 0 : std::min<uint64_t>(take, (uint64_t)k);          // a launch costs the same ~0.4 s for 100 members as for 1000
             }
             (from_back ? deal->back : deal->front) += take;
@@ -570,7 +581,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         if (inflate_stream) (void)hipStreamDestroy(inflate_stream);
     };
 #define GS_FILES_FAIL(code) do { const int rc_ = (code); cleanup(); return rc_; } while (0)
-    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
+    for (int i = 0; i < 2; i++) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | (dev_gzip ? hipEventBlockingSync : 0)) != hipSuccess ||
                                     hipEventCreateWithFlags(&iev[i], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { gs::set_error("hipEventCreate failed"); GS_FILES_FAIL(GS_ERR_HIP); }
     for (uint32_t t = 0; t < std::max<uint32_t>(1, (uint32_t)std::min<uint64_t>(n_threads, n_files)); t++)
         team.th.emplace_back([&]() {
