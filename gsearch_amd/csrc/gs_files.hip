@@ -514,7 +514,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
                     if (fz && fseek(fz, -4, SEEK_END) == 0 && fread(t4, 1, 4, fz) == 4) want = (uint64_t)t4[0] | (uint64_t)t4[1] << 8 | (uint64_t)t4[2] << 16 | (uint64_t)t4[3] << 24;
                     if (fz) fclose(fz);
                     if (want < (uint64_t)st.st_size / 2 || want > (uint64_t)st.st_size * 64 || want >= (1u << 30)) want = 0;       // not a plausible single member
-                    if (want && dev_gzip) {          // the device's: member -> pinned compressed buffer, text -> the group's device-text region
+                    if (want && dev_gzip && dtot + (uint64_t)st.st_size < ((uint64_t)12 << 30)) {          // (k_inflate indexes the compressed words of a launch with 32 bits) the device's: member -> pinned compressed buffer, text -> the group's device-text region
                         doff[f - f0] = dtot; dcap[f - f0] = (uint64_t)st.st_size; dtot += ((uint64_t)st.st_size + 63) / 64 * 64;
                         goff[f - f0] = gtot; cap[f - f0] = want; gtot += (want + 63) / 64 * 64;
                         continue;

@@ -599,6 +599,7 @@ int gs_gunzip_batch(gs_ctx *c, const uint8_t *const *in, const uint64_t *in_len,
         const uint8_t *t = in[i] + in_len[i] - 4;
         isize[i] = (uint64_t)t[0] | (uint64_t)t[1] << 8 | (uint64_t)t[2] << 16 | (uint64_t)t[3] << 24;
         if (isize[i] > out_cap[i] || isize[i] >= ((uint64_t)1 << 30)) { status[i] = 104; continue; }
+        GS_REQUIRE(ctot + in_len[i] < ((uint64_t)12 << 30), GS_ERR_INVALID, "gs_gunzip_batch: more than 12 GiB of members in one call");
         coff[i] = ctot;
         st.push_back({ctot + h, in_len[i] - h, otot, isize[i]});
         who.push_back(i);
