@@ -450,7 +450,14 @@ def run_request(args, D):
         if D.world > 1 or args.no_cpu_baseline:                # parity sample and CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = None
         else:
-            out.update(request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, nsteps_q, gbytes, words))
+            par, oix = request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, nsteps_q, gbytes, words)
+            out.update(par)
+            if not args.no_extra_legs and args.redundant_roots > 0:
+                try:
+                    out["request_redundant"] = redundant_leg(args, ctx, hn, lib, chk, torch, sketch_dev, d_rs, d_rl, d_goff, gbytes, oix, out["ms_per_step"])
+                except Exception as e:                          # the headline line must survive a failing side leg
+                    out["request_redundant"] = {"error": repr(e)}
+            del oix
         if D.world == 1 and not args.no_extra_legs:
             try:
                 out["extra_legs"] = extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff)
@@ -756,7 +763,7 @@ def request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, n
     # (b) the same graph searched by the oracle (CPU, all cores)
     db = hn.get_data()
     oix = O.Index(np.float32, m, args.max_nb_conn, args.ef_construction, scale_modify=args.scale_modify, seed=args.seed)
-    oix.import_graph(db, hn.export_graph())
+    oix.import_graph(db, hn.export_graph(), view=True)           # a pointer to the 21.6 GB of rows, not a second copy
     t0 = time.perf_counter()
     oids, odist, ocnt, oev = oix.parallel_search(qsig, knbn, ef, nthreads=min(cores, ns))
     cpu_search_s = time.perf_counter() - t0
@@ -776,7 +783,53 @@ def request_parity_and_cpu(args, ctx, hn, d_qsig, d_qseq, ids_t, dist_t, ev_t, n
                            "sample": "%d of the step's query genomes on %d OpenMP threads = the CPUs this process may use (affinity / cgroup quota; the host lists %d): oracle sketch %.2fs + oracle parallel_search (same graph, ef=%d) %.2fs"
                                      % (ns, min(cores, ns), logical, cpu_sketch_s, ef, cpu_search_s),
                            "note": "CPU restatement (oracle), not upstream gsearch: the Rust reference cannot be built here"}
-    return out
+    return out, oix
+
+
+def redundant_leg(args, ctx, hn, lib, chk, torch, sketch_dev, d_rs, d_rl, d_goff, gbytes, oix, headline_ms):
+    """`request` on the data gsearch is run on (GTDB / NCBI prokaryotes, /root/reference/README.md:134: thousands of near-identical genomes per
+    species): the same database, but the 10 000 queries of a step are isolates of only `--redundant-roots` of its families (~330 per family
+    instead of ~3). Same code path, same parameters; sketch + search timed like a headline step (wall clock around the calls, inputs resident)."""
+    import ctypes as C
+    k, m, L, qps, knbn, ef = args.kmer, args.sketch_size, args.genome_len, args.queries_per_step, args.knbn, args.ef_search
+    R = args.redundant_roots
+    d_seq = ctx.alloc(qps * gbytes + 64)
+    d_sig = ctx.alloc(qps * m * 4)
+    ids = torch.empty((qps, knbn), dtype=torch.int64, device="cuda"); dist = torch.empty((qps, knbn), dtype=torch.float32, device="cuda")
+    cnt = torch.empty((qps,), dtype=torch.int32, device="cuda"); ev = torch.zeros((qps,), dtype=torch.int64, device="cuda")
+    try:
+        steps = []
+        for i in range(3):                                             # step 0 warms up; every step has its own query genomes
+            chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, 2_000_000_000 + i * qps, qps, L, R, 0.001, 0.08, d_seq))
+            ctx.sync()
+            ctx.profile(True)
+            for fam in range(4):
+                ctx.profile_read(fam, reset=True)
+            hn.search_stats(reset=True)
+            t0 = time.perf_counter()
+            sketch_dev(d_seq, qps, d_sig, d_rs, d_rl, d_goff)
+            chk(lib.gs_index_parallel_search_dev(hn.h, d_sig, qps, knbn, ef, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr(), ev.data_ptr()))
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            srch, prod, sk = ctx.profile_read(2, reset=True), ctx.profile_read(1, reset=True), ctx.profile_read(0, reset=True)
+            ctx.profile(False)
+            st = hn.search_stats(reset=True)
+            if i:
+                steps.append({"ms": dt * 1e3, "sketch_ms": sk[0], "producer_ms": prod[0], "producer_launches": prod[1], "traversal_ms": srch[0], "join_atomics": st.get("join_atomics", 0)})
+        best = min(steps, key=lambda x: x["ms"])
+        ns = 32
+        qsig = ctx.download(d_sig, (qps, m), np.float32)[:ns]
+        oids, odist, ocnt, oev = oix.parallel_search(qsig, knbn, ef, nthreads=min(host_cpu_budget()[1], ns))
+        same = bool(np.array_equal(oids, ids.cpu().numpy().view(np.uint64)[:ns]) and np.array_equal(odist.view(np.uint32), dist.cpu().numpy()[:ns].view(np.uint32))
+                    and np.array_equal(oev, ev.cpu().numpy().view(np.uint64)[:ns]))
+        return {"workload": "request, redundant regime: %d query genomes x %.1f Mbp per step, all isolates of %d of the database's %d families (~%d queries per family; the headline has ~%.1f)"
+                            % (qps, L / 1e6, R, max(args.db_genomes // args.per_root, 1), qps // R, qps / max(args.db_genomes // args.per_root, 1)),
+                "genomes_per_sec": qps / (best["ms"] * 1e-3), "ms_per_step": best["ms"], "steps": steps, "ms_per_step_over_headline": best["ms"] / headline_ms,
+                "ids_distances_evals_equal_oracle_%d_queries" % ns: same,
+                "note": "count matrix by the match-join with heavy blocks (gs_join.hip): the (query, node) blocks of a species are written by the compare tile kernel, "
+                        "equal keys of a block's queries enter the hash table once; `producer_ms` sums every kernel of the count-matrix producer (HIP events)"}
+    finally:
+        ctx.free(d_seq); ctx.free(d_sig)
 
 
 def main():
@@ -802,6 +855,7 @@ def main():
     ap.add_argument("--scale-modify", type=float, default=0.25)
     ap.add_argument("--per-root", type=int, default=100)
     ap.add_argument("--build-chunk", type=int, default=8192)
+    ap.add_argument("--redundant-roots", type=int, default=30, help="families the queries of the `request_redundant` side leg are drawn from (0 = skip the leg)")
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the post-run legs (other sketchers, configs[4], gz ingest)")

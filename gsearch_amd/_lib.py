@@ -44,6 +44,7 @@ SYMBOLS = {
     "gs_ctx_release_scratch": (_i, [_vp]),
     "gs_ctx_stream": (_vp, [_vp]),
     "gs_ctx_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_u64), C.c_char_p, C.c_size_t]),
+    "gs_ctx_last_sketch_info": (_i, [_vp, _vp]),
     "gs_ctx_timer_start": (_i, [_vp]),
     "gs_ctx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "gs_ctx_profile": (_i, [_vp, _i]),
@@ -82,6 +83,7 @@ SYMBOLS = {
     "gs_index_parallel_insert_dev": (_i, [_vp, _vp, _u64]),
     "gs_index_parallel_search": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "gs_index_parallel_search_dev": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "gs_index_count_matrix": (_i, [_vp, _vp, _u64, _vp]),
     "gs_index_bruteforce_search": (_i, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "gs_index_import": (_i, [_vp, _vp, _u64, _vp, C.c_int64, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     "gs_index_export": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -70,6 +70,12 @@ class Context:
         check(self.L.gs_ctx_device_info(self.h, C.byref(ncu), C.byref(hbm), name, 128))
         return {"n_cu": ncu.value, "hbm_bytes": hbm.value, "name": name.value.decode()}
 
+    def last_sketch_info(self):
+        """form of the slot-min sketch kernel the last sketch call launched (include/gsearch_amd.h gs_ctx_last_sketch_info)"""
+        out = np.zeros(4, np.uint32)
+        check(self.L.gs_ctx_last_sketch_info(self.h, _p(out)))
+        return {"filtered": bool(out[0]), "table_in_lds": bool(out[1]), "workgroups_per_genome": int(out[2]), "launches": int(out[3])}
+
     # stopwatch / per-family kernel timers (HIP events on the context's stream)
     def timer_start(self):
         check(self.L.gs_ctx_timer_start(self.h))
@@ -568,6 +574,13 @@ class Hnsw:
         ids, dist, cnt, _ = self.search_arrays(datas, knbn, ef)
         return [[Neighbour(int(ids[i, j]), float(dist[i, j])) for j in range(int(cnt[i]))] for i in range(len(ids))]
 
+    def count_matrix(self, datas):
+        """mismatch counts of every query against every node (nq x nb_point, uint16) from the dense producer the search would use"""
+        datas = np.ascontiguousarray(datas, dtype=self.dtype)
+        out = np.zeros((datas.shape[0], self.get_nb_point()), dtype=np.uint16)
+        check(self.ctx.L.gs_index_count_matrix(self.h, _p(datas), datas.shape[0], _p(out)))
+        return out
+
     def bruteforce_search(self, datas, knbn):
         datas = np.ascontiguousarray(datas, dtype=self.dtype)
         ids = np.zeros((datas.shape[0], knbn), dtype=np.uint64)
@@ -632,7 +645,7 @@ class Hnsw:
         check(self.ctx.L.gs_index_search_stats(self.h, _p(out), int(reset)))
         pops = int(out[1])
         return {"join_atomics": int(out[0]), "pops": pops, "accepting_pops": int(out[2]), "wg_in_flight": int(out[3]),
-                "adj_bytes": pops * int(out[4]), "pops_phase1": int(out[5]), "pops_phase2": int(out[6])}
+                "adj_bytes": pops * int(out[4]), "pops_phase1": int(out[5]), "pops_phase2": int(out[6]), "join_shared_expansions": int(out[7])}
 
     def file_dump_hnswrs(self, basename, truncate_255=False):
         """Hnsw::file_dump(dir, "hnswdump") in hnsw_rs' own format: <basename>.hnsw.graph + <basename>.hnsw.data (dumpload.rs:26-31).

@@ -88,6 +88,13 @@ int gs_ctx_device_info(gs_ctx *c, int *n_cu, uint64_t *hbm, char *name, size_t c
     if (name && cap) { strncpy(name, c->name, cap - 1); name[cap - 1] = 0; }
     return GS_OK;
 }
+int gs_ctx_last_sketch_info(gs_ctx *c, uint32_t out[4])
+{
+    GS_REQUIRE(c && out, GS_ERR_INVALID, "gs_ctx_last_sketch_info: null argument");
+    GS_CTX_LOCK(c);
+    for (int i = 0; i < 4; i++) out[i] = c->last_sketch[i];
+    return GS_OK;
+}
 int gs_ctx_timer_start(gs_ctx *c)
 {
     GS_REQUIRE(c, GS_ERR_INVALID, "null context");

@@ -57,17 +57,21 @@ __device__ __forceinline__ void cmp_acc8_64(uint32_t (&c)[8], uint64_t a, const 
     GS_CMP8("v_cmp_ne_u64");
 }
 
-template <int KIND, bool VEC4>
+// IDX: the tiles of a work list instead of a grid over Q x C (the heavy blocks of the match-join, gs_join.hip): item = {first entry and length
+// of its query rows in qlist, first entry and length of its candidate rows in clist}; the rows are Q + qlist[.] * strideQ / C + clist[.] *
+// strideC and the counts go to out_cnt16[qlist[.] * ld_out + clist[.]].
+template <int KIND, bool VEC4, bool IDX>
 __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict__ Q, uint64_t nq, uint64_t strideQ, const uint32_t *__restrict__ C, uint64_t nc,
                                                       uint64_t strideC, uint32_t m, float *__restrict__ out, uint32_t *__restrict__ out_cnt, uint16_t *__restrict__ out_cnt16, uint64_t ld_out,
-                                                      uint32_t ksplit_words)
+                                                      uint32_t ksplit_words, const uint4 *__restrict__ items, const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ clist)
 {
     constexpr int EW = ElemCmp<KIND>::EW;
     __shared__ uint32_t sq[2][HT * HP];
     __shared__ uint32_t sc[2][HT * HP];
     // query tiles on the FAST grid dimension: blocks that share a candidate tile are dispatched together, so the candidate rows
     // come from HBM once and from L2 / Infinity Cache for the other query tiles
-    const uint64_t q0 = (uint64_t)blockIdx.x * HT, c0 = (uint64_t)blockIdx.y * HT;
+    uint64_t q0 = (uint64_t)blockIdx.x * HT, c0 = (uint64_t)blockIdx.y * HT;
+    if (IDX) { const uint4 it = items[blockIdx.x]; q0 = it.x; nq = q0 + it.y; c0 = it.z; nc = c0 + it.w; }      // (list positions; at most HT rows each)
     const uint32_t tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const uint64_t roww_full = (uint64_t)m * EW;     // words per row
     // K-split (small Q x C problems): blockIdx.z owns words [kbeg, roww); partial counts are added atomically (zeroed out_cnt)
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t idx = threadIdx.x + 256 * i, r = idx >> 3, kq = (idx & 7) * 4;
-            const uint64_t qr = q0 + r < nq ? q0 + r : nq - 1, cr = c0 + r < nc ? c0 + r : nc - 1;   // clamped rows: results discarded
+            uint64_t qr = q0 + r < nq ? q0 + r : nq - 1, cr = c0 + r < nc ? c0 + r : nc - 1;   // clamped rows: results discarded
+            if (IDX) { qr = qlist[qr]; cr = clist[cr]; }
             const uint32_t *pq = Q + qr * strideQ + w0 + kq, *pc = C + cr * strideC + w0 + kq;
             if (VEC4 && w0 + kq + 4 <= roww) { rq[i] = *(const uint4 *)pq; rc[i] = *(const uint4 *)pc; }
             else {
@@ -147,6 +152,14 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
             if (cj < nc) {
                 if (out) out[qi * ld_out + cj] = (float)cnt[i][j] / fm;
                 else if (out_cnt) { if (ksplit_words) atomicAdd(&out_cnt[qi * ld_out + cj], cnt[i][j]); else out_cnt[qi * ld_out + cj] = cnt[i][j]; }
+                else if (IDX) {
+                    const uint64_t idx = (uint64_t)qlist[qi] * ld_out + clist[cj];
+                    if (!ksplit_words) out_cnt16[idx] = (uint16_t)cnt[i][j];
+                    else {          // K-split: the counter was set to m (k_blocks_set); this part takes its MATCHES off, through the 32-bit container
+                        const uint32_t matches = (uint32_t)((roww - kbeg) / EW) - cnt[i][j];
+                        if (matches) atomicSub((uint32_t *)out_cnt16 + (idx >> 1), matches << ((idx & 1) * 16));
+                    }
+                }
                 else out_cnt16[qi * ld_out + cj] = (uint16_t)cnt[i][j];
             }
         }
@@ -200,11 +213,49 @@ int hamming_qxc_strided(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t
     ProfScope ps(c, FAM_HAMMING);
     const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
     const bool vec4 = (strideQ_bytes % 16 == 0) && (strideC_bytes % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)C % 16 == 0);
-#define GS_LAUNCH_QXC(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V>), grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt, out_cnt16, ld_out, ksplit_words)
+#define GS_LAUNCH_QXC(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V, false>), grid, block, 0, c->stream, (const uint32_t *)Q, nq, sq, (const uint32_t *)C, nc, sc, m, out, out_cnt, out_cnt16, ld_out, ksplit_words, (const uint4 *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
     if (kind == GS_KIND_F32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_F32, true); else GS_LAUNCH_QXC(GS_KIND_F32, false); }
     else if (kind == GS_KIND_U32) { if (vec4) GS_LAUNCH_QXC(GS_KIND_U32, true); else GS_LAUNCH_QXC(GS_KIND_U32, false); }
     else { if (vec4) GS_LAUNCH_QXC(GS_KIND_U64, true); else GS_LAUNCH_QXC(GS_KIND_U64, false); }
 #undef GS_LAUNCH_QXC
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+// every counter of the work list's tiles = m (before a K-split run takes the matches off)
+__global__ __launch_bounds__(256) void k_blocks_set(const uint4 *__restrict__ items, const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ clist, uint16_t *__restrict__ out16,
+                                                    uint64_t ld, uint32_t m)
+{
+    const uint4 it = items[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < it.y * it.w; i += 256) {
+        const uint32_t a = i / it.w, b = i - a * it.w;
+        out16[(uint64_t)qlist[it.x + a] * ld + clist[it.z + b]] = (uint16_t)m;
+    }
+}
+// the tiles of a work list (see k_hamming_qxc IDX): n_items x {qlist offset, rows (<= 128), clist offset, rows (<= 128)}, all in device memory
+int hamming_blocks(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t strideQ_bytes, const void *C, uint64_t strideC_bytes, const void *items_dev,
+                   uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out)
+{
+    if (n_items == 0) return GS_OK;
+    GS_REQUIRE(kind == GS_KIND_F32 || kind == GS_KIND_U32 || kind == GS_KIND_U64, GS_ERR_UNSUPPORTED, "DistHamming kind %d not on the device path", kind);
+    const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
+    const bool vec4 = (strideQ_bytes % 16 == 0) && (strideC_bytes % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)C % 16 == 0);
+    dim3 grid(n_items), block(256);
+    // few tiles (thirty species in a batch = thirty tiles): the rows are split over blockIdx.z so that the whole chip works on them
+    uint32_t ksplit_words = 0;
+    const uint64_t roww_all = (uint64_t)m * (kind == GS_KIND_U64 ? 2 : 1);
+    if ((uint64_t)n_items * 2 <= (uint64_t)c->n_cu * 2 && roww_all >= 8 * HKW) {
+        const uint32_t nz = (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu * 4 / n_items, roww_all / (4 * HKW));
+        if (nz > 1) {
+            ksplit_words = (uint32_t)(((roww_all + nz - 1) / nz + HKW - 1) / HKW * HKW);
+            grid.z = (uint32_t)((roww_all + ksplit_words - 1) / ksplit_words);
+            hipLaunchKernelGGL(k_blocks_set, dim3(n_items), dim3(256), 0, c->stream, (const uint4 *)items_dev, qlist_dev, clist_dev, out_cnt16, ld_out, m);
+        }
+    }
+#define GS_LAUNCH_BLK(K, V) hipLaunchKernelGGL((k_hamming_qxc<K, V, true>), grid, block, 0, c->stream, (const uint32_t *)Q, (uint64_t)0, sq, (const uint32_t *)C, (uint64_t)0, sc, m, (float *)nullptr, (uint32_t *)nullptr, out_cnt16, ld_out, ksplit_words, (const uint4 *)items_dev, qlist_dev, clist_dev)
+    if (kind == GS_KIND_F32) { if (vec4) GS_LAUNCH_BLK(GS_KIND_F32, true); else GS_LAUNCH_BLK(GS_KIND_F32, false); }
+    else if (kind == GS_KIND_U32) { if (vec4) GS_LAUNCH_BLK(GS_KIND_U32, true); else GS_LAUNCH_BLK(GS_KIND_U32, false); }
+    else { if (vec4) GS_LAUNCH_BLK(GS_KIND_U64, true); else GS_LAUNCH_BLK(GS_KIND_U64, false); }
+#undef GS_LAUNCH_BLK
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

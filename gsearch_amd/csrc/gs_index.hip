@@ -1666,7 +1666,7 @@ struct gs_index {
     // the neighbour-selection heuristic looks pair distances up instead of streaming rows; 288 GB of HBM hold it up to ~500 k points
     // column-major copy of the signatures for the match-join (gs_join.hip)
     gs::DevBuf cols; uint64_t cols_cap = 0, cols_n = 0;
-    gs::DevBuf join_scratch[5];
+    gs::DevBuf join_scratch[gs::JOIN_SCRATCH];
     gs::DevBuf stats;                 // device work counters: [0] join atomics, [1] dense-traversal pops, [2] accepting pops (gs_index_search_stats)
     uint64_t stat_wg_in_flight = 0, stat_adj_row_bytes = 0;
     gs::DevBuf rowptr;
@@ -1873,7 +1873,7 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
         const uint64_t nb = std::min<uint64_t>(jq, nq - q0);
         int declined = 0;
         if ((rc = match_join_counts(c, ix->ikind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch,
-                                    &declined, ix->stats.as<unsigned long long>()))) return rc;
+                                    &declined, ix->stats.as<unsigned long long>(), true, 0, ix->data.p, ix->stride))) return rc;
         if (declined &&      // too many matches to record one by one (redundant queries against a redundant database): fixed-cost compare kernel
             (rc = hamming_qxc_strided(c, ix->ikind, ix->prm.m, qrows + q0 * ix->stride, nb, ix->stride, ix->data.p, n, ix->stride, nullptr, nullptr, out16 + q0 * ld, ld))) return rc;
     }
@@ -2122,7 +2122,7 @@ int gs_index_search_stats(gs_index *ix, uint64_t out[8], int reset)
         GS_HIP_CHECK(hipMemcpyAsync(h, ix->stats.p, 128, hipMemcpyDeviceToHost, c->stream));
         if (reset) GS_HIP_CHECK(hipMemsetAsync(ix->stats.p, 0, 128, c->stream));
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[5] = h[5]; out[6] = h[6];
+        out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[5] = h[5]; out[6] = h[6]; out[7] = h[7];
         if (getenv("GS_TRAV_PHASES") && h[12])      // shader-clock cycles of workgroup 0 per query: tau scan, phase 1, phase 2 (list + Bloom build, drain, T merge)
             fprintf(stderr, "[GS_TRAV_PHASES] workgroup 0, %llu queries: cycles per query tau scan %.0f, phase 1 %.0f, phase 2 %.0f, output %.0f\n", h[12],
                     (double)h[8] / h[12], (double)h[9] / h[12], (double)h[10] / h[12], (double)h[11] / h[12]),
@@ -2254,6 +2254,28 @@ static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_
     GS_HIP_CHECK(hipMemcpyAsync(dist, ddist.p, 4 * nq * knbn, hipMemcpyDeviceToHost, c->stream));
     if (count) GS_HIP_CHECK(hipMemcpyAsync(count, dcount.p, 4 * nq, hipMemcpyDeviceToHost, c->stream));
     if (evals) GS_HIP_CHECK(hipMemcpyAsync(evals, devals.p, 8 * nq, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_index_count_matrix(gs_index *ix, const void *queries, uint64_t nq, uint16_t *counts_out)
+{
+    GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
+    if (nq == 0) return GS_OK;
+    GS_REQUIRE(queries && counts_out, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(ix->n > 0, GS_ERR_STATE, "count matrix of an empty index");
+    GS_REQUIRE(ix->prm.m <= 65535, GS_ERR_UNSUPPORTED, "16-bit counts need m <= 65535");
+    gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    gs::PoolBuf dq(c, 32);
+    int rc;
+    if ((rc = dq.alloc(ix->stride * nq))) return rc;
+    if ((rc = gs::upload_user_rows(ix, dq.p, queries, nq, hipMemcpyHostToDevice))) return rc;
+    const uint64_t ld = gs::round_up(ix->n, 8);
+    if (ix->mat.bytes < (size_t)2 * nq * ld && (rc = gs::alloc_or_evict(ix, ix->mat, (size_t)2 * nq * ld))) return rc;
+    if ((rc = gs::dense_counts(ix, dq.as<uint8_t>(), nq, ix->n, ix->mat.as<uint16_t>(), ld))) return rc;
+    GS_HIP_CHECK(hipMemcpy2DAsync(counts_out, 2 * ix->n, ix->mat.p, 2 * ld, 2 * ix->n, nq, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GS_OK;
 }

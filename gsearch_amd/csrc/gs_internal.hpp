@@ -54,6 +54,7 @@ struct gs_ctx {
     hipEvent_t sync_ev = nullptr;      // blocking-sync event of gs::stream_wait (a sleeping wait: the file pipelines leave the cores to the decoders)
     gs_ctx *child = nullptr;           // second context (own stream, pools) on the same device: gs_sketch_files runs its host-decoded files on it
     void *pinned_pool = nullptr;       // gs::PinnedPool: grow-only pinned host staging buffers of gs_sketch_files (hipHostMalloc costs ~0.3 s per GB)
+    uint32_t last_sketch[4] = {0, 0, 0, 0};   // gs_ctx_last_sketch_info: {filtered emitter, slot table in LDS, workgroups per genome, launches} of the last slot-min sketch call
     // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
     // and parallel_search through &self from many threads (dnasketch.rs:252,305,322): every entry point that touches the stream or the
     // pool takes this lock, so concurrent calls on one context are safe (they queue on the GPU anyway); recursive because entry
@@ -108,11 +109,17 @@ int narrow_u16_rows(gs_ctx *c, const void *src_dev, uint64_t src_stride_bytes, u
 
 struct DevBuf;
 // match-join form of the dense count matrix (gs_join.hip): counts of nq strided query rows against the first n nodes of the
-// column-major database copy `cols` ([m][colcap]); out16[q * ld + e] = mismatch count. scratch: 5 reusable buffers. init = false: the
+// column-major database copy `cols` ([m][colcap]); out16[q * ld + e] = mismatch count. scratch: JOIN_SCRATCH reusable buffers. init = false: the
 // counters already hold m (a sub-range of columns of rows initialised by an earlier call: the row-spanning memset would wipe their neighbours); col0: node e of the range is column col0 + e of the matrix.
 uint64_t match_join_max_queries();
+enum { JOIN_SCRATCH = 16 };
+// rows / rstride (optional): the row-major signatures of the same nodes - with them a request batch's heavy (query, node) blocks are found and
+// written by the compare tile kernel instead of being counted match by match (gs_join.hip "heavy blocks")
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
-                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined = nullptr, unsigned long long *stats = nullptr, bool init = true, uint64_t col0 = 0);
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined = nullptr, unsigned long long *stats = nullptr, bool init = true, uint64_t col0 = 0,
+                      const void *rows = nullptr, uint64_t rstride = 0);
+int hamming_blocks(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t strideQ_bytes, const void *C, uint64_t strideC_bytes, const void *items_dev,
+                   uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out);
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);
 
 inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }

@@ -9,6 +9,7 @@
 // HBM traffic: the database once per BATCH (21.6 GB for 300 k x 18000 f32) instead of once per 128 queries; arithmetic: ~1.5 LDS
 // probes per (slot, node) instead of nq compares. Output is bit-identical to the tile kernel.
 #include <algorithm>
+#include <vector>
 #include "gs_internal.hpp"
 
 namespace gs {
@@ -72,6 +73,7 @@ constexpr int JU = 4;             // database values in flight per lane
 constexpr int JP_MAX_LOG2 = 13;   // largest table: 8192 entries (64 KB for 4-byte keys, 96 KB for 8-byte keys)
 constexpr int JQ_MAX = 3276;      // queries per join call: load factor <= 0.4
 constexpr int JB_LOG2 = 16;       // bits of the pre-filter bitmap (8 KB)
+constexpr uint32_t HTILE = 128;   // edge of the compare tile kernel's tiles (gs_hamming.hip HT)
 
 __device__ __forceinline__ uint32_t join_hash(uint32_t k) { return k * 0x9E3779B1u; }
 __device__ __forceinline__ uint32_t join_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }
@@ -115,25 +117,54 @@ __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t
 // queries of an insert batch a table is 1024 entries and a slot's fixed work (three barriers, clearing 3 K words, 256 inserts on a quarter of
 // the lanes) weighs on its 8192 probes; four slots per round: -10.5 % of the join time of a 300 k build (tools/build_trace.sh). SR = 1 for
 // request batches, whose 72 KB tables fill the LDS.
-template <int KIND, typename T, int SR>
+// CL (request batches, DESIGN.md 3.8 "heavy blocks"): queries and nodes carry the id of the heavy block ("cluster") they belong to, if any.
+//   * the tag word of a table entry is query + 1 (12 bits) | JTAG_MULTI | cluster << 13;
+//   * a hit of a node on an entry of ITS OWN cluster is dropped: the counters of a cluster's (query, node) pairs are written afterwards by
+//     the compare tile kernel over the block (hamming_blocks) - thousands of matches per pair that would otherwise be atomics;
+//   * 4-byte keys: key and tag word share one 8-byte LDS entry, so an insert sees complete entries and a query whose cluster already holds
+//     this key in this slot is NOT inserted again (the entry gets JTAG_MULTI): 83 isolates of one species put one entry where they agree
+//     instead of a run of 83 every probe has to walk. A hit of a FOREIGN node on a MULTI entry (a chance match) stands for a match with
+//     every member that holds the key: the wavefront expands it together, lanes over the cluster's members in the cluster-sorted key copy
+//     `qs` (cl_lo / qlist: member ranges and query numbers), one atomic per member found. (A first version queued these hits for a kernel
+//     of its own: 1.4e7 same-address queue atomics per batch and 3e8 count atomics no longer hidden under the probes - 35 % slower.)
+constexpr uint32_t JTAG_MASK = 0xFFFu, JTAG_MULTI = 0x1000u;
+constexpr int JTAG_CL_SHIFT = 13;
+constexpr uint32_t JCL_MAX = 2047;      // cluster ids 1..2047
+
+template <int KIND, typename T, int SR, bool CL>
 __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
-                                                    uint32_t m, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
-                                                    unsigned long long *__restrict__ stats, int chunk_major, uint64_t col0)
+                                                    uint32_t slot_lo, uint32_t slot_hi, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
+                                                    unsigned long long *__restrict__ stats, int chunk_major, uint64_t col0, const uint16_t *__restrict__ qcl,
+                                                    const uint16_t *__restrict__ nodelab, const T *__restrict__ qs, uint32_t nh, const uint32_t *__restrict__ cl_lo,
+                                                    const uint32_t *__restrict__ qlist)
 {
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
+    static_assert(!CL || SR == 1, "clusters: request batches only");
+    constexpr bool DEDUP = CL && sizeof(T) == 4;                 // key + tag word in one 8-byte entry
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
     constexpr uint32_t BMW = (1u << JB_LOG2) / 32;                // bitmap words per slot
-    uint32_t *tag = (uint32_t *)s_raw;                            // [SR][P]
-    uint32_t *bm = (uint32_t *)(s_raw + 4 * (size_t)P * SR);      // [SR][BMW]
+    uint32_t *tag = (uint32_t *)s_raw;                            // [SR][P]            (DEDUP: ent[P] of {key, tag word} first, then the bitmap)
+    uint32_t *bm = DEDUP ? (uint32_t *)(s_raw + 8 * (size_t)P) : (uint32_t *)(s_raw + 4 * (size_t)P * SR);      // [SR][BMW]
     T *key = (T *)(s_raw + (4 * (size_t)P + (size_t)BMW * 4) * SR);   // [SR][P]
+    unsigned long long *ent = (unsigned long long *)s_raw;
     // chunk_major: consecutive workgroups sweep the slot blocks of ONE node chunk, so the counters being updated at any time are
     // those of a few chunks (a window of the count matrix that fits the 256 MB Infinity Cache) instead of all of them
     const uint32_t bchunk = chunk_major ? blockIdx.y : blockIdx.x, bslot = chunk_major ? blockIdx.x : blockIdx.y;
     const uint64_t e0 = (uint64_t)bchunk * (JT * JN) + threadIdx.x;      // the lane's nodes: e0 + i * JT, i < JN
-    const uint32_t s0 = bslot * slots_per_wg, s1 = s0 + slots_per_wg < m ? s0 + slots_per_wg : m;
+    const uint32_t s0 = slot_lo + bslot * slots_per_wg, s1 = s0 + slots_per_wg < slot_hi ? s0 + slots_per_wg : slot_hi;
+    uint32_t hotbits = 0, hotlab = 0;                             // CL: bit i = the lane's node i belongs to a cluster; label of the first such node | i << 16
+    if (CL) {
+#pragma unroll
+        for (int i = 0; i < JN; i++) {
+            const uint64_t e = e0 + (uint64_t)i * JT;
+            const uint32_t l = e < n ? nodelab[e] : 0u;
+            if (l) { if (!hotbits) hotlab = l | ((uint32_t)i << 16); hotbits |= 1u << i; }
+        }
+    }
     uint32_t sticky[JN];
     uint32_t natom = 0;                                           // memory-side atomics this lane sends (work counter for the bench's roofline)
+    uint32_t nexp = 0;                                            // CL: chance matches on shared entries this wavefront expanded
 #pragma unroll
     for (int i = 0; i < JN; i++) sticky[i] = 0;
     T vn[JU];
@@ -142,19 +173,35 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     for (uint32_t sr = s0; sr < s1; sr += SR) {
         const uint32_t nr = s1 - sr < (uint32_t)SR ? s1 - sr : (uint32_t)SR;       // slots of this round
         join_lds_barrier();                                       // the previous round's probes are done
-        for (uint32_t i = threadIdx.x; i < P * SR; i += JT) tag[i] = 0;
+        if (DEDUP) { for (uint32_t i = threadIdx.x; i < P; i += JT) ent[i] = 0ull; }
+        else for (uint32_t i = threadIdx.x; i < P * SR; i += JT) tag[i] = 0;
         for (uint32_t i = threadIdx.x; i < BMW * SR; i += JT) bm[i] = 0;
         join_lds_barrier();
         for (uint32_t i = threadIdx.x; i < nq * nr; i += JT) {
             const uint32_t r = SR == 1 ? 0 : i / nq, q = SR == 1 ? i : i - r * nq;
             T k = qkey[(uint64_t)(sr + r) * nq + q];
+            const uint32_t tw = CL ? (q + 1) | ((uint32_t)qcl[q] << JTAG_CL_SHIFT) : q + 1;
             if (never_equal<KIND, T>(k)) continue;
             k = canon<KIND, T>(k);
             const uint32_t hq = join_hash(k);
             atomicOr(&bm[r * BMW + (hq >> (32 - JB_LOG2 + 5))], 1u << ((hq >> (32 - JB_LOG2)) & 31));
             uint32_t h = hq >> sh;
-            while (atomicCAS(&tag[r * P + h], 0u, q + 1) != 0u) h = (h + 1) & mask;
-            key[r * P + h] = k;
+            if (DEDUP) {
+                const unsigned long long nw = ((unsigned long long)tw << 32) | (uint32_t)k;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&ent[h], 0ull, nw);
+                    if (old == 0ull) break;
+                    // same key already entered by a query of the same cluster: that entry stands for this query too
+                    if ((tw >> JTAG_CL_SHIFT) && (uint32_t)old == (uint32_t)k && ((uint32_t)(old >> 32) >> JTAG_CL_SHIFT) == (tw >> JTAG_CL_SHIFT)) {
+                        atomicOr((uint32_t *)&ent[h] + 1, JTAG_MULTI);
+                        break;
+                    }
+                    h = (h + 1) & mask;
+                }
+            } else {
+                while (atomicCAS(&tag[r * P + h], 0u, tw) != 0u) h = (h + 1) & mask;
+                key[r * P + h] = k;
+            }
         }
         join_lds_barrier();
 #pragma unroll 1
@@ -187,6 +234,61 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                     vn[u] = (e < n && (!wrap || s + 1 < s1)) ? src[e] : (T)0;
                 }
                 uint32_t hh = 0, uu = 0; T vv = 0; bool have = false;
+                if constexpr (DEDUP) {
+                    // the same state machine, but the wavefront stays together until its last lane is done, so that all 64 lanes can expand
+                    // a chance match on a shared entry
+                    uint32_t mitem = 0;                              // (node index + 1) << 16 | cluster of this lane's pending expansion
+                    for (;;) {
+                        if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
+                        if (!__any(have)) break;
+                        if (have) {
+                            const unsigned long long en = ent[hh];
+                            const uint32_t t = (uint32_t)(en >> 32);
+                            if (t == 0u) have = false;
+                            else {
+                                if ((uint32_t)en == (uint32_t)vv) {
+                                    const uint32_t ni = it * JU + uu;
+                                    const uint64_t el = e0 + (uint64_t)ni * JT;                  // node within this column range
+                                    bool count_it = true;
+                                    if (t >> 12) {                                               // entry of a cluster
+                                        const uint32_t cl = t >> JTAG_CL_SHIFT;
+                                        bool own = false;
+                                        if ((hotbits >> ni) & 1u) own = ((hotlab >> 16) == ni ? (hotlab & 0xFFFFu) : (uint32_t)nodelab[el]) == cl;
+                                        if (own) count_it = false;                               // the block compare writes this pair's counter
+                                        else if (t & JTAG_MULTI) { mitem = ((ni + 1) << 16) | cl; count_it = false; }
+                                    }
+                                    if (count_it) {
+                                        uint32_t st = GS_SEL4((sticky + it * JU), uu);
+                                        GS_JOIN_HIT(st, t & JTAG_MASK, col0 + el);
+#pragma unroll
+                                        for (int u = 0; u < JU; u++) if (uu == (uint32_t)u) sticky[it * JU + u] = st;
+                                    }
+                                }
+                                hh = (hh + 1) & mask;
+                            }
+                        }
+                        unsigned long long pm = __ballot(mitem != 0u);
+                        while (pm) {
+                            const int src = __ffsll((long long)pm) - 1;
+                            pm &= pm - 1;
+                            nexp++;
+                            const uint32_t mi = __builtin_amdgcn_readlane(mitem, src);
+                            const uint32_t vsrc = __builtin_amdgcn_readlane((uint32_t)vv, src);
+                            const uint32_t cl = mi & 0xFFFFu, lane = threadIdx.x & 63;
+                            const uint64_t e = col0 + (e0 - lane + (uint32_t)src) + (uint64_t)((mi >> 16) - 1) * JT;
+                            const uint32_t lo = cl_lo[cl], hi = cl_lo[cl + 1];
+                            for (uint32_t pos = lo + lane; pos < hi; pos += 64) {
+                                const T k2 = qs[(uint64_t)s * nh + pos];
+                                if (!never_equal<KIND, T>(k2) && (uint32_t)canon<KIND, T>(k2) == vsrc) {
+                                    const uint64_t idx = (uint64_t)qlist[pos] * ld + e;
+                                    atomicSub(&mm32[idx >> 1], 1u << ((idx & 1) * 16));
+                                    natom++;
+                                }
+                            }
+                        }
+                        mitem = 0;
+                    }
+                } else {
                 for (;;) {
                     if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
                     if (!have) break;
@@ -194,13 +296,21 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                     const T k = key[tb + hh];
                     if (t == 0u) { have = false; continue; }
                     if (k == vv) {
-                        const uint64_t e = col0 + e0 + (uint64_t)(it * JU + uu) * JT;       // column of the count matrix (col0: the node range starts there)
-                        uint32_t st = GS_SEL4((sticky + it * JU), uu);
-                        GS_JOIN_HIT(st, t, e);
+                        const uint32_t ni = it * JU + uu;
+                        const uint64_t el = e0 + (uint64_t)ni * JT;                          // node within this column range
+                        bool count_it = true;
+                        if (CL && (t >> 12) && ((hotbits >> ni) & 1u))                       // (8-byte keys: no shared entries, only the own-cluster rule)
+                            count_it = ((hotlab >> 16) == ni ? (hotlab & 0xFFFFu) : (uint32_t)nodelab[el]) != (t >> JTAG_CL_SHIFT);
+                        if (count_it) {
+                            const uint64_t e = col0 + el;                                    // column of the count matrix (col0: the node range starts there)
+                            uint32_t st = GS_SEL4((sticky + it * JU), uu);
+                            GS_JOIN_HIT(st, t & JTAG_MASK, e);
 #pragma unroll
-                        for (int u = 0; u < JU; u++) if (uu == (uint32_t)u) sticky[it * JU + u] = st;
+                            for (int u = 0; u < JU; u++) if (uu == (uint32_t)u) sticky[it * JU + u] = st;
+                        }
                     }
                     hh = (hh + 1) & mask;
+                }
                 }
             }
         }
@@ -211,6 +321,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) natom += __shfl_down(natom, o);
         if ((threadIdx.x & 63) == 0 && natom) atomicAdd(stats, (unsigned long long)natom);
+        if (CL && (threadIdx.x & 63) == 0 && nexp) atomicAdd(stats + 7, (unsigned long long)nexp);
     }
 }
 // Match-density probe: what would the join cost on THIS batch? Its work is proportional to the number of matches it has to
@@ -269,9 +380,183 @@ __global__ __launch_bounds__(JT) void k_match_sample(const T *__restrict__ qkey,
     if ((threadIdx.x & 63) == 0 && hits) { atomicAdd(&out[0], (unsigned long long)hits); atomicAdd(&out[1], (unsigned long long)reps); }
 }
 
+// ---- heavy blocks ("clusters") of a request batch ---------------------------------------------------------------------------------
+// gsearch's stated databases (GTDB / NCBI prokaryotes, /root/reference/README.md:134) hold thousands of near-identical genomes per
+// species, and a request often is many isolates of a few species: every such query matches every database genome of its species in
+// thousands of slots. Recording those matches one atomic at a time (and walking, per probe, the run of equal keys 83 isolates leave in
+// the table) is what made such batches 4x slower than unrelated ones. Instead:
+//   phase 0  the join proper over the first JS0 slots only;
+//   scan     the (query, node) pairs whose counter already lost >= JHEAVY matches are the heavy pairs (chance: < 1e-6 per pair);
+//   labels   connected components of the heavy pairs by min-label propagation (a few rounds; ANY labelling is correct, see below);
+//   host     components with >= 2 queries become clusters: cluster id per query / per node, member lists, 128 x 128 tiles;
+//   main     the join over the remaining slots with CL = true (own-cluster hits dropped, equal keys of a cluster entered once, chance
+//            matches on such shared entries expanded over the cluster's members by the wavefront);
+//   blocks   the compare tile kernel over every cluster's queries x nodes block WRITES those counters (all m slots).
+// Correctness does not depend on how the labels were found: a pair is either counted match by match (phase 0 + main) or its
+// counter is overwritten by the exact compare - "own cluster" in the main pass and "member of the block" in the last are the same test.
+constexpr uint32_t JS0 = 48, JHEAVY = 3;
+constexpr uint64_t JPAIR_CAP = (uint64_t)4 << 20;
+constexpr uint32_t JTILE_CAP = 24576;
+
+// tiles of 8 consecutive counters per lane x 256 lanes; a workgroup walks many tiles, stages the heavy pairs it finds in LDS and sends them to
+// the list in blocks (a first version paid one same-address global atomic per wavefront and tile: 1.1e6 of them, 10 ms per batch)
+constexpr uint32_t HS_STAGE = 3072;
+__global__ __launch_bounds__(256) void k_heavy_scan(const uint16_t *__restrict__ mat, uint64_t ld, uint32_t nq, uint64_t n, uint32_t m, uint2 *__restrict__ pairs,
+                                                    unsigned long long *__restrict__ ctr /* [0] pairs, [1] matches so far */, uint64_t cap)
+{
+    __shared__ uint2 stage[HS_STAGE];
+    __shared__ uint32_t sn;
+    __shared__ unsigned long long sbase;
+    if (threadIdx.x == 0) sn = 0;
+    __syncthreads();
+    const uint64_t tiles_per_row = (n + 2047) / 2048, ntiles = tiles_per_row * nq;
+    uint32_t tot = 0;
+    auto flush = [&]() {                       // all lanes; sn pairs -> the global list
+        __syncthreads();
+        const uint32_t cnt = sn;
+        if (cnt) {
+            if (threadIdx.x == 0) sbase = atomicAdd(&ctr[0], (unsigned long long)cnt);
+            __syncthreads();
+            const unsigned long long base = sbase;
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) if (base + i < cap) pairs[base + i] = stage[i];
+            __syncthreads();
+            if (threadIdx.x == 0) sn = 0;
+        }
+        __syncthreads();
+    };
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t q = (uint32_t)(t / tiles_per_row);
+        const uint64_t e8 = (t - (uint64_t)q * tiles_per_row) * 2048 + (uint64_t)threadIdx.x * 8;
+        if (e8 < n) {
+            const uint4 w = *(const uint4 *)(mat + (uint64_t)q * ld + e8);        // ld is a multiple of 8 and the padding columns hold m
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t c = (ww[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+                const uint32_t def = (e8 + i < n) ? m - c : 0u;
+                tot += def;
+                if (def >= JHEAVY) stage[atomicAdd(&sn, 1u)] = make_uint2((uint32_t)(e8 + i), q | (def << 16));
+            }
+        }
+        __syncthreads();
+        if (sn >= HS_STAGE - 2048) flush();                                       // (uniform: sn is read after the barrier)
+    }
+    flush();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&ctr[1], (unsigned long long)tot);
+}
+__global__ void k_label_init(uint32_t *__restrict__ labq, uint32_t nq, uint32_t *__restrict__ labe, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) labq[i] = (uint32_t)i;
+    if (i < n) labe[i] = 0xFFFFFFFFu;
+}
+__global__ void k_label_prop(const uint2 *__restrict__ pairs, const unsigned long long *__restrict__ ctr, uint64_t cap, uint32_t *__restrict__ labq, uint32_t *__restrict__ labe)
+{
+    const uint64_t np = ctr[0] < cap ? ctr[0] : cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 p = pairs[i];
+        const uint32_t q = p.y & 0xFFFFu, a = labq[q], b = labe[p.x], l = a < b ? a : b;
+        if (l < a) atomicMin(&labq[q], l);
+        if (l < b) atomicMin(&labe[p.x], l);
+    }
+}
+// cluster-sorted copy of the keys of the clustered queries: qs[s * nh + pos] = row qlist[pos], slot s
+template <typename T>
+__global__ __launch_bounds__(256) void k_query_cols_list(const uint8_t *__restrict__ rows, uint64_t stride, const uint32_t *__restrict__ qlist, uint32_t nh, uint32_t m, T *__restrict__ qs)
+{
+    __shared__ T tile[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint64_t r0 = (uint64_t)blockIdx.x * 32, s0 = (uint64_t)blockIdx.y * 32;
+    for (uint32_t j = ty; j < 32; j += 8) {
+        const uint64_t r = r0 + j, s = s0 + tx;
+        tile[j][tx] = (r < nh && s < m) ? ((const T *)(rows + (uint64_t)qlist[r] * stride))[s] : (T)0;
+    }
+    __syncthreads();
+    for (uint32_t j = ty; j < 32; j += 8) {
+        const uint64_t s = s0 + j, r = r0 + tx;
+        if (s < m && r < nh) qs[s * nh + r] = tile[tx][j];
+    }
+}
+struct JoinGeom { uint32_t chunks, log2p; size_t lds1; };
+
+template <int KIND, typename T, bool CL>
+static int join_launch(gs_ctx *c, const JoinGeom &g, const T *qkey, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint32_t slot_lo, uint32_t slot_hi,
+                       uint16_t *out16, uint64_t ld, unsigned long long *stats, uint64_t col0, bool few_blocks, const uint16_t *qcl, const uint16_t *nodelab, const T *qs,
+                       uint32_t nh, const uint32_t *cl_lo, const uint32_t *qlist)
+{
+    // one workgroup = JT * JN nodes x a block of slots; blocks sized so that the grid is about eight rounds of 2 workgroups per CU
+    // (one round leaves the slowest workgroup's tail exposed: 145 -> 125 ms per 10 k-query request), at least 32 slots each
+    const uint32_t ms = slot_hi - slot_lo, chunks = g.chunks;
+    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((16 * c->n_cu) / chunks, std::max<uint32_t>(ms / 32, (2 * c->n_cu) / chunks)));
+    if (few_blocks) blocks = std::max<uint32_t>(1, std::min<uint32_t>(ms / 4, (2 * c->n_cu + chunks - 1) / chunks));        // phase 0: one round of short blocks
+    if (getenv("GS_JOIN_BLOCKS") && !few_blocks) blocks = (uint32_t)atoi(getenv("GS_JOIN_BLOCKS"));
+    blocks = std::min<uint32_t>(std::max<uint32_t>(blocks, 1), ms);
+    const uint32_t slots_per_wg = (ms + blocks - 1) / blocks;
+    const int chunk_major = getenv("GS_JOIN_CHUNK_MAJOR") ? atoi(getenv("GS_JOIN_CHUNK_MAJOR")) : 0;
+    const uint32_t nblk = (ms + slots_per_wg - 1) / slots_per_wg;
+    dim3 jg(chunk_major ? nblk : chunks, chunk_major ? chunks : nblk);
+    // small tables (an insert batch): several slots per barrier round while two workgroups still fit a CU
+    int sr = 1;
+    if (!CL) {
+        if (4 * g.lds1 <= 80 * 1024 && slots_per_wg >= 8) sr = 4; else if (2 * g.lds1 <= 80 * 1024 && slots_per_wg >= 4) sr = 2;
+        if (getenv("GS_JOIN_SLOTS_PER_ROUND")) { const int e = atoi(getenv("GS_JOIN_SLOTS_PER_ROUND")); if (e == 1 || (e == 2 && 2 * g.lds1 <= 80 * 1024) || (e == 4 && 4 * g.lds1 <= 80 * 1024)) sr = e; }
+    }
+    const size_t lds = g.lds1 * sr;
+    ProfScope ps(c, FAM_HAMMING);
+#define GS_JOIN_GO(KERN)                                                                                                                              \
+    do {                                                                                                                                              \
+        auto kern = KERN;                                                                                                                             \
+        if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, qkey, nq, g.log2p, (const T *)cols, colcap, n, slot_lo, slot_hi, slots_per_wg, (uint32_t *)out16, ld, \
+                           stats, chunk_major, col0, qcl, nodelab, qs, nh, cl_lo, qlist);                                                             \
+    } while (0)
+    if (CL) GS_JOIN_GO((k_match_join<KIND, T, 1, CL>));
+    else if (sr == 4) GS_JOIN_GO((k_match_join<KIND, T, 4, false>));
+    else if (sr == 2) GS_JOIN_GO((k_match_join<KIND, T, 2, false>));
+    else GS_JOIN_GO((k_match_join<KIND, T, 1, false>));
+#undef GS_JOIN_GO
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+// the sampled decision of the unclustered join: 1 = hand the batch to the compare tile kernel
+template <int KIND, typename T>
+static int join_sample_declines(gs_ctx *c, const JoinGeom &g, uint32_t m, const T *qkey, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, DevBuf *scratch, int *decline_out)
+{
+    // sampled match density -> estimated join time (column stream + one memory-side atomic per match the accumulator does not
+    // absorb, 1.6e10/s: profiles/r01_match_join_pmc.txt) against the fixed cost of the compare tile kernel
+    int rc;
+    const uint32_t nsamp = 24;
+    DevBuf &cnt = scratch[1];
+    if ((rc = cnt.ensure(16))) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 16, c->stream));
+    const size_t lds_s = (sizeof(T) + 4) * ((size_t)1 << g.log2p);
+    auto ks = k_match_sample<KIND, T>;
+    if (lds_s > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    hipLaunchKernelGGL(ks, dim3(g.chunks, nsamp), dim3(JT), lds_s, c->stream, qkey, nq, g.log2p, (const T *)cols, colcap, n, m, nsamp, cnt.as<unsigned long long>());
+    GS_HIP_CHECK(hipGetLastError());
+    unsigned long long hr[2] = {0, 0};
+    GS_HIP_CHECK(hipMemcpyAsync(hr, cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const double scale = (double)m / (double)nsamp;
+    const double atomics = (double)(hr[0] - hr[1]) * scale + (double)hr[1] * scale / 64.0;       // absorbed runs still flush now and then
+    const double t_join = (double)n * m * sizeof(T) / 3.5e12 + atomics / 1.6e10 + (double)hr[0] * scale / 2.0e11;
+    const double t_tile = (double)((nq + 127) / 128 * 128) * (double)n * (double)m / (KIND == GS_KIND_U64 ? 1.4e13 : 1.6e13);   // 128-query tiles
+    const char *force = getenv("GS_JOIN_DECLINE");
+    const bool decline = force ? atoi(force) != 0 : t_join > t_tile;
+    if (getenv("GS_JOIN_VERBOSE"))
+        fprintf(stderr, "[GS_JOIN] nq=%u n=%llu sampled matches %llu repeats %llu -> est. join %.2f ms, tile %.2f ms: %s\n", nq, (unsigned long long)n, hr[0], hr[1],
+                t_join * 1e3, t_tile * 1e3, decline ? "tile" : "join");
+    *decline_out = decline ? 1 : 0;
+    return GS_OK;
+}
+
 template <int KIND, typename T>
 static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstride, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint16_t *out16,
-                     uint64_t ld, DevBuf *scratch /* [5] reusable */, int *declined, unsigned long long *stats, bool init, uint64_t col0)
+                     uint64_t ld, DevBuf *scratch /* [JOIN_SCRATCH] reusable */, int *declined, unsigned long long *stats, bool init, uint64_t col0,
+                     const void *rows, uint64_t rstride)
 {
     int rc;
     if (declined) *declined = 0;
@@ -284,57 +569,114 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     dim3 tg((nq + 31) / 32, (m + 31) / 32);
     hipLaunchKernelGGL((k_query_cols<KIND, T>), tg, dim3(256), 0, c->stream, qrows, qstride, nq, m, k0.as<T>());
     GS_HIP_CHECK(hipGetLastError());
-    uint32_t log2p = 6;
-    while (log2p < (uint32_t)JP_MAX_LOG2 && (double)(1u << log2p) * 0.4 < (double)nq) log2p++;
-    if (declined && m >= 64 && n >= 4096) {
-        // sampled match density -> estimated join time (column stream + one memory-side atomic per match the accumulator does not
-        // absorb, 1.6e10/s: profiles/r01_match_join_pmc.txt) against the fixed cost of the compare tile kernel
-        const uint32_t nsamp = 24;
-        DevBuf &cnt = scratch[1];
-        if ((rc = cnt.ensure(16))) return rc;
-        GS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 16, c->stream));
-        const uint32_t chunks_s = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
-        const size_t lds_s = (sizeof(T) + 4) * ((size_t)1 << log2p);
-        auto ks = k_match_sample<KIND, T>;
-        if (lds_s > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-        hipLaunchKernelGGL(ks, dim3(chunks_s, nsamp), dim3(JT), lds_s, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, nsamp, cnt.as<unsigned long long>());
-        GS_HIP_CHECK(hipGetLastError());
-        unsigned long long hr[2] = {0, 0};
-        GS_HIP_CHECK(hipMemcpyAsync(hr, cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
-        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        const double scale = (double)m / (double)nsamp;
-        const double atomics = (double)(hr[0] - hr[1]) * scale + (double)hr[1] * scale / 64.0;       // absorbed runs still flush now and then
-        const double t_join = (double)n * m * sizeof(T) / 3.5e12 + atomics / 1.6e10 + (double)hr[0] * scale / 2.0e11;
-        const double t_tile = (double)((nq + 127) / 128 * 128) * (double)n * (double)m / (KIND == GS_KIND_U64 ? 1.4e13 : 1.6e13);   // 128-query tiles
-        const char *force = getenv("GS_JOIN_DECLINE");
-        const bool decline = force ? atoi(force) != 0 : t_join > t_tile;
-        if (getenv("GS_JOIN_VERBOSE"))
-            fprintf(stderr, "[GS_JOIN] nq=%u n=%llu sampled matches %llu repeats %llu -> est. join %.2f ms, tile %.2f ms: %s\n", nq, (unsigned long long)n, hr[0], hr[1],
-                    t_join * 1e3, t_tile * 1e3, decline ? "tile" : "join");
-        if (decline) { *declined = 1; return GS_OK; }
+    JoinGeom g;
+    g.log2p = 6;
+    while (g.log2p < (uint32_t)JP_MAX_LOG2 && (double)(1u << g.log2p) * 0.4 < (double)nq) g.log2p++;
+    g.chunks = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
+    g.lds1 = (sizeof(T) + 4) * ((size_t)1 << g.log2p) + ((size_t)1 << JB_LOG2) / 8;
+    const bool may_decline = declined && m >= 64 && n >= 4096;
+    const char *ce = getenv("GS_JOIN_CLUSTER");
+    // heavy blocks: request batches (the insert path passes no `declined`) large enough for phase 0 to be a small part of the work
+    bool cluster = declined && init && col0 == 0 && rows && nq >= 256 && n >= 8192 && m >= 16 * JS0 && (ld % 8) == 0 && !(ce && !atoi(ce)) && !getenv("GS_JOIN_DECLINE");
+    if (ce && atoi(ce) == 2) cluster = declined && init && col0 == 0 && rows && m >= 2 * JS0 && (ld % 8) == 0;       // tests: small shapes too
+    if (!cluster) {
+        if (may_decline) {
+            int dec = 0;
+            if ((rc = join_sample_declines<KIND, T>(c, g, m, k0.as<T>(), nq, cols, colcap, n, scratch, &dec))) return rc;
+            if (dec) { *declined = 1; return GS_OK; }
+        }
+        return join_launch<KIND, T, false>(c, g, k0.as<T>(), nq, cols, colcap, n, 0, m, out16, ld, stats, col0, false, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
     }
-    // one workgroup = JT * JN nodes x a block of slots; blocks sized so that the grid is about eight rounds of 2 workgroups per CU
-    // (one round leaves the slowest workgroup's tail exposed: 145 -> 125 ms per 10 k-query request), at least 32 slots each
-    const uint32_t chunks = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
-    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((16 * c->n_cu) / chunks, std::max<uint32_t>(m / 32, (2 * c->n_cu) / chunks)));
-    if (getenv("GS_JOIN_BLOCKS")) blocks = (uint32_t)atoi(getenv("GS_JOIN_BLOCKS"));
-    blocks = std::min<uint32_t>(std::max<uint32_t>(blocks, 1), m);
-    const uint32_t slots_per_wg = (m + blocks - 1) / blocks;
-    const int chunk_major = getenv("GS_JOIN_CHUNK_MAJOR") ? atoi(getenv("GS_JOIN_CHUNK_MAJOR")) : 0;
-    const uint32_t nblk = (m + slots_per_wg - 1) / slots_per_wg;
-    dim3 jg(chunk_major ? nblk : chunks, chunk_major ? chunks : nblk);
-    const size_t lds1 = (sizeof(T) + 4) * ((size_t)1 << log2p) + ((size_t)1 << JB_LOG2) / 8;
-    // small tables (an insert batch): several slots per barrier round while two workgroups still fit a CU
-    int sr = 1;
-    if (4 * lds1 <= 80 * 1024 && slots_per_wg >= 8) sr = 4; else if (2 * lds1 <= 80 * 1024 && slots_per_wg >= 4) sr = 2;
-    if (getenv("GS_JOIN_SLOTS_PER_ROUND")) { const int e = atoi(getenv("GS_JOIN_SLOTS_PER_ROUND")); if (e == 1 || (e == 2 && 2 * lds1 <= 80 * 1024) || (e == 4 && 4 * lds1 <= 80 * 1024)) sr = e; }
-    const size_t lds = lds1 * sr;
+    const bool verbose = getenv("GS_JOIN_VERBOSE") != nullptr;
+    // ---- phase 0 + heavy pairs + labels
+    DevBuf &pairs = scratch[2], &ctr = scratch[3], &labq = scratch[4], &labe = scratch[5];
+    if ((rc = pairs.ensure(JPAIR_CAP * 8)) || (rc = ctr.ensure(64)) || (rc = labq.ensure(4 * (size_t)nq)) || (rc = labe.ensure(4 * (size_t)n))) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));
+    if ((rc = join_launch<KIND, T, false>(c, g, k0.as<T>(), nq, cols, colcap, n, 0, JS0, out16, ld, stats, 0, true, nullptr, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
+    hipLaunchKernelGGL(k_heavy_scan, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, ld, nq, n, m, pairs.as<uint2>(), ctr.as<unsigned long long>(), JPAIR_CAP);
+    hipLaunchKernelGGL(k_label_init, dim3((uint32_t)((std::max<uint64_t>(n, nq) + 255) / 256)), dim3(256), 0, c->stream, labq.as<uint32_t>(), nq, labe.as<uint32_t>(), n);
+    for (int it = 0; it < 6; it++)
+        hipLaunchKernelGGL(k_label_prop, dim3(c->n_cu * 4), dim3(256), 0, c->stream, pairs.as<uint2>(), ctr.as<unsigned long long>(), JPAIR_CAP, labq.as<uint32_t>(), labe.as<uint32_t>());
+    GS_HIP_CHECK(hipGetLastError());
+    // (pinned staging: a pageable destination makes the runtime bounce 1.2 MB through its own buffer, synchronously)
+    uint8_t *pin = (uint8_t *)pinned_pool(c)->ensure(34, 64 + 4 * ((size_t)nq + n) + 2 * ((size_t)nq + n) + 64);
+    GS_REQUIRE(pin, GS_ERR_HIP, "match-join: pinned staging buffer");
+    unsigned long long *hc = (unsigned long long *)pin;
+    uint32_t *hlq = (uint32_t *)(pin + 64), *hle = hlq + nq;
+    GS_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(hlq, labq.p, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(hle, labe.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const uint64_t npairs = hc[0];
+    // ---- clusters: labels with >= 2 queries and >= 1 node, largest blocks dropped while the tile budget is exceeded
+    std::vector<uint32_t> cq(nq, 0), ce_(nq, 0), cid(nq, 0);
+    uint32_t K = 0, ntiles = 0, nhq = 0;
+    uint64_t nhe = 0;
+    if (npairs <= JPAIR_CAP) {
+        for (uint32_t q = 0; q < nq; q++) if (hlq[q] < nq) cq[hlq[q]]++;
+        for (uint64_t e = 0; e < n; e++) if (hle[e] < nq) ce_[hle[e]]++;
+        std::vector<uint32_t> order;
+        for (uint32_t l = 0; l < nq; l++) if (cq[l] >= 2 && ce_[l] >= 1) order.push_back(l);
+        auto tiles_of = [&](uint32_t l) { return ((cq[l] + HTILE - 1) / HTILE) * ((ce_[l] + HTILE - 1) / HTILE); };
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { const uint32_t ta = tiles_of(a), tb = tiles_of(b); return ta != tb ? ta < tb : a < b; });
+        for (uint32_t l : order) {
+            if (K >= JCL_MAX || ntiles + tiles_of(l) > JTILE_CAP) break;                          // cheapest blocks first
+            cid[l] = ++K; ntiles += tiles_of(l); nhq += cq[l]; nhe += ce_[l];
+        }
+    }
+    // what the blocks save: the run-length accumulator of the plain join absorbs ONE query per node, every further query of a node's cluster
+    // costs an atomic per match (and a longer probe run). A batch of unrelated isolates (a few families with two or three queries) gains
+    // nothing from the cluster-aware kernel; a redundant one gains 4x.
+    uint64_t saved_pairs = 0;
+    for (uint32_t l = 0; l < nq; l++) if (cid[l]) saved_pairs += (uint64_t)(cq[l] - 1) * ce_[l];
+    const uint64_t min_saved = getenv("GS_JOIN_CLUSTER_MIN") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MIN")) : (ce && atoi(ce) == 2 ? 0 : (uint64_t)nq * 48);
+    if (verbose)
+        fprintf(stderr, "[GS_JOIN] nq=%u n=%llu heavy pairs %llu (matches in the first %u slots %llu): %u clusters, %u queries x %llu nodes in %u tiles, %llu pairs off the atomics%s\n", nq,
+                (unsigned long long)n, (unsigned long long)npairs, JS0, hc[1], K, nhq, (unsigned long long)nhe, ntiles, (unsigned long long)saved_pairs,
+                K && saved_pairs < min_saved ? " - not worth the cluster-aware pass" : "");
+    if (K && saved_pairs < min_saved) K = 0;
+    if (K == 0) {
+        // nothing to cluster (or too much: pair list overflow): the plain join over the remaining slots - unless the matches of phase 0, scaled to
+        // all slots as if every one cost an atomic, say the tile kernel may be cheaper: then the sampled estimate (which knows about runs) decides
+        const double t_tile = (double)((nq + 127) / 128 * 128) * (double)n * (double)m / (KIND == GS_KIND_U64 ? 1.4e13 : 1.6e13);
+        if (may_decline && (npairs > JPAIR_CAP || (double)hc[1] * ((double)m / JS0) / 1.6e10 > 0.5 * t_tile)) {
+            int dec = 0;
+            if ((rc = join_sample_declines<KIND, T>(c, g, m, k0.as<T>(), nq, cols, colcap, n, scratch, &dec))) return rc;
+            if (dec) { *declined = 1; return GS_OK; }
+        }
+        return join_launch<KIND, T, false>(c, g, k0.as<T>(), nq, cols, colcap, n, JS0, m, out16, ld, stats, 0, false, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+    }
+    // member lists in cluster order, tiles, per-query / per-node cluster ids
+    std::vector<uint32_t> cl_lo(K + 2, 0), ce_lo(K + 2, 0);
+    for (uint32_t l = 0; l < nq; l++) if (cid[l]) { cl_lo[cid[l] + 1] = cq[l]; ce_lo[cid[l] + 1] = ce_[l]; }
+    for (uint32_t k = 1; k <= K + 1; k++) { cl_lo[k] += cl_lo[k - 1]; ce_lo[k] += ce_lo[k - 1]; }
+    std::vector<uint32_t> qlist(nhq), elist(nhe), fq(cl_lo.begin(), cl_lo.end()), fe(ce_lo.begin(), ce_lo.end());
+    uint16_t *hqcl = (uint16_t *)(hle + n), *hnl = hqcl + nq;          // (pinned, behind the labels)
+    for (uint32_t q = 0; q < nq; q++) { const uint32_t l = hlq[q]; hqcl[q] = 0; if (l < nq && cid[l]) { hqcl[q] = (uint16_t)cid[l]; qlist[fq[cid[l]]++] = q; } }
+    for (uint64_t e = 0; e < n; e++) { const uint32_t l = hle[e]; hnl[e] = 0; if (l < nq && cid[l]) { hnl[e] = (uint16_t)cid[l]; elist[fe[cid[l]]++] = (uint32_t)e; } }
+    std::vector<uint4> tiles;
+    tiles.reserve(ntiles);
+    for (uint32_t k = 1; k <= K; k++)
+        for (uint32_t a = cl_lo[k]; a < cl_lo[k + 1]; a += HTILE)
+            for (uint32_t b = ce_lo[k]; b < ce_lo[k + 1]; b += HTILE)
+                tiles.push_back(make_uint4(a, std::min<uint32_t>(HTILE, cl_lo[k + 1] - a), b, std::min<uint32_t>(HTILE, ce_lo[k + 1] - b)));
+    DevBuf &dqcl = scratch[6], &dnl = scratch[7], &dql = scratch[8], &del = scratch[9], &dtl = scratch[10], &dqs = scratch[11], &dcl = scratch[13];
+    if ((rc = dqcl.ensure(2 * (size_t)nq)) || (rc = dnl.ensure(2 * (size_t)n)) || (rc = dql.ensure(4 * (size_t)nhq)) || (rc = del.ensure(4 * (size_t)nhe)) ||
+        (rc = dtl.ensure(16 * tiles.size())) || (rc = dqs.ensure(sizeof(T) * (size_t)m * nhq)) || (rc = dcl.ensure(4 * (size_t)(K + 2)))) return rc;
+    GS_HIP_CHECK(hipMemcpyAsync(dqcl.p, hqcl, 2 * (size_t)nq, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dnl.p, hnl, 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dql.p, qlist.data(), 4 * (size_t)nhq, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(del.p, elist.data(), 4 * (size_t)nhe, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dtl.p, tiles.data(), 16 * tiles.size(), hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dcl.p, cl_lo.data(), 4 * (size_t)(K + 2), hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));                  // (the host vectors above are pageable: the copies must be done before they go)
+    hipLaunchKernelGGL((k_query_cols_list<T>), dim3((nhq + 31) / 32, (m + 31) / 32), dim3(256), 0, c->stream, qrows, qstride, dql.as<uint32_t>(), nhq, m, dqs.as<T>());
+    GS_HIP_CHECK(hipGetLastError());
+    if ((rc = join_launch<KIND, T, true>(c, g, k0.as<T>(), nq, cols, colcap, n, JS0, m, out16, ld, stats, 0, false, dqcl.as<uint16_t>(), dnl.as<uint16_t>(), dqs.as<T>(), nhq,
+                                         dcl.as<uint32_t>(), dql.as<uint32_t>()))) return rc;
     {
         ProfScope ps(c, FAM_HAMMING);
-        auto kern = sr == 4 ? k_match_join<KIND, T, 4> : sr == 2 ? k_match_join<KIND, T, 2> : k_match_join<KIND, T, 1>;
-        if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, k0.as<T>(), nq, log2p, (const T *)cols, colcap, n, m, slots_per_wg, (uint32_t *)out16, ld, stats, chunk_major, col0);
-        GS_HIP_CHECK(hipGetLastError());
+        if ((rc = hamming_blocks(c, KIND, m, qrows, qstride, rows, rstride, dtl.p, (uint32_t)tiles.size(), dql.as<uint32_t>(), del.as<uint32_t>(), out16, ld))) return rc;
     }
     return GS_OK;
 }
@@ -344,13 +686,13 @@ uint64_t match_join_max_queries() { const char *e = getenv("GS_JOIN_MAXQ"); retu
 // `declined` (optional): set to 1 - and out16 is left at its initial value m - when the sampled match density says the compare tile kernel is the
 // cheaper producer for this batch (the caller then runs it)
 int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64_t qstride, uint64_t nq, const void *cols, uint64_t colcap, uint64_t n,
-                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined, unsigned long long *stats, bool init, uint64_t col0)
+                      uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined, unsigned long long *stats, bool init, uint64_t col0, const void *rows, uint64_t rstride)
 {
     GS_REQUIRE(nq >= 1 && nq <= 4094 && m <= 65535 && (ld % 2) == 0 && ((uintptr_t)out16 % 4) == 0, GS_ERR_INVALID, "match_join_counts: bad shape");
     GS_REQUIRE((uint64_t)m * nq < ((uint64_t)1 << 31), GS_ERR_INVALID, "match_join_counts: batch too large");
-    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0);
-    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0);
-    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0);
+    if (kind == GS_KIND_U64) return join_impl<GS_KIND_U64, uint64_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0, rows, rstride);
+    if (kind == GS_KIND_F32) return join_impl<GS_KIND_F32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0, rows, rstride);
+    return join_impl<GS_KIND_U32, uint32_t>(c, m, (const uint8_t *)qrows, qstride, (uint32_t)nq, cols, colcap, n, out16, ld, scratch, declined, stats, init, col0, rows, rstride);
 }
 
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first)

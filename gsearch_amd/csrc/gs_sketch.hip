@@ -576,9 +576,11 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
     // (and only for genomes long enough to warm the table up: >= 64 k-mers per slot; below that the survivor rate stays above 1/4)
     const bool filt = !aa && ge.use_lds && !(getenv("GS_SKETCH_FILTER") && !atoi(getenv("GS_SKETCH_FILTER"))) && avg_units * 32 >= (uint64_t)64 * m &&
                       (lds_f <= half_cu || (lds > half_cu && lds_f <= 160 * 1024 - 256));
+    c->last_sketch[0] = filt; c->last_sketch[1] = ge.use_lds; c->last_sketch[2] = ge.parts; c->last_sketch[3] = 0;
     for (uint64_t g0 = 0; g0 < n_genomes; g0 += 65535) {       // grid.y limit
         uint64_t ng = n_genomes - g0 < 65535 ? n_genomes - g0 : 65535;
         dim3 grid(ge.parts, (uint32_t)ng), block(SK_THREADS);
+        c->last_sketch[3]++;
         const uint64_t *gro = genome_rec_off + g0; const uint64_t *gu = gen_units + g0;
         T *tab = table + g0 * m;
         ProfScope ps(c, FAM_SKETCH);

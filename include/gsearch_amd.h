@@ -58,6 +58,11 @@ int   gs_ctx_timer_stop(gs_ctx *, float *elapsed_ms);
 int   gs_ctx_profile(gs_ctx *, int enable);
 int   gs_ctx_profile_read(gs_ctx *, int family, double *total_ms, uint64_t *launches, int reset);
 
+/* which form of the slot-min sketch kernel (optdens / revoptdens / super / super2 level 0) the LAST sketch call on this context launched:
+ * out[0] = 1 when the early-rejection ("filtered") emitter ran, out[1] = 1 when the slot table lived in LDS, out[2] = workgroups per
+ * genome, out[3] = launches. Tests use it to prove that a parity case exercised the instantiation the bench times. */
+int   gs_ctx_last_sketch_info(gs_ctx *, uint32_t out[4]);
+
 /* plain device-memory helpers so that hosts without a HIP binding can keep data resident in HBM */
 int   gs_dev_alloc(gs_ctx *, size_t bytes, void **dev_ptr);
 int   gs_dev_free(gs_ctx *, void *dev_ptr);
@@ -189,6 +194,10 @@ int      gs_index_parallel_search_dev(gs_index *, const void *queries_dev, uint6
 /* exact top-k by exhaustive DistHamming (recall ground truth; also what bindash.rs:120-157 computes) */
 int      gs_index_bruteforce_search(gs_index *, const void *queries, uint64_t nq, uint32_t knbn,
                                     uint64_t *ids_out, float *dist_out);
+/* the dense producer on its own: DistHamming of every query against EVERY node as 16-bit mismatch counts (count / m = the distance), the
+ * matrix the dense traversal looks its distances up in - match-join (with heavy blocks through the compare tile kernel) or compare tile kernel
+ * as the search would choose. counts_out: HOST nq x nb_point, row-major. Needs m <= 65535. (bindash.rs:120-157 computes the same all-pairs) */
+int      gs_index_count_matrix(gs_index *, const void *queries, uint64_t nq, uint16_t *counts_out);
 /* Graph import / export (the role of hnswio::HnswIo::load_hnsw / Hnsw::file_dump, reloadhnsw.rs:41-51,
  * dumpload.rs:31, in this library's own dense layout): levels[n], entry id, layer 0: deg0[n], nbr0[n*2M],
  * cnt0[n*2M] (mismatch counts to the owner); upper layers: upidx[n] (-1 for level-0 nodes) and for the
@@ -215,7 +224,8 @@ int      gs_index_load_hnswrs(gs_ctx *, const char *basename, const gs_index_par
 uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluations spent by inserts so far */
 /* device-side work counters of the searches and dense-mode inserts since the last reset (bench.py prices kernels with them):
  * out[0] memory-side atomics sent by the match-join, out[1] candidates popped by the dense traversal, out[2] pops that accepted
- * at least one neighbour, out[3] traversal workgroups in flight (last launch), out[4] bytes of adjacency a pop loads, out[5..7] 0 */
+ * at least one neighbour, out[3] traversal workgroups in flight (last launch), out[4] bytes of adjacency a pop loads, out[5] / out[6] pops before / after the traversal
+ * became order-free, out[7] chance matches on shared table entries the match-join expanded over a cluster's members (heavy blocks) */
 int      gs_index_search_stats(gs_index *, uint64_t out[8], int reset);
 
 /* ---------------------------------------------------------------------------------------------- */

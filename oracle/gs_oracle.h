@@ -80,6 +80,10 @@ int      go_index_export(const go_index *, uint8_t *levels, int64_t *entry, uint
 int      go_index_import(go_index *, const void *sigs, uint64_t n, const uint8_t *levels, int64_t entry, const uint32_t *deg0,
                          const uint32_t *nbr0, const uint32_t *cnt0, const int32_t *upidx, const uint32_t *degU,
                          const uint32_t *nbrU, const uint32_t *cntU);
+/* search-only view: keeps a pointer to the caller's rows instead of copying them */
+int      go_index_import_view(go_index *, const void *sigs, uint64_t n, const uint8_t *levels, int64_t entry, const uint32_t *deg0,
+                         const uint32_t *nbr0, const uint32_t *cnt0, const int32_t *upidx, const uint32_t *degU,
+                         const uint32_t *nbrU, const uint32_t *cntU);
 uint64_t go_index_total_evals(const go_index *);       /* distance evaluations spent in insert so far */
 
 /* ---- test hooks (PRNG restatement vs published reference vectors) ---- */

@@ -77,6 +77,7 @@ def lib():
         L.go_bruteforce_topk.argtypes = [C.c_int, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_int]
         L.go_index_export.argtypes = [C.c_void_p] + [vp] * 10
         L.go_index_import.argtypes = [C.c_void_p, vp, C.c_uint64, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+        L.go_index_import_view.argtypes = L.go_index_import.argtypes
         _lib = L
     return _lib
 
@@ -200,11 +201,14 @@ class Index:
     def nb_point(self):
         return lib().go_index_nb_point(self.h)
 
-    def import_graph(self, sigs, g):
+    def import_graph(self, sigs, g, view=False):
+        """view=True: keep a pointer to `sigs` instead of a copy (search only; the array is held alive by this object)"""
         sigs = np.ascontiguousarray(sigs, dtype=self.dtype)
         a = {k: np.ascontiguousarray(v) for k, v in g.items() if isinstance(v, np.ndarray)}
         U = int(g["n_upper"])
-        rc = lib().go_index_import(self.h, _p(sigs), sigs.shape[0], _p(a["levels"]), int(g["entry"]), _p(a["deg0"]), _p(a["nbr0"]),
+        if view:
+            self._rows = sigs
+        rc = (lib().go_index_import_view if view else lib().go_index_import)(self.h, _p(sigs), sigs.shape[0], _p(a["levels"]), int(g["entry"]), _p(a["deg0"]), _p(a["nbr0"]),
                                    _p(a["cnt0"]), _p(a["upidx"]), _p(a["degU"]) if U else None, _p(a["nbrU"]) if U else None,
                                    _p(a["cntU"]) if U else None)
         assert rc == 0

@@ -1,0 +1,120 @@
+"""BASELINE.json configs[1] and configs[2] at FULL size against the CPU oracle: the comparisons bench.py makes after its
+timed region, as tests the driver's `pytest -m gpu` runs.
+
+  configs[1]  k=21 s=18000 optdens (and revoptdens) on 5 Mbp genomes -> signature bits == oracle, through the filtered instantiation of
+              k_sketch_min the bench times (it is not launched below 64 k-mers per slot, i.e. below 1.15 Mbp at s=18000)
+              [/root/reference/src/dna/dnarequest.rs:272, src/dna/dnasketch.rs:336]
+  configs[2]  request against a 300 000-node s=18000 HNSW (M=128, efc=1600), ef=5000, n=50 -> ids, distances, evaluation counts ==
+              oracle.parallel_search on the exported graph, dense (match-join + dense traversal) and gather (row streaming) strategies,
+              tie-aware recall@50 against the exhaustive search  [/root/reference/src/dna/dnarequest.rs:353, src/bin/gsearch.rs:893]
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def test_config1_sketch_5mbp_s18000(gpu_ctx, monkeypatch):
+    import gsearch_amd as G
+    k, m, L = 21, 18000, 5_000_000
+    rng = np.random.default_rng(2024)
+    root = H.rand_dna(rng, L)
+    singles = [H.dna_ascii(g) for g in (root, H.mutate(rng, root, 0.01), H.mutate(rng, root, 0.05), H.rand_dna(rng, L), H.rand_dna(rng, L),
+                                         H.rand_dna(rng, L + 1234), H.rand_dna(rng, L - 777))]
+    g7 = H.dna_ascii(H.rand_dna(rng, L))
+    multi = [g7[:1_200_000], g7[1_200_000:2_000_000].lower(), b"ACGTACGTAC", b"", g7[2_000_000:2_000_020],            # short / empty records
+             g7[2_000_020:3_300_000] + b"NNNNNNNNNNnnnnRYK" + g7[3_300_000:4_100_000], g7[4_100_000:]]                 # N runs / IUPAC codes split k-mers
+    genomes = [[s] for s in singles] + [multi]
+    recs = [r for g in genomes for r in g]
+    goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
+    seq, rs, rl = O.pack_dna(recs)
+    ng = len(genomes)
+    # the same genomes 65 times over (the packed buffer repeated, 650 MB): 520 genomes >= 2 x CUs, one workgroup per genome like the bench
+    reps = 65
+    seq_r = np.tile(seq, reps)
+    rs_r = np.concatenate([rs + np.uint64(r * len(seq) * 4) for r in range(reps)])
+    rl_r = np.tile(rl, reps)
+    goff_r = np.concatenate([goff[:-1] + np.uint64(r * len(rs)) for r in range(reps)] + [np.array([reps * len(rs)], np.uint64)])
+    for algo in ("optdens", "revoptdens"):
+        ref = O.sketch_batch(O.params(k, m, algo), seq, rs, rl, goff, nthreads=os.cpu_count())
+        sk = G.sketcher_for(G.SeqSketcherParams(k, m, algo))
+        got = sk.sketch_packed(seq, rs, rl, goff)                   # 8 genomes: every genome split over many workgroups (global slot table)
+        info = sk.ctx.last_sketch_info()
+        assert info["filtered"] and info["workgroups_per_genome"] > 1, info
+        assert got.dtype == ref.dtype and np.array_equal(_bits(got), _bits(ref)), algo
+        big = sk.sketch_packed(seq_r, rs_r, rl_r, goff_r)             # 520 genomes: one workgroup per genome, slot table + survivor queues in LDS
+        info = sk.ctx.last_sketch_info()
+        assert info["filtered"] and info["table_in_lds"] and info["workgroups_per_genome"] == 1, info
+        assert np.array_equal(_bits(big), np.tile(_bits(ref), (reps, 1))), algo
+    # A/B: the unfiltered instantiation gives the same bits
+    monkeypatch.setenv("GS_SKETCH_FILTER", "0")
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "optdens"))
+    plain = sk.sketch_packed(seq, rs, rl, goff)
+    assert not sk.ctx.last_sketch_info()["filtered"]
+    ref = O.sketch_batch(O.params(k, m, "optdens"), seq, rs, rl, goff, nthreads=os.cpu_count())
+    assert np.array_equal(_bits(plain), _bits(ref))
+
+
+def test_config2_request_300k(gpu_ctx, monkeypatch):
+    import gsearch_amd as G
+    ctx, lib, chk = gpu_ctx, gpu_ctx.L, G._lib.check
+    n, m, M, efc, knbn, ef, nq = 300_000, 18000, 128, 1600, 50, 5000, 40
+    n_roots = 3000                                              # SURVEY 8d sketch-level database: 3000 roots x ~100 members, J ~ U[0.3, 0.99]
+    d_db = ctx.alloc(n * m * 4)
+    d_q = ctx.alloc(nq * m * 4)
+    hn = None
+    try:
+        chk(lib.gs_synth_sigs_dev(ctx.h, G._lib.KIND_F32, m, 4242, 0, n, n_roots, 0.3, 0.99, d_db))
+        chk(lib.gs_synth_sigs_dev(ctx.h, G._lib.KIND_F32, m, 4242, 5_000_000, nq, n_roots, 0.3, 0.99, d_q))
+        hn = G.Hnsw.new(M, n, 16, efc, G.DistHamming(ctx), dtype=np.float32, seed=99, insert_batch=256, ctx=ctx)
+        hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+        hn._ensure(m)
+        for g0 in range(0, n, 8192):                            # tohnsw: parallel_insert in the chunks the reference's collector hands over
+            chk(lib.gs_index_parallel_insert_dev(hn.h, d_db + g0 * m * 4, min(8192, n - g0)))
+        assert hn.get_nb_point() == n
+        ctx.free(d_db); d_db = None
+        q = ctx.download(d_q, (nq, m), np.float32)
+        res = {}
+        for mode in ("dense", "gather"):
+            monkeypatch.setenv("GS_DIST_MODE", mode)
+            res[mode] = hn.search_arrays(q, knbn, ef)
+        monkeypatch.delenv("GS_DIST_MODE")
+        res["default"] = hn.search_arrays(q, knbn, ef)
+        st = hn.search_stats(reset=True)
+        bi, bd = hn.bruteforce_search(q, knbn)
+        g = hn.export_graph()
+        db = hn.get_data()
+    finally:
+        if hn is not None:
+            hn.close()
+        for p in (d_db, d_q):
+            if p:
+                ctx.free(p)
+        ctx.release_scratch()
+    assert g["deg0"].min() >= 1 and g["deg0"].max() > 64            # (level scale 0.25 / ln 128: upper layers are practically empty, as in gsearch)
+    oix = O.Index(np.float32, m, M, efc, scale_modify=0.25, seed=99)
+    oix.import_graph(db, g, view=True)
+    want = oix.parallel_search(q, knbn, ef, nthreads=os.cpu_count())
+    for mode, got in res.items():
+        for name, a, b in zip(("ids", "distances", "counts", "evaluations"), got, want):
+            assert np.array_equal(_bits(a), _bits(b)), (mode, name)
+    assert st["pops"] > 0                                       # the default strategy at this size is the dense traversal
+    ids, dist, cnt, ev = res["default"]
+    assert (cnt == knbn).all() and (ev >= ef).all()
+    # tie-aware recall@50: a returned neighbour counts when it lies within the exact 50th distance
+    rec = float(np.mean([(dist[i] <= bd[i, -1]).mean() for i in range(nq)]))
+    rec_cpu = float(np.mean([(want[1][i] <= bd[i, -1]).mean() for i in range(nq)]))
+    assert rec == rec_cpu and rec >= 0.99, (rec, rec_cpu)
+    # the exhaustive search itself against the oracle's exhaustive search on a few queries
+    oi, od = O.bruteforce_topk(db, q[:4], knbn, nthreads=os.cpu_count())
+    assert np.array_equal(od, bd[:4])

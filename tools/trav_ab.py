@@ -21,6 +21,7 @@ ap.add_argument("--per-root", type=int, default=100)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--genomes", action="store_true", help="database and queries sketched from synthetic genomes like bench.py (representative match statistics)")
 ap.add_argument("--genome-len", type=int, default=5_000_000)
+ap.add_argument("--query-roots", type=int, default=0, help="draw the queries from the first R roots only (0 = all): the redundant regime, many isolates of a few species")
 ap.add_argument("variants", nargs="*", default=[""])
 a = ap.parse_args()
 
@@ -42,14 +43,14 @@ if a.genomes:
     d_seq = ctx.alloc(nrec * gb + 64)
     d_rs, d_rl, d_go = ctx.alloc(8 * nrec), ctx.alloc(8 * nrec), ctx.alloc(8 * (nrec + 1))
     ctx.upload(d_rs, np.arange(nrec, dtype=np.uint64) * np.uint64(words * 32)); ctx.upload(d_rl, np.full(nrec, Lg, np.uint64)); ctx.upload(d_go, np.arange(nrec + 1, dtype=np.uint64))
-    def sk(first, n, d_out):
-        _lib.check(L.gs_synth_dna_family_dev(ctx.h, 2024, first, n, Lg, n_roots, 0.001, 0.08, d_seq))
+    def sk(first, n, d_out, roots=n_roots):
+        _lib.check(L.gs_synth_dna_family_dev(ctx.h, 2024, first, n, Lg, roots, 0.001, 0.08, d_seq))
         _lib.check(L.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, n * gb + 64, d_rs, d_rl, n, d_go, n, d_out))
     for r0 in range(0, a.n, chunk):
         nr = min(chunk, a.n - r0)
         sk(r0, nr, d_rows)
         _lib.check(L.gs_index_parallel_insert_dev(hn.h, d_rows, nr))
-    sk(1_000_000_000, a.nq, d_q)
+    sk(1_000_000_000, a.nq, d_q, a.query_roots or n_roots)
     for p_ in (d_seq, d_rs, d_rl, d_go):
         ctx.free(p_)
 else:
@@ -57,7 +58,7 @@ else:
         nr = min(chunk, a.n - r0)
         _lib.check(L.gs_synth_sigs_dev(ctx.h, 3, a.m, 99, r0, nr, n_roots, 0.3, 0.99, d_rows))
         _lib.check(L.gs_index_parallel_insert_dev(hn.h, d_rows, nr))
-    _lib.check(L.gs_synth_sigs_dev(ctx.h, 3, a.m, 99, 10_000_000, a.nq, n_roots, 0.3, 0.99, d_q))
+    _lib.check(L.gs_synth_sigs_dev(ctx.h, 3, a.m, 99, 10_000_000, a.nq, a.query_roots or n_roots, 0.3, 0.99, d_q))
 ctx.sync()
 print("built %d nodes in %.1fs" % (a.n, time.perf_counter() - t0), flush=True)
 ctx.free(d_rows)
