@@ -24,7 +24,7 @@ KIND_DTYPE = {KIND_U16: np.dtype(np.uint16), KIND_U32: np.dtype(np.uint32), KIND
               KIND_F32: np.dtype(np.float32)}
 DTYPE_KIND = {v: k for k, v in KIND_DTYPE.items()}
 
-Neighbour = namedtuple("Neighbour", ["d_id", "distance"])   # hnsw_rs::Neighbour fields gsearch reads (answer.rs:42,55-57)
+Neighbour = namedtuple("Neighbour", ["d_id", "distance", "p_id"], defaults=[None])   # hnsw_rs::Neighbour; gsearch reads d_id and distance (answer.rs:42,55-57); p_id = (layer, rank in layer)
 
 # At interpreter exit the HIP runtime may already be torn down when Python finalises leftover objects: destroying device
 # objects then would call into a dead runtime. After this flag is set __del__ becomes a no-op (the OS reclaims everything).
@@ -545,17 +545,43 @@ class Hnsw:
     def get_nb_point(self):
         return 0 if self.h is None else self.ctx.L.gs_index_nb_point(self.h)
 
-    def parallel_insert(self, datas):
-        """datas: (n, m) array, or list of (vector, id) like the reference (ids must be nb_point.. in order)."""
+    def parallel_insert(self, datas, ids=None):
+        """datas: (n, m) array (ids: optional DataIds, default nb_point..), or a list of (vector, id) pairs like the reference's
+        parallel_insert(&[(&Vec<Sig>, usize)]) (dnasketch.rs:426-435); searches return the ids as d_id"""
         if isinstance(datas, (list, tuple)) and len(datas) and isinstance(datas[0], tuple):
-            base = self.get_nb_point()
-            for i, (_, did) in enumerate(datas):
-                if did != base + i:
-                    raise GsError(_lib.GS_ERR_INVALID, "ids must continue the index in order (dnasketch.rs:429-433)")
+            ids = [did for _, did in datas]
             datas = np.stack([d for d, _ in datas])
         datas = np.ascontiguousarray(datas, dtype=self.dtype)
         self._ensure(datas.shape[1])
-        check(self.ctx.L.gs_index_parallel_insert(self.h, _p(datas), datas.shape[0]))
+        if ids is None:
+            check(self.ctx.L.gs_index_parallel_insert(self.h, _p(datas), datas.shape[0]))
+        else:
+            ids = np.ascontiguousarray(ids, dtype=np.uint64)
+            if len(ids) != datas.shape[0]:
+                raise GsError(_lib.GS_ERR_INVALID, "one id per vector")
+            check(self.ctx.L.gs_index_parallel_insert_ids(self.h, _p(datas), _p(ids), datas.shape[0]))
+
+    def set_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        check(self.ctx.L.gs_index_set_ids(self.h, _p(ids), len(ids)))
+
+    def get_ids(self, first=0, n=None):
+        n = self.get_nb_point() - first if n is None else n
+        out = np.zeros(n, dtype=np.uint64)
+        check(self.ctx.L.gs_index_get_ids(self.h, first, n, _p(out)))
+        return out
+
+    def search_arrays_pid(self, datas, knbn, ef):
+        """search_arrays plus hnsw_rs' PointId of every neighbour: (ids, dist, cnt, evals, pid_layer, pid_rank)"""
+        datas = np.ascontiguousarray(datas, dtype=self.dtype)
+        if self.h is None:
+            raise GsError(_lib.GS_ERR_STATE, "search on an empty index")
+        nq = datas.shape[0]
+        ids, dist = np.zeros((nq, knbn), np.uint64), np.zeros((nq, knbn), np.float32)
+        cnt, ev = np.zeros(nq, np.uint32), np.zeros(nq, np.uint64)
+        pl, pr = np.zeros((nq, knbn), np.uint8), np.zeros((nq, knbn), np.int32)
+        check(self.ctx.L.gs_index_parallel_search_pid(self.h, _p(datas), nq, knbn, ef, _p(ids), _p(dist), _p(cnt), _p(ev), _p(pl), _p(pr)))
+        return ids, dist, cnt, ev, pl, pr
 
     def search_arrays(self, datas, knbn, ef):
         datas = np.ascontiguousarray(datas, dtype=self.dtype)
@@ -571,8 +597,8 @@ class Hnsw:
 
     def parallel_search(self, datas, knbn, ef):
         """-> Vec<Vec<Neighbour>>, ascending distance (dnarequest.rs:353)."""
-        ids, dist, cnt, _ = self.search_arrays(datas, knbn, ef)
-        return [[Neighbour(int(ids[i, j]), float(dist[i, j])) for j in range(int(cnt[i]))] for i in range(len(ids))]
+        ids, dist, cnt, _, pl, pr = self.search_arrays_pid(datas, knbn, ef)
+        return [[Neighbour(int(ids[i, j]), float(dist[i, j]), (int(pl[i, j]), int(pr[i, j]))) for j in range(int(cnt[i]))] for i in range(len(ids))]
 
     def count_matrix(self, datas):
         """mismatch counts of every query against every node (nq x nb_point, uint16) from the dense producer the search would use"""

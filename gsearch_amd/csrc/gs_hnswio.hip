@@ -18,6 +18,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "gs_internal.hpp"
 
@@ -73,6 +74,8 @@ int gs_index_dump_hnswrs_ex(gs_index *ix, const char *basename, uint32_t flags)
     if ((rc = gs_index_export(ix, nullptr, &entry, nullptr, nullptr, nullptr, nullptr, &U, nullptr, nullptr, nullptr))) return rc;
     std::vector<uint32_t> dU(std::max<uint64_t>(U, 1) * ML), nU(std::max<uint64_t>(U, 1) * ML * M), cU(std::max<uint64_t>(U, 1) * ML * M);
     if ((rc = gs_index_export(ix, lv.data(), &entry, d0.data(), n0.data(), c0.data(), up.data(), &U, dU.data(), nU.data(), cU.data()))) return rc;
+    std::vector<uint64_t> oid(n);
+    if ((rc = gs_index_get_ids(ix, 0, n, oid.data()))) return rc;
     // PointId = (top layer, rank among the points of that layer in id order)
     std::vector<int32_t> rank(n); std::vector<std::vector<uint32_t>> by_layer(ML);
     for (uint64_t i = 0; i < n; i++) { rank[i] = (int32_t)by_layer[lv[i]].size(); by_layer[lv[i]].push_back((uint32_t)i); }
@@ -101,19 +104,19 @@ int gs_index_dump_hnswrs_ex(gs_index *ix, const char *basename, uint32_t flags)
             for (size_t j = j0; j < j1; j++) {
                 const uint32_t id = by_layer[L][j];
                 if (!contiguous && (rc = gs_index_get_data(ix, id, 1, rows.data() + (j - j0) * esz * m))) { fclose(fg); fclose(fd); return rc; }
-                g.put<uint32_t>(gs::fmt::MAGICPOINT); g.put<uint64_t>(id); g.put<uint8_t>((uint8_t)L); g.put<int32_t>((int32_t)j);
+                g.put<uint32_t>(gs::fmt::MAGICPOINT); g.put<uint64_t>(oid[id]); g.put<uint8_t>((uint8_t)L); g.put<int32_t>((int32_t)j);
                 for (uint32_t l = 0; l < gs::fmt::NB_LAYER_MAX; l++) {
                     uint32_t deg = 0; const uint32_t *nb = nullptr, *cn = nullptr;
                     if (l == 0) { deg = d0[id]; nb = &n0[(uint64_t)id * 2 * M]; cn = &c0[(uint64_t)id * 2 * M]; }
                     else if (l <= L) { const uint64_t u = (uint64_t)up[id]; deg = dU[u * ML + (l - 1)]; nb = &nU[(u * ML + (l - 1)) * M]; cn = &cU[(u * ML + (l - 1)) * M]; }
                     g.put<uint8_t>((uint8_t)deg);
-                    for (uint32_t t = 0; t < deg; t++) { g.put<uint64_t>(nb[t]); g.put<uint8_t>(lv[nb[t]]); g.put<int32_t>(rank[nb[t]]); g.put<float>((float)cn[t] / fm); }
+                    for (uint32_t t = 0; t < deg; t++) { g.put<uint64_t>(oid[nb[t]]); g.put<uint8_t>(lv[nb[t]]); g.put<int32_t>(rank[nb[t]]); g.put<float>((float)cn[t] / fm); }
                 }
-                d.put<uint32_t>(gs::fmt::MAGICDATAP); d.put<uint64_t>(id); d.put<uint64_t>(esz * m); d.bytes(rows.data() + (j - j0) * esz * m, esz * m);
+                d.put<uint32_t>(gs::fmt::MAGICDATAP); d.put<uint64_t>(oid[id]); d.put<uint64_t>(esz * m); d.bytes(rows.data() + (j - j0) * esz * m, esz * m);
             }
         }
     }
-    g.put<uint64_t>((uint64_t)entry); g.put<uint8_t>(lv[entry]); g.put<int32_t>(rank[entry]);
+    g.put<uint64_t>(oid[entry]); g.put<uint8_t>(lv[entry]); g.put<int32_t>(rank[entry]);
     const bool ok = g.ok && d.ok;
     fclose(fg); fclose(fd);
     GS_REQUIRE(ok, GS_ERR_IO, "short write to %s", gname.c_str());
@@ -123,7 +126,7 @@ int gs_index_dump_hnswrs_ex(gs_index *ix, const char *basename, uint32_t flags)
 /* HnswIo::load_hnsw (reloadhnsw.rs:41-51): reads <basename>.hnsw.graph / .hnsw.data into a new index on ctx. The dump does not hold
  * what Hnsw::new was given beyond max_nb_connection and ef: `hint` (optional) supplies capacity, scale_modify, extend_candidates,
  * keep_pruned, seed and insert_batch for later insertions (gsearch's `add` re-reads them from parameters.json, gsearch.rs:717-741).
- * Point ids must be 0..n-1 (gsearch's ids are dictionary ranks, dnasketch.rs:429-433). */
+ * DataIds 0..n-1 (gsearch's dictionary ranks, dnasketch.rs:429-433) become the node numbers; any other distinct ids are kept as caller ids. */
 int gs_index_load_hnswrs(gs_ctx *c, const char *basename, const gs_index_params *hint, gs_index **out)
 {
     GS_REQUIRE(c && basename && out, GS_ERR_INVALID, "null argument");
@@ -149,12 +152,39 @@ int gs_index_load_hnswrs(gs_ctx *c, const char *basename, const gs_index_params 
     const size_t esz = gs::kind_bytes(kind);
     // data file
     GS_REQUIRE(d.get<uint32_t>() == gs::fmt::MAGICDATAP && d.get<uint64_t>() == dim && d.ok, GS_ERR_IO, "%s: bad header", dname.c_str());
-    std::vector<uint8_t> sigs((size_t)n * esz * m); std::vector<uint8_t> have(n, 0);
+    // DataIds: gsearch's are the dictionary ranks 0..n-1 (dnasketch.rs:429-433) and then ARE the node numbers of this library; any other set of
+    // distinct ids is kept as the caller's ids (gs_index_set_ids) over nodes numbered in the order of the data file
+    std::vector<uint8_t> sigs((size_t)n * esz * m);
+    std::vector<uint64_t> oid(n);
+    const long data_pos = ftell(fd);
+    bool dense = true;
+    {
+        std::vector<uint8_t> have(n, 0);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint32_t mg = d.get<uint32_t>(); const uint64_t id = d.get<uint64_t>(), nb = d.get<uint64_t>();
+            GS_REQUIRE(d.ok && mg == gs::fmt::MAGICDATAP && nb == esz * m, GS_ERR_IO, "%s: bad vector record %llu", dname.c_str(), (unsigned long long)i);
+            oid[i] = id;
+            if (id >= n || have[id]) dense = false; else have[id] = 1;
+            GS_REQUIRE(fseek(fd, (long)(esz * m), SEEK_CUR) == 0, GS_ERR_IO, "%s is truncated", dname.c_str());
+        }
+    }
+    std::unordered_map<uint64_t, uint64_t> node_of;
+    if (!dense) {
+        node_of.reserve(n * 2);
+        for (uint64_t i = 0; i < n; i++) GS_REQUIRE(node_of.emplace(oid[i], i).second, GS_ERR_IO, "%s: id %llu appears twice", dname.c_str(), (unsigned long long)oid[i]);
+    }
+    auto node = [&](uint64_t id, bool *ok) -> uint64_t {          // DataId -> node number
+        if (dense) { if (id >= n) *ok = false; return id; }
+        auto it = node_of.find(id);
+        if (it == node_of.end()) { *ok = false; return 0; }
+        return it->second;
+    };
+    GS_REQUIRE(fseek(fd, data_pos, SEEK_SET) == 0, GS_ERR_IO, "%s: seek", dname.c_str());
     for (uint64_t i = 0; i < n; i++) {
-        const uint32_t mg = d.get<uint32_t>(); const uint64_t id = d.get<uint64_t>(), nb = d.get<uint64_t>();
-        GS_REQUIRE(d.ok && mg == gs::fmt::MAGICDATAP && id < n && nb == esz * m && !have[id], GS_ERR_IO, "%s: bad vector record %llu", dname.c_str(), (unsigned long long)i);
-        d.bytes(sigs.data() + id * esz * m, esz * m); have[id] = 1;
-        GS_REQUIRE(d.ok, GS_ERR_IO, "%s is truncated", dname.c_str());
+        (void)d.get<uint32_t>(); const uint64_t id = d.get<uint64_t>(); (void)d.get<uint64_t>();
+        bool ok = true;
+        d.bytes(sigs.data() + node(id, &ok) * esz * m, esz * m);
+        GS_REQUIRE(d.ok && ok, GS_ERR_IO, "%s is truncated", dname.c_str());
     }
     // graph
     GS_REQUIRE(g.get<uint8_t>() == gs::fmt::NB_LAYER_MAX && g.ok, GS_ERR_IO, "%s: bad layer count", gname.c_str());
@@ -168,16 +198,18 @@ int gs_index_load_hnswrs(gs_ctx *c, const char *basename, const gs_index_params 
         const uint64_t np = g.get<uint64_t>();
         GS_REQUIRE(g.ok && seen + np <= n, GS_ERR_IO, "%s: layer %u claims %llu points", gname.c_str(), L, (unsigned long long)np);
         for (uint64_t j = 0; j < np; j++) {
-            const uint32_t mg = g.get<uint32_t>(); const uint64_t id = g.get<uint64_t>(); const uint8_t pl = g.get<uint8_t>(); (void)g.get<int32_t>();
-            GS_REQUIRE(g.ok && mg == gs::fmt::MAGICPOINT && id < n && pl == L && lv[id] == 0xFF, GS_ERR_IO, "%s: bad point record (layer %u, rank %llu)", gname.c_str(), L, (unsigned long long)j);
+            bool idok = true;
+            const uint32_t mg = g.get<uint32_t>(); const uint64_t id = node(g.get<uint64_t>(), &idok); const uint8_t pl = g.get<uint8_t>(); (void)g.get<int32_t>();
+            GS_REQUIRE(g.ok && idok && mg == gs::fmt::MAGICPOINT && id < n && pl == L && lv[id] == 0xFF, GS_ERR_IO, "%s: bad point record (layer %u, rank %llu)", gname.c_str(), L, (unsigned long long)j);
             lv[id] = (uint8_t)L;
             if (L > 0) { up[id] = (int32_t)upper.size(); upper.emplace_back(ML); }
             for (uint32_t l = 0; l < ML; l++) {
                 const uint8_t cnt = g.get<uint8_t>();
                 std::vector<uint64_t> keys(cnt);
                 for (uint32_t t = 0; t < cnt; t++) {
-                    const uint64_t nid = g.get<uint64_t>(); (void)g.get<uint8_t>(); (void)g.get<int32_t>(); const float dist = g.get<float>();
-                    GS_REQUIRE(g.ok && nid < n && dist >= 0.0f && dist <= 1.0f, GS_ERR_IO, "%s: bad neighbour of point %llu", gname.c_str(), (unsigned long long)id);
+                    bool nok = true;
+                    const uint64_t nid = node(g.get<uint64_t>(), &nok); (void)g.get<uint8_t>(); (void)g.get<int32_t>(); const float dist = g.get<float>();
+                    GS_REQUIRE(g.ok && nok && nid < n && dist >= 0.0f && dist <= 1.0f, GS_ERR_IO, "%s: bad neighbour of point %llu", gname.c_str(), (unsigned long long)id);
                     keys[t] = ((uint64_t)(uint32_t)llrintf(dist * fm) << 32) | nid;
                 }
                 GS_REQUIRE(g.ok, GS_ERR_IO, "%s is truncated", gname.c_str());
@@ -196,8 +228,9 @@ int gs_index_load_hnswrs(gs_ctx *c, const char *basename, const gs_index_params 
         seen += np;
     }
     GS_REQUIRE(seen == n, GS_ERR_IO, "%s holds %llu points, its description says %llu", gname.c_str(), (unsigned long long)seen, (unsigned long long)n);
-    const uint64_t entry = g.get<uint64_t>();
-    GS_REQUIRE(g.ok && entry < n, GS_ERR_IO, "%s: entry point missing", gname.c_str());
+    bool eok = true;
+    const uint64_t entry = node(g.get<uint64_t>(), &eok);
+    GS_REQUIRE(g.ok && eok && entry < n, GS_ERR_IO, "%s: entry point missing", gname.c_str());
     const uint64_t U = upper.size();
     std::vector<uint32_t> dU(std::max<uint64_t>(U, 1) * ML, 0), nU(std::max<uint64_t>(U, 1) * ML * M, 0), cU(std::max<uint64_t>(U, 1) * ML * M, 0);
     for (uint64_t u = 0; u < U; u++)
@@ -212,6 +245,7 @@ int gs_index_load_hnswrs(gs_ctx *c, const char *basename, const gs_index_params 
     gs_index *ix = nullptr;
     int rc = gs_index_create(c, &prm, &ix); if (rc) return rc;
     rc = gs_index_import(ix, sigs.data(), n, lv.data(), (int64_t)entry, d0.data(), n0.data(), c0.data(), up.data(), U, U ? dU.data() : nullptr, U ? nU.data() : nullptr, U ? cU.data() : nullptr);
+    if (rc == GS_OK && !dense) rc = gs_index_set_ids(ix, oid.data(), n);
     if (rc) { gs_index_destroy(ix); return rc; }
     *out = ix;
     return GS_OK;

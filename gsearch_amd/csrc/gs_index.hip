@@ -1673,6 +1673,13 @@ struct gs_index {
     std::vector<gs::DevBuf *> slabs;
     uint64_t pair_cache_bytes = 0, pair_cache_budget = 0;
     bool early_cached = false;        // the nodes older than the first cached batch have all-pairs rows (insert_common)
+    // hnsw_rs' DataId / PointId (answer.rs:42-57 reads Neighbour{d_id, distance, p_id}): nodes are numbered 0.. in insertion order inside the
+    // library; `origin` maps them to the ids the caller inserted them under (empty = the caller's ids ARE 0.. in order, gsearch's own case,
+    // dnasketch.rs:429-433), pid_rank[i] = rank of node i among the nodes of its level (PointId = (level, rank))
+    std::vector<uint64_t> origin;
+    std::vector<int32_t> pid_rank;
+    uint64_t level_count[17] = {0};
+    gs::DevBuf origin_d, pid_rank_d; uint64_t origin_d_n = 0, pid_rank_d_n = 0;
     ~gs_index()
     {
         if (jstream) { (void)hipStreamSynchronize(jstream); (void)hipStreamDestroy(jstream); }
@@ -1683,6 +1690,8 @@ struct gs_index {
 };
 
 namespace gs {
+
+static void ids_append(gs_index *ix, const uint64_t *ids, const uint8_t *lv, uint64_t n);
 
 // Gives the insert-time pair cache back. Its slabs are an optimisation (the plan kernel streams the rows of pairs that are not cached);
 // the signatures, their column copy and the count matrix are not, so when one of THOSE cannot be allocated the cache goes and stays off.
@@ -2187,6 +2196,7 @@ int gs_index_import(gs_index *ix, const void *sigs, uint64_t n, const uint8_t *l
     }
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     ix->n = n; ix->n_upper = n_upper; ix->entry = entry; ix->top = top;
+    gs::ids_append(ix, nullptr, levels, n);
     return GS_OK;
 }
 
@@ -2225,9 +2235,68 @@ int gs_index_get_data(gs_index *ix, uint64_t first, uint64_t n, void *out)
     return gs::download_user_rows(ix, first, n, out);
 }
 
-static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
-                         uint32_t *count, uint64_t *evals)
+}  // extern "C"
+namespace gs {
+// bookkeeping of the ids / PointIds of `n` new nodes whose levels are lv[0..n) (ids == nullptr: they continue the caller's 0.. numbering)
+static void ids_append(gs_index *ix, const uint64_t *ids, const uint8_t *lv, uint64_t n)
 {
+    const uint64_t first = ix->pid_rank.size();
+    if (ids && ix->origin.empty()) { ix->origin.resize(first); for (uint64_t i = 0; i < first; i++) ix->origin[i] = i; }
+    for (uint64_t i = 0; i < n; i++) {
+        ix->pid_rank.push_back((int32_t)ix->level_count[lv[i] <= 16 ? lv[i] : 16]++);
+        if (ids) ix->origin.push_back(ids[i]);
+        else if (!ix->origin.empty()) ix->origin.push_back(first + i);
+    }
+}
+__global__ void k_pid_of(const uint64_t *__restrict__ ids, uint64_t total, const uint8_t *__restrict__ levels, const int32_t *__restrict__ rank, uint8_t *__restrict__ layer_out,
+                         int32_t *__restrict__ rank_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t id = ids[i];
+    const bool ok = id != ~(uint64_t)0;
+    layer_out[i] = ok ? levels[id] : (uint8_t)0xFF;
+    rank_out[i] = ok ? rank[id] : -1;
+}
+__global__ void k_map_ids(uint64_t *__restrict__ ids, uint64_t total, const uint64_t *__restrict__ origin)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total && ids[i] != ~(uint64_t)0) ids[i] = origin[ids[i]];
+}
+// after a search on the device: PointIds of the answers (optional), then internal node numbers -> the caller's ids
+static int finish_ids(gs_index *ix, uint64_t *ids_dev, uint64_t total, uint8_t *pid_layer_dev, int32_t *pid_rank_dev)
+{
+    gs_ctx *c = ix->ctx;
+    int rc;
+    if (pid_layer_dev && pid_rank_dev) {
+        if (ix->pid_rank_d_n != ix->n) {
+            if ((rc = ix->pid_rank_d.ensure(4 * (size_t)ix->cap))) return rc;
+            GS_HIP_CHECK(hipMemcpyAsync(ix->pid_rank_d.p, ix->pid_rank.data(), 4 * (size_t)ix->n, hipMemcpyHostToDevice, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            ix->pid_rank_d_n = ix->n;
+        }
+        hipLaunchKernelGGL(k_pid_of, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, c->stream, ids_dev, total, ix->levels.as<uint8_t>(), ix->pid_rank_d.as<int32_t>(), pid_layer_dev, pid_rank_dev);
+        GS_HIP_CHECK(hipGetLastError());
+    }
+    if (!ix->origin.empty()) {
+        if (ix->origin_d_n != ix->n) {
+            if ((rc = ix->origin_d.ensure(8 * (size_t)ix->cap))) return rc;
+            GS_HIP_CHECK(hipMemcpyAsync(ix->origin_d.p, ix->origin.data(), 8 * (size_t)ix->n, hipMemcpyHostToDevice, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            ix->origin_d_n = ix->n;
+        }
+        hipLaunchKernelGGL(k_map_ids, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, c->stream, ids_dev, total, ix->origin_d.as<uint64_t>());
+        GS_HIP_CHECK(hipGetLastError());
+    }
+    return GS_OK;
+}
+}  // namespace gs
+extern "C" {
+
+static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
+                         uint32_t *count, uint64_t *evals, uint8_t *pid_layer = nullptr, int32_t *pid_rank = nullptr)
+{
+    GS_REQUIRE((pid_layer == nullptr) == (pid_rank == nullptr), GS_ERR_INVALID, "pid_layer_out and pid_rank_out go together");
     GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
     GS_REQUIRE(knbn >= 1 && ef >= 1, GS_ERR_INVALID, "knbn and ef must be positive");
     if (nq == 0) return GS_OK;
@@ -2242,14 +2311,22 @@ static int search_common(gs_index *ix, const void *queries, bool on_dev, uint64_
     if ((rc = gs::upload_user_rows(ix, dq.p, queries, nq, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
     if (on_dev) {
         if ((rc = gs::search_dev(ix, dq.p, nq, knbn, ef, ids, dist, count, evals))) return rc;
+        if ((rc = gs::finish_ids(ix, ids, nq * knbn, pid_layer, pid_rank))) return rc;
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         return GS_OK;
     }
+    gs::PoolBuf dpl(c, 40), dpr(c, 41);
     if ((rc = dids.alloc(8 * nq * knbn))) return rc;
     if ((rc = ddist.alloc(4 * nq * knbn))) return rc;
     if ((rc = dcount.alloc(4 * nq))) return rc;
     if ((rc = devals.alloc(8 * nq))) return rc;
+    if (pid_layer && ((rc = dpl.alloc(nq * knbn)) || (rc = dpr.alloc(4 * nq * knbn)))) return rc;
     if ((rc = gs::search_dev(ix, dq.p, nq, knbn, ef, dids.as<uint64_t>(), ddist.as<float>(), dcount.as<uint32_t>(), devals.as<uint64_t>()))) return rc;
+    if ((rc = gs::finish_ids(ix, dids.as<uint64_t>(), nq * knbn, pid_layer ? dpl.as<uint8_t>() : nullptr, pid_layer ? dpr.as<int32_t>() : nullptr))) return rc;
+    if (pid_layer) {
+        GS_HIP_CHECK(hipMemcpyAsync(pid_layer, dpl.p, nq * knbn, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipMemcpyAsync(pid_rank, dpr.p, 4 * nq * knbn, hipMemcpyDeviceToHost, c->stream));
+    }
     GS_HIP_CHECK(hipMemcpyAsync(ids, dids.p, 8 * nq * knbn, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dist, ddist.p, 4 * nq * knbn, hipMemcpyDeviceToHost, c->stream));
     if (count) GS_HIP_CHECK(hipMemcpyAsync(count, dcount.p, 4 * nq, hipMemcpyDeviceToHost, c->stream));
@@ -2289,6 +2366,32 @@ int gs_index_parallel_search_dev(gs_index *ix, const void *queries_dev, uint64_t
                                  uint32_t *count, uint64_t *evals)
 {
     return search_common(ix, queries_dev, true, nq, knbn, ef, ids, dist, count, evals);
+}
+int gs_index_parallel_search_pid(gs_index *ix, const void *queries, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist, uint32_t *count, uint64_t *evals,
+                                 uint8_t *pid_layer, int32_t *pid_rank)
+{
+    return search_common(ix, queries, false, nq, knbn, ef, ids, dist, count, evals, pid_layer, pid_rank);
+}
+int gs_index_parallel_search_pid_dev(gs_index *ix, const void *queries_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist, uint32_t *count,
+                                     uint64_t *evals, uint8_t *pid_layer, int32_t *pid_rank)
+{
+    return search_common(ix, queries_dev, true, nq, knbn, ef, ids, dist, count, evals, pid_layer, pid_rank);
+}
+int gs_index_set_ids(gs_index *ix, const uint64_t *ids, uint64_t n)
+{
+    GS_REQUIRE(ix && ids, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(n == ix->n, GS_ERR_INVALID, "gs_index_set_ids: %llu ids for %llu points", (unsigned long long)n, (unsigned long long)ix->n);
+    GS_CTX_LOCK(ix->ctx);
+    ix->origin.assign(ids, ids + n);
+    ix->origin_d_n = 0;
+    return GS_OK;
+}
+int gs_index_get_ids(gs_index *ix, uint64_t first, uint64_t n, uint64_t *ids_out)
+{
+    GS_REQUIRE(ix && (ids_out || n == 0) && first + n <= ix->n, GS_ERR_INVALID, "bad range");
+    GS_CTX_LOCK(ix->ctx);
+    for (uint64_t i = 0; i < n; i++) ids_out[i] = ix->origin.empty() ? first + i : ix->origin[first + i];
+    return GS_OK;
 }
 
 static int gen_level_host(const gs_index *ix, uint64_t id)
@@ -2362,7 +2465,7 @@ static int plan_prepass(gs_index *ix, uint32_t nb, uint32_t efc, const uint16_t 
 }
 }  // namespace gs
 
-static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n)
+static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n, const uint64_t *ids = nullptr)
 {
     GS_REQUIRE(ix, GS_ERR_INVALID, "null index");
     if (n == 0) return GS_OK;
@@ -2382,6 +2485,16 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
     int rc = gs::index_reserve(ix, ix->n + n, nup);
     if (rc) return rc;
     const uint64_t first = ix->n;
+    gs::ids_append(ix, ids, lv.data(), n);
+    struct IdGuard {          // an insert that fails half-way leaves ix->n behind first + n: drop the ids / ranks of the points that did not make it
+        gs_index *ix; const std::vector<uint8_t> &lv; uint64_t first;
+        ~IdGuard()
+        {
+            for (uint64_t i = ix->n > first ? ix->n - first : 0; i < lv.size() && first + i < ix->pid_rank.size(); i++) ix->level_count[lv[i] <= 16 ? lv[i] : 16]--;
+            if (ix->pid_rank.size() > ix->n) ix->pid_rank.resize(ix->n);
+            if (ix->origin.size() > ix->n) ix->origin.resize(ix->n);
+        }
+    } id_guard{ix, lv, first};
     if ((rc = gs::upload_user_rows(ix, ix->data.as<uint8_t>() + first * ix->stride, sigs, n, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice))) return rc;
     GS_HIP_CHECK(hipMemcpyAsync(ix->levels.as<uint8_t>() + first, lv.data(), n, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(ix->upidx.as<int32_t>() + first, up.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
@@ -2623,6 +2736,16 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
 
 int gs_index_parallel_insert(gs_index *ix, const void *sigs, uint64_t n) { return insert_common(ix, sigs, false, n); }
 int gs_index_parallel_insert_dev(gs_index *ix, const void *sigs_dev, uint64_t n) { return insert_common(ix, sigs_dev, true, n); }
+int gs_index_parallel_insert_ids(gs_index *ix, const void *sigs, const uint64_t *ids, uint64_t n)
+{
+    GS_REQUIRE(ids || n == 0, GS_ERR_INVALID, "null ids");
+    return insert_common(ix, sigs, false, n, ids);
+}
+int gs_index_parallel_insert_ids_dev(gs_index *ix, const void *sigs_dev, const uint64_t *ids, uint64_t n)
+{
+    GS_REQUIRE(ids || n == 0, GS_ERR_INVALID, "null ids");
+    return insert_common(ix, sigs_dev, true, n, ids);
+}
 
 int gs_index_bruteforce_search(gs_index *ix, const void *queries, uint64_t nq, uint32_t knbn, uint64_t *ids, float *dist)
 {
@@ -2662,7 +2785,7 @@ int gs_index_bruteforce_search(gs_index *ix, const void *queries, uint64_t nq, u
             const uint64_t kk = std::min<uint64_t>(knbn, n);
             std::partial_sort(keys.begin(), keys.begin() + kk, keys.end());
             for (uint32_t t = 0; t < knbn; t++) {
-                if (t < kk) { ids[(q0 + i) * knbn + t] = (uint32_t)keys[t]; dist[(q0 + i) * knbn + t] = row[(uint32_t)keys[t]]; }
+                if (t < kk) { const uint32_t e = (uint32_t)keys[t]; ids[(q0 + i) * knbn + t] = ix->origin.empty() ? e : ix->origin[e]; dist[(q0 + i) * knbn + t] = row[e]; }
                 else { ids[(q0 + i) * knbn + t] = ~(uint64_t)0; dist[(q0 + i) * knbn + t] = INFINITY; }
             }
         }
@@ -2683,7 +2806,8 @@ int gs_index_save(gs_index *ix, const char *path)
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
     const uint64_t n = ix->n, U = ix->n_upper;
     int rc = GS_OK;
-    const char magic[8] = {'G', 'S', 'A', 'M', 'D', 'I', 'X', '1'};
+    // 'GSAMDIX1': ids are 0..n-1; 'GSAMDIX2': the caller's ids (n x u64) follow the graph
+    const char magic[8] = {'G', 'S', 'A', 'M', 'D', 'I', 'X', ix->origin.empty() ? '1' : '2'};
     uint64_t hdr[4] = {n, U, (uint64_t)ix->entry, (uint64_t)(int64_t)ix->top};
     bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&ix->prm, sizeof(ix->prm), 1, f) == 1 && fwrite(hdr, 8, 4, f) == 4;
     const uint64_t CH = 4096;
@@ -2701,6 +2825,7 @@ int gs_index_save(gs_index *ix, const char *path)
             ok = fwrite(lv.data(), 1, n, f) == n && fwrite(d0.data(), 4, n, f) == n && fwrite(n0.data(), 4, n * 2 * M, f) == n * 2 * M &&
                  fwrite(c0.data(), 4, n * 2 * M, f) == n * 2 * M && fwrite(up.data(), 4, n, f) == n && fwrite(dU.data(), 4, U * ML, f) == U * ML &&
                  fwrite(nU.data(), 4, U * ML * M, f) == U * ML * M && fwrite(cU.data(), 4, U * ML * M, f) == U * ML * M;
+        if (ok && rc == GS_OK && !ix->origin.empty()) ok = fwrite(ix->origin.data(), 8, n, f) == n;
     }
     fclose(f);
     if (rc) return rc;
@@ -2714,7 +2839,8 @@ int gs_index_load(gs_ctx *c, const char *path, gs_index **out)
     GS_REQUIRE(f, GS_ERR_IO, "cannot open %s", path);
     char magic[8]; gs_index_params prm; uint64_t hdr[4];
     memset(&prm, 0, sizeof prm);
-    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GSAMDIX1", 8) && fread(&prm, sizeof(prm), 1, f) == 1 && fread(hdr, 8, 4, f) == 4;
+    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GSAMDIX", 7) && (magic[7] == '1' || magic[7] == '2') && fread(&prm, sizeof(prm), 1, f) == 1 && fread(hdr, 8, 4, f) == 4;
+    const bool with_ids = ok && magic[7] == '2';
     if (!ok) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s is not a gsearch_amd index dump", path); }
     const uint64_t n = hdr[0], U = hdr[1];
     const uint32_t M = prm.max_nb_conn, ML = prm.max_layer;
@@ -2724,22 +2850,25 @@ int gs_index_load(gs_ctx *c, const char *path, gs_index **out)
                       ML >= 1 && ML <= 16 && prm.ef_construction >= 1 && n >= 1 && n < ((uint64_t)1 << 31) && U <= n && fstat(fileno(f), &st) == 0;
     if (!sane) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s: corrupt header", path); }
     const size_t rowbytes = gs::kind_bytes(prm.kind) * (size_t)prm.m;
-    const unsigned __int128 expect = (unsigned __int128)8 + sizeof(prm) + 32 + (unsigned __int128)n * (rowbytes + 1 + 4 + (size_t)16 * M + 4) + (unsigned __int128)U * ML * (4 + (size_t)8 * M);
+    const unsigned __int128 expect = (unsigned __int128)8 + sizeof(prm) + 32 + (unsigned __int128)n * (rowbytes + 1 + 4 + (size_t)16 * M + 4 + (with_ids ? 8 : 0)) + (unsigned __int128)U * ML * (4 + (size_t)8 * M);
     if (expect != (unsigned __int128)(uint64_t)st.st_size) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s: size %llu does not match its header (truncated or corrupt)", path, (unsigned long long)st.st_size); }
-    std::vector<uint8_t> sigs, lv; std::vector<uint32_t> d0, n0, c0, dU, nU, cU; std::vector<int32_t> up;
+    std::vector<uint8_t> sigs, lv; std::vector<uint32_t> d0, n0, c0, dU, nU, cU; std::vector<int32_t> up; std::vector<uint64_t> oid;
     try {
+        if (with_ids) oid.resize(n);
         sigs.resize(rowbytes * n); lv.resize(n); d0.resize(n); n0.resize(n * 2 * M); c0.resize(n * 2 * M); up.resize(n);
         dU.resize(std::max<uint64_t>(U, 1) * ML); nU.resize(std::max<uint64_t>(U, 1) * ML * M); cU.resize(std::max<uint64_t>(U, 1) * ML * M);
     } catch (const std::exception &) { fclose(f); GS_REQUIRE(false, GS_ERR_IO, "%s: not enough host memory for %llu points", path, (unsigned long long)n); }
     ok = fread(sigs.data(), rowbytes, n, f) == n && fread(lv.data(), 1, n, f) == n && fread(d0.data(), 4, n, f) == n &&
          fread(n0.data(), 4, n * 2 * M, f) == n * 2 * M && fread(c0.data(), 4, n * 2 * M, f) == n * 2 * M && fread(up.data(), 4, n, f) == n &&
-         fread(dU.data(), 4, U * ML, f) == U * ML && fread(nU.data(), 4, U * ML * M, f) == U * ML * M && fread(cU.data(), 4, U * ML * M, f) == U * ML * M;
+         fread(dU.data(), 4, U * ML, f) == U * ML && fread(nU.data(), 4, U * ML * M, f) == U * ML * M && fread(cU.data(), 4, U * ML * M, f) == U * ML * M &&
+         (!with_ids || fread(oid.data(), 8, n, f) == n);
     fclose(f);
     GS_REQUIRE(ok, GS_ERR_IO, "%s is truncated", path);
     gs_index *ix = nullptr;
     int rc = gs_index_create(c, &prm, &ix);
     if (rc) return rc;
     rc = gs_index_import(ix, sigs.data(), n, lv.data(), (int64_t)hdr[2], d0.data(), n0.data(), c0.data(), up.data(), U, dU.data(), nU.data(), cU.data());
+    if (rc == GS_OK && with_ids) rc = gs_index_set_ids(ix, oid.data(), n);
     if (rc) { gs_index_destroy(ix); return rc; }
     *out = ix;
     return GS_OK;

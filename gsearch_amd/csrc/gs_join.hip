@@ -9,6 +9,7 @@
 // HBM traffic: the database once per BATCH (21.6 GB for 300 k x 18000 f32) instead of once per 128 queries; arithmetic: ~1.5 LDS
 // probes per (slot, node) instead of nq compares. Output is bit-identical to the tile kernel.
 #include <algorithm>
+#include <chrono>
 #include <vector>
 #include "gs_internal.hpp"
 
@@ -588,12 +589,25 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         return join_launch<KIND, T, false>(c, g, k0.as<T>(), nq, cols, colcap, n, 0, m, out16, ld, stats, col0, false, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
     }
     const bool verbose = getenv("GS_JOIN_VERBOSE") != nullptr;
+    // GS_JOIN_TIMES=1: wall time of every stage (a sync after each: diagnostic only)
+    const bool times = getenv("GS_JOIN_TIMES") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!times) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[GS_JOIN_TIMES] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    lap("query columns + memset");
     // ---- phase 0 + heavy pairs + labels
     DevBuf &pairs = scratch[2], &ctr = scratch[3], &labq = scratch[4], &labe = scratch[5];
     if ((rc = pairs.ensure(JPAIR_CAP * 8)) || (rc = ctr.ensure(64)) || (rc = labq.ensure(4 * (size_t)nq)) || (rc = labe.ensure(4 * (size_t)n))) return rc;
     GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));
     if ((rc = join_launch<KIND, T, false>(c, g, k0.as<T>(), nq, cols, colcap, n, 0, JS0, out16, ld, stats, 0, true, nullptr, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
+    lap("phase 0 (first slots)");
     hipLaunchKernelGGL(k_heavy_scan, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, ld, nq, n, m, pairs.as<uint2>(), ctr.as<unsigned long long>(), JPAIR_CAP);
+    lap("heavy scan");
     hipLaunchKernelGGL(k_label_init, dim3((uint32_t)((std::max<uint64_t>(n, nq) + 255) / 256)), dim3(256), 0, c->stream, labq.as<uint32_t>(), nq, labe.as<uint32_t>(), n);
     for (int it = 0; it < 6; it++)
         hipLaunchKernelGGL(k_label_prop, dim3(c->n_cu * 4), dim3(256), 0, c->stream, pairs.as<uint2>(), ctr.as<unsigned long long>(), JPAIR_CAP, labq.as<uint32_t>(), labe.as<uint32_t>());
@@ -605,18 +619,30 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     uint32_t *hlq = (uint32_t *)(pin + 64), *hle = hlq + nq;
     GS_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(hlq, labq.p, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipMemcpyAsync(hle, labe.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    lap("labels + query labels down");
     const uint64_t npairs = hc[0];
     // ---- clusters: labels with >= 2 queries and >= 1 node, largest blocks dropped while the tile budget is exceeded
     std::vector<uint32_t> cq(nq, 0), ce_(nq, 0), cid(nq, 0);
     uint32_t K = 0, ntiles = 0, nhq = 0;
     uint64_t nhe = 0;
+    const uint32_t minq = getenv("GS_JOIN_CLUSTER_MINQ") ? (uint32_t)std::max(2, atoi(getenv("GS_JOIN_CLUSTER_MINQ"))) : (ce && atoi(ce) == 2 ? 2u : 12u);
+    bool any = false;
     if (npairs <= JPAIR_CAP) {
-        for (uint32_t q = 0; q < nq; q++) if (hlq[q] < nq) cq[hlq[q]]++;
+        for (uint32_t q = 0; q < nq; q++) if (hlq[q] < nq) any |= ++cq[hlq[q]] >= minq;
+    }
+    if (any) {
+        // only now the node labels (1.2 MB for 300 k nodes, and a pass over them): a batch of unrelated isolates never gets here
+        GS_HIP_CHECK(hipMemcpyAsync(hle, labe.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         for (uint64_t e = 0; e < n; e++) if (hle[e] < nq) ce_[hle[e]]++;
+        // Which components become clusters. What a cluster saves grows with the number of its queries: in the plain join a node's hit walks the run
+        // of equal keys its cluster's queries left in the table (83 isolates: 83 entries) while the rest of the wavefront waits, and all but one
+        // of them cost an atomic per match. What it costs is the cluster-aware kernel's own-cluster test on every hit of its nodes. Measured on
+        // 300 k genomes, 2500-query batches (profiles/r04_join_cluster_sweep.txt): 83 queries per family 4.1x faster, 8 per family even, 3 per
+        // family 1.6x slower - components below GS_JOIN_CLUSTER_MINQ (12) queries stay with the run-length accumulator.
         std::vector<uint32_t> order;
-        for (uint32_t l = 0; l < nq; l++) if (cq[l] >= 2 && ce_[l] >= 1) order.push_back(l);
+        for (uint32_t l = 0; l < nq; l++) if (cq[l] >= minq && ce_[l] >= 1) order.push_back(l);
         auto tiles_of = [&](uint32_t l) { return ((cq[l] + HTILE - 1) / HTILE) * ((ce_[l] + HTILE - 1) / HTILE); };
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { const uint32_t ta = tiles_of(a), tb = tiles_of(b); return ta != tb ? ta < tb : a < b; });
         for (uint32_t l : order) {
@@ -624,17 +650,16 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
             cid[l] = ++K; ntiles += tiles_of(l); nhq += cq[l]; nhe += ce_[l];
         }
     }
-    // what the blocks save: the run-length accumulator of the plain join absorbs ONE query per node, every further query of a node's cluster
-    // costs an atomic per match (and a longer probe run). A batch of unrelated isolates (a few families with two or three queries) gains
-    // nothing from the cluster-aware kernel; a redundant one gains 4x.
+    // (query, node) pairs the blocks take off the match-by-match path; a handful is not worth a second kernel variant and the tile launch
     uint64_t saved_pairs = 0;
     for (uint32_t l = 0; l < nq; l++) if (cid[l]) saved_pairs += (uint64_t)(cq[l] - 1) * ce_[l];
-    const uint64_t min_saved = getenv("GS_JOIN_CLUSTER_MIN") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MIN")) : (ce && atoi(ce) == 2 ? 0 : (uint64_t)nq * 48);
+    const uint64_t min_saved = getenv("GS_JOIN_CLUSTER_MIN") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MIN")) : (ce && atoi(ce) == 2 ? 0 : (uint64_t)nq * 8);
     if (verbose)
         fprintf(stderr, "[GS_JOIN] nq=%u n=%llu heavy pairs %llu (matches in the first %u slots %llu): %u clusters, %u queries x %llu nodes in %u tiles, %llu pairs off the atomics%s\n", nq,
                 (unsigned long long)n, (unsigned long long)npairs, JS0, hc[1], K, nhq, (unsigned long long)nhe, ntiles, (unsigned long long)saved_pairs,
                 K && saved_pairs < min_saved ? " - not worth the cluster-aware pass" : "");
     if (K && saved_pairs < min_saved) K = 0;
+    lap("host: components");
     if (K == 0) {
         // nothing to cluster (or too much: pair list overflow): the plain join over the remaining slots - unless the matches of phase 0, scaled to
         // all slots as if every one cost an atomic, say the tile kernel may be cheaper: then the sampled estimate (which knows about runs) decides
@@ -660,6 +685,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         for (uint32_t a = cl_lo[k]; a < cl_lo[k + 1]; a += HTILE)
             for (uint32_t b = ce_lo[k]; b < ce_lo[k + 1]; b += HTILE)
                 tiles.push_back(make_uint4(a, std::min<uint32_t>(HTILE, cl_lo[k + 1] - a), b, std::min<uint32_t>(HTILE, ce_lo[k + 1] - b)));
+    lap("host: lists");
     DevBuf &dqcl = scratch[6], &dnl = scratch[7], &dql = scratch[8], &del = scratch[9], &dtl = scratch[10], &dqs = scratch[11], &dcl = scratch[13];
     if ((rc = dqcl.ensure(2 * (size_t)nq)) || (rc = dnl.ensure(2 * (size_t)n)) || (rc = dql.ensure(4 * (size_t)nhq)) || (rc = del.ensure(4 * (size_t)nhe)) ||
         (rc = dtl.ensure(16 * tiles.size())) || (rc = dqs.ensure(sizeof(T) * (size_t)m * nhq)) || (rc = dcl.ensure(4 * (size_t)(K + 2)))) return rc;
@@ -672,11 +698,14 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));                  // (the host vectors above are pageable: the copies must be done before they go)
     hipLaunchKernelGGL((k_query_cols_list<T>), dim3((nhq + 31) / 32, (m + 31) / 32), dim3(256), 0, c->stream, qrows, qstride, dql.as<uint32_t>(), nhq, m, dqs.as<T>());
     GS_HIP_CHECK(hipGetLastError());
+    lap("uploads + sorted key copy");
     if ((rc = join_launch<KIND, T, true>(c, g, k0.as<T>(), nq, cols, colcap, n, JS0, m, out16, ld, stats, 0, false, dqcl.as<uint16_t>(), dnl.as<uint16_t>(), dqs.as<T>(), nhq,
                                          dcl.as<uint32_t>(), dql.as<uint32_t>()))) return rc;
     {
         ProfScope ps(c, FAM_HAMMING);
+        lap("cluster-aware join");
         if ((rc = hamming_blocks(c, KIND, m, qrows, qstride, rows, rstride, dtl.p, (uint32_t)tiles.size(), dql.as<uint32_t>(), del.as<uint32_t>(), out16, ld))) return rc;
+        lap("block compare");
     }
     return GS_OK;
 }

@@ -180,9 +180,17 @@ int      gs_index_create(gs_ctx *, const gs_index_params *, gs_index **out);
 void     gs_index_destroy(gs_index *);
 uint64_t gs_index_nb_point(const gs_index *);
 int      gs_index_get_params(const gs_index *, gs_index_params *out);
-/* parallel_insert(&[(&Vec<Sig>, usize)]): ids are assigned nb_point.. in input order (dnasketch.rs:429-433) */
+/* parallel_insert(&[(&Vec<Sig>, usize)]) for ids that continue nb_point.. in input order, gsearch's own case (dnasketch.rs:429-433) */
 int      gs_index_parallel_insert(gs_index *, const void *sigs, uint64_t n);
 int      gs_index_parallel_insert_dev(gs_index *, const void *sigs_dev, uint64_t n);
+/* parallel_insert(&[(&Vec<Sig>, usize)]) with the caller's DataIds (HOST array in both forms; hnsw_rs takes any usize, dnasketch.rs:426-435): searches
+ * return them as d_id, both dump formats store them, and gs_index_set_ids / gs_index_get_ids carry them across gs_index_import / _export.
+ * Inside the library nodes are numbered in insertion order; that number breaks distance ties in answers ((distance, insertion order) ascending)
+ * and is the id whenever no ids were given. */
+int      gs_index_parallel_insert_ids(gs_index *, const void *sigs, const uint64_t *ids, uint64_t n);
+int      gs_index_parallel_insert_ids_dev(gs_index *, const void *sigs_dev, const uint64_t *ids, uint64_t n);
+int      gs_index_set_ids(gs_index *, const uint64_t *ids, uint64_t n /* == nb_point */);
+int      gs_index_get_ids(gs_index *, uint64_t first, uint64_t n, uint64_t *ids_out);
 /* parallel_search(&[Vec<Sig>], knbn, ef) -> per query min(knbn, found) Neighbour{d_id, distance},
  * ascending by (distance, d_id). Unused tail slots: id = UINT64_MAX, distance = +inf.
  * evals_out (optional): number of DistHamming evaluations spent per query. */
@@ -191,6 +199,13 @@ int      gs_index_parallel_search(gs_index *, const void *queries, uint64_t nq, 
 int      gs_index_parallel_search_dev(gs_index *, const void *queries_dev, uint64_t nq, uint32_t knbn, uint32_t ef,
                                       uint64_t *ids_out_dev, float *dist_out_dev, uint32_t *count_out_dev,
                                       uint64_t *evals_out_dev);
+/* the same search, also returning hnsw_rs' PointId of every neighbour (Neighbour.p_id, answer.rs:42): pid_layer_out[nq x knbn] = the layer the
+ * point is filed under (its level), pid_rank_out[nq x knbn] = its rank among the points of that layer in insertion order; 0xFF / -1 in unused slots */
+int      gs_index_parallel_search_pid(gs_index *, const void *queries, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids_out, float *dist_out,
+                                      uint32_t *count_out, uint64_t *evals_out, uint8_t *pid_layer_out, int32_t *pid_rank_out);
+int      gs_index_parallel_search_pid_dev(gs_index *, const void *queries_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids_out_dev,
+                                          float *dist_out_dev, uint32_t *count_out_dev, uint64_t *evals_out_dev, uint8_t *pid_layer_out_dev,
+                                          int32_t *pid_rank_out_dev);
 /* exact top-k by exhaustive DistHamming (recall ground truth; also what bindash.rs:120-157 computes) */
 int      gs_index_bruteforce_search(gs_index *, const void *queries, uint64_t nq, uint32_t knbn,
                                     uint64_t *ids_out, float *dist_out);

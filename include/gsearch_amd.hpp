@@ -151,8 +151,10 @@ private:
 // reformat.rs:80-86
 inline double calculate_ani(double distance, int kmer, int model) { return gs_ani(distance, kmer, model); }
 
-// hnsw_rs::Neighbour fields gsearch reads (answer.rs:42,55-57)
-struct Neighbour { size_t d_id; float distance; float get_distance() const { return distance; } };
+// hnsw_rs::Neighbour{d_id, distance, p_id}: gsearch reads d_id (the DataId the point was inserted under: an index into its seqdict) and distance
+// (answer.rs:42,55-57); p_id = PointId(layer, rank in layer)
+struct PointId { uint8_t layer; int32_t rank; };
+struct Neighbour { size_t d_id; float distance; PointId p_id{0xFF, -1}; float get_distance() const { return distance; } };
 
 // (path, fasta id, sequence length) of one database / request item: what ReqAnswer::dump reads of
 // utils::idsketch::ItemDict via get_id().get_path(), get_id().get_fasta_id(), get_len() (answer.rs:48-50,56,68-69)
@@ -223,19 +225,20 @@ public:
     void set_extend_candidates(bool b) { frozen(); prm_.extend_candidates = b; }       // dnasketch.rs:159
     void set_keeping_pruned(bool b) { frozen(); prm_.keep_pruned = b; }                // dnasketch.rs:160
     size_t get_nb_point() const { return h_ ? gs_index_nb_point(h_) : 0; }
-    // parallel_insert(&[(&Vec<T>, usize)]): ids must continue the index in order (dnasketch.rs:429-435)
+    // parallel_insert(&[(&Vec<T>, usize)]) (dnasketch.rs:429-435): any DataIds; searches return them as d_id
     void parallel_insert(const std::vector<std::pair<const std::vector<T> *, size_t>> &datas)
     {
         if (datas.empty()) return;
         const size_t m = datas[0].first->size();
         ensure(m);
         std::vector<T> flat(datas.size() * m);
-        const size_t base = get_nb_point();
+        std::vector<uint64_t> ids(datas.size());
         for (size_t i = 0; i < datas.size(); i++) {
-            if (datas[i].second != base + i || datas[i].first->size() != m) throw Error(GS_ERR_INVALID, "ids must continue the index in order");
+            if (datas[i].first->size() != m) throw Error(GS_ERR_INVALID, "signature length mismatch");
+            ids[i] = datas[i].second;
             std::copy(datas[i].first->begin(), datas[i].first->end(), flat.begin() + i * m);
         }
-        check(gs_index_parallel_insert(h_, flat.data(), datas.size()));
+        check(gs_index_parallel_insert_ids(h_, flat.data(), ids.data(), datas.size()));
     }
     // parallel_search(&[Vec<T>], knbn, ef) -> Vec<Vec<Neighbour>>, ascending distance (dnarequest.rs:353)
     std::vector<std::vector<Neighbour>> parallel_search(const std::vector<std::vector<T>> &datas, size_t knbn, size_t ef) const
@@ -245,9 +248,11 @@ public:
         std::vector<T> flat(nq * m);
         for (size_t i = 0; i < nq; i++) { if (datas[i].size() != m) throw Error(GS_ERR_INVALID, "signature length mismatch"); std::copy(datas[i].begin(), datas[i].end(), flat.begin() + i * m); }
         std::vector<uint64_t> ids(nq * knbn); std::vector<float> dist(nq * knbn); std::vector<uint32_t> cnt(nq);
-        check(gs_index_parallel_search(h_, flat.data(), nq, (uint32_t)knbn, (uint32_t)ef, ids.data(), dist.data(), cnt.data(), nullptr));
+        std::vector<uint8_t> pl(nq * knbn); std::vector<int32_t> pr(nq * knbn);
+        check(gs_index_parallel_search_pid(h_, flat.data(), nq, (uint32_t)knbn, (uint32_t)ef, ids.data(), dist.data(), cnt.data(), nullptr, pl.data(), pr.data()));
         std::vector<std::vector<Neighbour>> out(nq);
-        for (size_t i = 0; i < nq; i++) for (uint32_t j = 0; j < cnt[i]; j++) out[i].push_back(Neighbour{(size_t)ids[i * knbn + j], dist[i * knbn + j]});
+        for (size_t i = 0; i < nq; i++)
+            for (uint32_t j = 0; j < cnt[i]; j++) out[i].push_back(Neighbour{(size_t)ids[i * knbn + j], dist[i * knbn + j], PointId{pl[i * knbn + j], pr[i * knbn + j]}});
         return out;
     }
     void file_dump(const std::string &path) const { check(gs_index_save(h_, path.c_str())); }      // dumpload.rs:31 (own format)

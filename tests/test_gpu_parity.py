@@ -536,7 +536,7 @@ def test_edge_cases_and_error_behaviour(gpu_ctx):
     assert dh.eval(np.array([1.5], np.float32), np.array([1.5], np.float32)) == 0.0
     with pytest.raises(G.GsError):
         dh.eval_qxc(np.zeros((2, 5), np.float32), np.zeros((2, 6), np.float32))
-    # index: search on empty index, wrong signature length, knbn > nb_point, ef beyond the LDS budget, ids out of order
+    # index: search on empty index, wrong signature length, knbn > nb_point, ef beyond the LDS budget, ragged id list
     hn = G.Hnsw.new(8, 1000, 16, 32, dh)
     with pytest.raises(G.GsError):
         hn.search_arrays(np.zeros((1, 16), np.float32), 3, 10)
@@ -548,7 +548,7 @@ def test_edge_cases_and_error_behaviour(gpu_ctx):
     with pytest.raises(G.GsError):
         hn.parallel_insert(np.zeros((2, 65), np.float32))
     with pytest.raises(G.GsError):
-        hn.parallel_insert([(db[0], 99)])
+        hn.parallel_insert(db[:2], ids=[99])                                    # one id per vector (any ids are fine: tests/test_gpu_ids.py)
     ids, dist, cnt, _ = hn.search_arrays(db[:2], 50, 10)                        # knbn > nb_point: short lists, padded
     oix = O.Index(np.float32, 64, 8, 32, seed=0)
     oix.parallel_insert(db, batch=64)
