@@ -280,7 +280,7 @@ def run_sketch(args, D):
 
 
 _PMC = None
-PMC_DEFAULTS = ("profiles/r03_pmc_sidecar.json", "profiles/r02_pmc_sidecar.json")
+PMC_DEFAULTS = ("profiles/r04_pmc_sidecar.json", "profiles/r03_pmc_sidecar.json", "profiles/r02_pmc_sidecar.json")
 
 
 def _pmc_load():
@@ -434,10 +434,13 @@ def run_request(args, D):
         "metric": "query genomes/sec", "value": value, "unit": "genomes/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "request: %d query genomes x %.1f Mbp per GPU per step (k=%d s=%d optdens sketch + HNSW search n=%d ef=%d) against a %d-genome "
-                               "OptDens HNSW (M=%d efc=%d scale %.2f) built on the GPU, DB replicated per GPU, queries sharded (BASELINE configs[2]/[3])"
-                               % (qps, L / 1e6, k, m, knbn, ef, N, args.max_nb_conn, args.ef_construction, args.scale_modify),
+                               "OptDens HNSW (M=%d efc=%d scale %.2f) built on the GPU, DB replicated per GPU, queries sharded (BASELINE configs[2]/[3]); query genomes "
+                               "HBM-resident before the timed region, %d distinct sets rotated over the steps; queries are fresh mutants of the DB's %d families (~%.1f per "
+                               "family per step); dense strategy (match-join count matrix + look-up traversal); the many-isolates-per-species regime is `request_redundant`"
+                               % (qps, L / 1e6, k, m, knbn, ef, N, args.max_nb_conn, args.ef_construction, args.scale_modify, max(nq_rank // qps, 1), n_roots, qps / n_roots),
                    "db_genomes": N, "queries_per_gpu_per_step": qps, "genome_len": L, "kmer_size": k, "sketch_size": m, "knbn": knbn, "ef_search": ef,
-                   "max_nb_conn": args.max_nb_conn, "ef_construction": args.ef_construction, "collectives_per_step": 1 if D.on else 0},
+                   "max_nb_conn": args.max_nb_conn, "ef_construction": args.ef_construction, "collectives_per_step": 1 if D.on else 0,
+                   "distinct_query_sets": max(nq_rank // qps, 1), "queries_per_db_family_per_step": qps / n_roots},
         "step_ms": [round(x, 2) for x in step_ms], "build_seconds": build_s, "build_genomes_per_sec": N / build_s, "dist_evals_per_query": evals_total / (qps * args.steps),
         "sketch_kmers_per_sec": (L - k + 1) * qps * sk_n / (sk_ms * 1e-3) if sk_ms > 0 else None,
         "multi_gpu_check": {"rccl_ranks_seen": bin(rank_mask).count("1"), "ranks_whose_block_and_checksum_verified": n_ok, "world": D.world,
@@ -477,9 +480,12 @@ def request_accounting(args, ctx, hn, lib, chk, torch, D, r):
     dense = tile_n > 0
     if dense:   # dense mode: the counts of every (query, node) pair of the step are produced up front
         pairs_total = float(qps) * N * args.steps
+        if join:        # a join batch is two launches (the first 48 slots, then the rest: gs_join.hip heavy blocks) - price the batch, not the launch
+            tile_n = args.steps * (-(-qps // 3276))
         avg_ms = tile_ms / tile_n
         kd = {"kernel": "k_match_join" if join else "k_hamming_qxc", "total_ms": tile_ms, "launches": tile_n, "avg_launch_ms": avg_ms,
-              "role": ("equi-join of the query batch with the column-major DB copy (all query x node pairs)" if join
+              "role": ("equi-join of a query batch (<= 3276 queries) with the column-major DB copy (all query x node pairs); `launches` counts batches, each = the join over "
+                       "the first 48 slots + the join over the rest" if join
                        else "dense DistHamming compare tile (all query x node pairs)"),
               "nominal_bytes_avoided_per_launch": pairs_total / tile_n * row_bytes}
         if join:
@@ -573,6 +579,84 @@ def _gz_write(job):
     return path
 
 
+def synth_proteome(seed, g, length):
+    """host twin of gs_synth_aa_dev: the residues of synthetic proteome g (include/gsearch_amd.h), padded to whole 8-byte words"""
+    nw = (length + 7) // 8
+    with np.errstate(over="ignore"):
+        base = np.uint64((((seed ^ 0xAA5EED) * 0x9e3779b97f4a7c15) + g * 0xbf58476d1ce4e5b9) & MASK64)
+        x = splitmix_mix(base + np.arange(nw, dtype=np.uint64))
+    return np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)[x.view(np.uint8) % 20]
+
+
+def sig_row_roots(seed, first, n, n_roots):
+    """host twin of the family assignment of gs_synth_sigs_dev: root of rows first .. first + n"""
+    with np.errstate(over="ignore"):
+        r = np.arange(first, first + n, dtype=np.uint64)
+        return splitmix_mix(np.uint64((seed * 31) & MASK64) + r * np.uint64(0xA24BAED4963EE407) + np.uint64(3)) % np.uint64(n_roots)
+
+
+def c5_distance_leg(args, ctx, lib, chk, O):
+    """DistHamming on u64 signatures of m = 24000 (configs[4]) through the row-gather traversal: 192 kB per evaluation. 50 000 rows (9.6 GB, far beyond
+    the 256 MB Infinity Cache) of 2000 families; every query from a DIFFERENT family. ef = 5000 makes each traversal evaluate >= 5000 of the 50 000
+    rows, so concurrent queries re-read one another's rows from L2 / Infinity Cache: the ALGORITHMIC rate (192 kB x evaluations / time) is not an HBM
+    rate. The roofline fraction printed is the one of the memory-side counters (tools/pmc_bench.sh collects FETCH_SIZE of this very launch through
+    `bench.py --workload c5dist`); without a sidecar it is null."""
+    import gsearch_amd as G
+    maa, nd, n_roots, nqx, seed = 24000, args.c5_rows, 2000, 256, 77
+    prev_mode = os.environ.get("GS_DIST_MODE")
+    os.environ["GS_DIST_MODE"] = "gather"
+    d_db = ctx.alloc(nd * maa * 8)
+    try:
+        chk(lib.gs_synth_sigs_dev(ctx.h, 2, maa, seed, 0, nd, n_roots, 0.3, 0.95, d_db))
+        hx = G.Hnsw.new(24, max(nd, 1024), 16, 64, G.DistHamming(ctx), dtype=np.uint64, seed=5, insert_batch=256, ctx=ctx)
+        hx.modify_level_scale(0.25); hx.set_extend_candidates(True); hx.set_keeping_pruned(False)
+        hx._ensure(maa)
+        t0 = time.perf_counter()
+        chk(lib.gs_index_parallel_insert_dev(hx.h, d_db, nd)); ctx.sync()
+        build_s = time.perf_counter() - t0
+        # 256 query rows of pairwise different families: the first row of each new family among rows 5 000 000 ..
+        roots = sig_row_roots(seed, 5_000_000, 4 * nqx, n_roots)
+        _, firsts = np.unique(roots, return_index=True)
+        rows = np.sort(firsts)[:nqx]
+        assert len(rows) == nqx
+        d_qx = ctx.alloc(nqx * maa * 8)
+        for i, r in enumerate(rows):
+            chk(lib.gs_synth_sigs_dev(ctx.h, 2, maa, seed, 5_000_000 + int(r), 1, n_roots, 0.3, 0.95, d_qx + i * maa * 8))
+        d_ids, d_dist, d_cnt, d_ev = ctx.alloc(8 * nqx * 50), ctx.alloc(4 * nqx * 50), ctx.alloc(4 * nqx), ctx.alloc(8 * nqx)
+        ms = None
+        for rep in range(2):
+            ctx.profile(True); ctx.profile_read(2, reset=True)
+            chk(lib.gs_index_parallel_search_dev(hx.h, d_qx, nqx, 50, 5000, d_ids, d_dist, d_cnt, d_ev))
+            g_ms, g_n = ctx.profile_read(2, reset=True); ctx.profile(False)
+            ms = g_ms if ms is None or g_ms < ms else ms
+        ev = ctx.download(d_ev, (nqx,), np.uint64)
+        gb = float(ev.sum()) * maa * 8
+        ids = ctx.download(d_ids, (nqx, 50), np.uint64); dist = ctx.download(d_dist, (nqx, 50), np.float32)
+        oix = O.Index(np.uint64, maa, 24, 64, scale_modify=0.25, seed=5)
+        oix.import_graph(ctx.download(d_db, (nd, maa), np.uint64), hx.export_graph(), view=True)
+        qh = ctx.download(d_qx, (nqx, maa), np.uint64)[:16]
+        oids, odist, _, oev = oix.parallel_search(qh, 50, 5000, nthreads=host_cpu_budget()[1])
+        traffic = pmc_traffic("k_hnsw_search_u64")
+        out = {"kernel": "k_hnsw_search<u64> (row gather, ballot/popcount)", "index_nodes": nd, "index_families": n_roots, "queries": nqx, "query_families": int(len(np.unique(roots[rows]))),
+               "evals_per_query": float(ev.mean()), "launch_ms": ms, "algorithmic_bytes": gb, "algorithmic_GBps": gb / (ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+               "traffic": traffic, "traffic_source": pmc_source() if traffic else None, "traffic_GBps": traffic / (ms * 1e-3) / 1e9 if traffic else None,
+               "frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None, "rows_re_served_by_caches": (gb / traffic) if traffic else None, "index_build_s": build_s,
+               "note": "frac = HBM bytes of the memory-side counters / launch time / 8 TB/s (null without a PMC sidecar); the algorithmic rate counts 192 kB per evaluation and, with every "
+                       "traversal touching >= 10 % of a 50 000-row index, includes rows re-served by L2 / Infinity Cache - it is NOT an HBM fraction",
+               "ids_distances_evals_equal_oracle_16_queries": bool(np.array_equal(oids, ids[:16]) and np.array_equal(odist, dist[:16]) and np.array_equal(oev, ev[:16]))}
+        del oix
+        hx.close()
+        for p_ in (d_qx, d_ids, d_dist, d_cnt, d_ev):
+            ctx.free(p_)
+        return out
+    finally:
+        ctx.free(d_db)
+        if prev_mode is None:
+            os.environ.pop("GS_DIST_MODE", None)
+        else:
+            os.environ["GS_DIST_MODE"] = prev_mode
+
+
 def extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff):
     """Driver-visible numbers for the rest of BASELINE's configs and of DESIGN 4's rate table, measured AFTER the timed region in the same
     run (rank 0, N = 1; each leg a few seconds): other sketchers at (k=21, s=18000) on the resident 5 Mbp query genomes, configs[4]
@@ -604,14 +688,13 @@ def extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff):
                        "bit_exact_vs_oracle_genome0": bool(np.array_equal(ref[0].view(np.uint8), sig[0].view(np.uint8)))}
         ctx.free(d_sig)
     out["other_sketchers_k21_s18000"] = rates
-    # ---- (2) BASELINE configs[4]: AA k=7 s=24000 super2 -> u64 signatures; 4096 proteomes = 16 shifted windows over 256 distinct 1.5 M-residue texts
-    kaa, maa, Laa, NP, ND = 7, 24000, 1_500_000, 4096, 256
-    rng = np.random.default_rng(5)
-    text = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)[rng.integers(0, 20, ND * Laa + 64)]
-    d_aa = ctx.alloc(ND * Laa + 64); ctx.upload(d_aa, text)
-    gi = np.arange(NP, dtype=np.uint64)
-    rs = (gi % np.uint64(ND)) * np.uint64(Laa) + (gi // np.uint64(ND)) * np.uint64(3)
-    rl = np.full(NP, Laa - 64, np.uint64)
+    # ---- (2) BASELINE configs[4]: AA k=7 s=24000 super2 -> u64 signatures, all 50 000 proteomes (75 GB of residues generated in HBM, gs_synth_aa_dev)
+    kaa, maa, Laa, NP = 7, 24000, 1_500_000, args.c5_proteomes
+    pb = (Laa + 7) // 8 * 8
+    d_aa = ctx.alloc(NP * pb + 64)
+    chk(lib.gs_synth_aa_dev(ctx.h, args.seed, 0, NP, Laa, d_aa))
+    rs = np.arange(NP, dtype=np.uint64) * np.uint64(pb)
+    rl = np.full(NP, Laa, np.uint64)
     d_ars, d_arl, d_ago = ctx.alloc(8 * NP), ctx.alloc(8 * NP), ctx.alloc(8 * (NP + 1))
     ctx.upload(d_ars, rs); ctx.upload(d_arl, rl); ctx.upload(d_ago, np.arange(NP + 1, dtype=np.uint64))
     prm = G.SeqSketcherParams(kaa, maa, "super2", "aa")
@@ -619,61 +702,19 @@ def extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff):
     best = None
     for rep in range(2):
         ctx.sync(); t0 = time.perf_counter()
-        chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_aa, ND * Laa + 64, d_ars, d_arl, NP, d_ago, NP, d_asig))
+        chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_aa, NP * pb + 64, d_ars, d_arl, NP, d_ago, NP, d_asig))
         ctx.sync(); dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
-    asig = ctx.download(d_asig, (NP, maa), np.uint64)
-    pick = [0, NP - 1]
-    ref = O.sketch_batch(O.params(kaa, maa, "super2", "aa"), text, rs[pick], rl[pick], np.arange(3, dtype=np.uint64), nthreads=2)
-    c5 = {"workload": "AA k=7 s=24000 super2 (u64 signatures): %d proteomes x %.2f M residues resident in HBM (16 shifted windows over %d distinct texts)" % (NP, (Laa - 64) / 1e6, ND),
-          "kmers_per_sec": float(Laa - 64 - kaa + 1) * NP / best, "proteomes_per_sec": NP / best, "wall_ms": best * 1e3,
-          "bit_exact_vs_oracle_sample": bool(np.array_equal(ref, asig[pick])), "sample": pick}
-    # DistHamming on those u64 signatures through the row-gather traversal (192 kB per evaluation): HBM GB/s against the 8 TB/s peak
-    prev_mode = os.environ.get("GS_DIST_MODE")
-    os.environ["GS_DIST_MODE"] = "gather"
-    try:
-        nd = 50000                                              # configs[4]: 50k proteomes (9.6 GB of u64 signatures)
-        d_db = ctx.alloc(nd * maa * 8)
-        chk(lib.gs_synth_sigs_dev(ctx.h, 2, maa, 77, 0, nd, 160, 0.3, 0.95, d_db))
-        hx = G.Hnsw.new(24, 100000, 16, 64, G.DistHamming(ctx), dtype=np.uint64, seed=5, insert_batch=256, ctx=ctx)
-        hx.modify_level_scale(0.25); hx.set_extend_candidates(True); hx.set_keeping_pruned(False)
-        hx._ensure(maa)
-        t0 = time.perf_counter()
-        chk(lib.gs_index_parallel_insert_dev(hx.h, d_db, nd)); ctx.sync()
-        build_s = time.perf_counter() - t0
-        nqx = 256
-        d_qx = ctx.alloc(nqx * maa * 8)
-        chk(lib.gs_synth_sigs_dev(ctx.h, 2, maa, 77, 5_000_000, nqx, 160, 0.3, 0.95, d_qx))
-        d_ids, d_dist, d_cnt, d_ev = ctx.alloc(8 * nqx * 50), ctx.alloc(4 * nqx * 50), ctx.alloc(4 * nqx), ctx.alloc(8 * nqx)
-        ms = None
-        for rep in range(2):
-            ctx.profile(True); ctx.profile_read(2, reset=True)
-            chk(lib.gs_index_parallel_search_dev(hx.h, d_qx, nqx, 50, 5000, d_ids, d_dist, d_cnt, d_ev))
-            g_ms, g_n = ctx.profile_read(2, reset=True); ctx.profile(False)
-            ms = g_ms if ms is None or g_ms < ms else ms
-        ev = ctx.download(d_ev, (nqx,), np.uint64)
-        gb = float(ev.sum()) * maa * 8
-        ids = ctx.download(d_ids, (nqx, 50), np.uint64); dist = ctx.download(d_dist, (nqx, 50), np.float32)
-        oix = O.Index(np.uint64, maa, 24, 64, scale_modify=0.25, seed=5)
-        oix.import_graph(ctx.download(d_db, (nd, maa), np.uint64), hx.export_graph())
-        qh = ctx.download(d_qx, (nqx, maa), np.uint64)[:16]
-        oids, odist, _, oev = oix.parallel_search(qh, 50, 5000, nthreads=host_cpu_budget()[1])
-        c5["distance_gather_u64_m24000"] = {"kernel": "k_hnsw_search<u64> (row gather, ballot/popcount)", "index_nodes": nd, "queries": nqx, "evals_per_query": float(ev.mean()),
-                                             "launch_ms": ms, "algorithmic_bytes": gb, "achieved_GBps": gb / (ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
-                                             "frac": gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "index_build_s": build_s,
-                                             "note": "algorithmic bytes (192 kB per evaluation) over launch time; 64-bit signatures of unrelated proteomes never tie, so a traversal touches a few thousand "
-                                                     "rows and concurrent queries share the popular ones: a fraction above 1 means rows were re-served by L2 / Infinity Cache, not that HBM exceeded its peak",
-                                             "ids_distances_evals_equal_oracle_16_queries": bool(np.array_equal(oids, ids[:16]) and np.array_equal(odist, dist[:16]) and np.array_equal(oev, ev[:16]))}
-        hx.close()
-        for p_ in (d_db, d_qx, d_ids, d_dist, d_cnt, d_ev):
-            ctx.free(p_)
-    finally:
-        if prev_mode is None:
-            os.environ.pop("GS_DIST_MODE", None)
-        else:
-            os.environ["GS_DIST_MODE"] = prev_mode
+    pick = [0, NP // 2, NP - 1]
+    asig = np.stack([ctx.download(d_asig + g * maa * 8, (maa,), np.uint64) for g in pick])
+    text = np.concatenate([synth_proteome(args.seed, g, Laa) for g in pick] + [np.zeros(16, np.uint8)])
+    ref = O.sketch_batch(O.params(kaa, maa, "super2", "aa"), text, np.arange(3, dtype=np.uint64) * np.uint64(pb), np.full(3, Laa, np.uint64), np.arange(4, dtype=np.uint64), nthreads=3)
+    c5 = {"workload": "AA k=7 s=24000 super2 (u64 signatures): %d proteomes x %.2f M residues resident in HBM (BASELINE configs[4]; iid residues, gs_synth_aa_dev)" % (NP, Laa / 1e6),
+          "proteomes": NP, "kmers_per_sec": float(Laa - kaa + 1) * NP / best, "proteomes_per_sec": NP / best, "wall_ms": best * 1e3,
+          "bit_exact_vs_oracle_sample": bool(np.array_equal(ref, asig)), "sample": pick}
     for p_ in (d_aa, d_ars, d_arl, d_ago, d_asig):
         ctx.free(p_)
+    c5["distance_gather_u64_m24000"] = c5_distance_leg(args, ctx, lib, chk, O)
     out["config4_aa_super2"] = c5
     # ---- (3) file-inclusive `request` input: the same 5 Mbp query genomes as gzip FASTA files on local disk -> gs_sketch_files
     nf = args.ingest_files
@@ -837,7 +878,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="request", choices=["sketch", "request"])
+    ap.add_argument("--workload", default="request", choices=["sketch", "request", "c5dist"], help="c5dist: only the configs[4] u64 distance leg (the PMC passes of tools/pmc_bench.sh run it)")
     ap.add_argument("--genomes", type=int, default=10000)
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--kmer", type=int, default=21)
@@ -846,7 +887,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512)
     # request workload (BASELINE configs[2])
     ap.add_argument("--db-genomes", type=int, default=300000)
-    ap.add_argument("--queries", type=int, default=10000, help="query genomes per GPU (resident in HBM)")
+    ap.add_argument("--queries", type=int, default=20000, help="query genomes per GPU resident in HBM: the steps rotate through queries / queries-per-step distinct sets")
     ap.add_argument("--queries-per-step", type=int, default=10000, help="query genomes per GPU per step (configs[2]: one request of 10k queries)")
     ap.add_argument("--knbn", type=int, default=50)
     ap.add_argument("--ef-search", type=int, default=5000, help="gsearch hard-codes 5000 (src/bin/gsearch.rs:893)")
@@ -855,6 +896,8 @@ def main():
     ap.add_argument("--scale-modify", type=float, default=0.25)
     ap.add_argument("--per-root", type=int, default=100)
     ap.add_argument("--build-chunk", type=int, default=8192)
+    ap.add_argument("--c5-proteomes", type=int, default=50000, help="proteomes of the configs[4] sketch leg (BASELINE: 50k)")
+    ap.add_argument("--c5-rows", type=int, default=50000, help="index rows of the configs[4] distance leg")
     ap.add_argument("--redundant-roots", type=int, default=30, help="families the queries of the `request_redundant` side leg are drawn from (0 = skip the leg)")
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     ap.add_argument("--verbose", action="store_true")
@@ -872,6 +915,12 @@ def main():
         run_selftest_launch(args, D)
     elif args.workload == "sketch":
         run_sketch(args, D)
+    elif args.workload == "c5dist":
+        import gsearch_amd as G
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        ctx = G.Context(D.local)
+        print(json.dumps({"config4_distance_leg": c5_distance_leg(args, ctx, ctx.L, G._lib.check, O)}))
     else:
         run_request(args, D)
     D.finish()

@@ -108,6 +108,7 @@ SYMBOLS = {
     "gs_comm_size": (_i, [_vp]),
     "gs_comm_allgather_topk_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "gs_synth_dna_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _vp]),
+    "gs_synth_aa_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _vp]),
     "gs_synth_dna_family_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _u64, C.c_double, C.c_double, _vp]),
     "gs_synth_sigs_dev": (_i, [_vp, _i, _u32, _u64, _u64, _u64, _u64, C.c_double, C.c_double, _vp]),
 }

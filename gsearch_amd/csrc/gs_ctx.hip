@@ -280,6 +280,23 @@ __global__ void k_synth_dna(uint64_t seed, uint64_t g0, uint64_t ng, uint64_t wo
         out[i] = x;
     }
 }
+// proteome g, 8 residues per word: residue j of word w = "ACDEFGHIKLMNPQRSTVWY"[byte j of synth_word(seed ^ 0xAA5EED, g, w) % 20]
+__global__ void k_synth_aa(uint64_t seed, uint64_t g0, uint64_t ng, uint64_t words_per, uint64_t *out)
+{
+    const uint64_t total = ng * words_per;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t g = i / words_per, w = i % words_per;
+        const uint64_t x = synth_word(seed ^ 0xAA5EEDULL, g0 + g, w);
+        uint64_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t r = (uint32_t)((x >> (8 * j)) & 0xFF) % 20u;
+            const char *A = "ACDEFGHIKLMNPQRSTVWY";
+            o |= (uint64_t)(uint8_t)A[r] << (8 * j);
+        }
+        out[i] = o;
+    }
+}
 // genome g = root genome (hash(seed,g) mod n_roots) with iid substitutions at rate mu(g) ~ U[mu_lo, mu_hi]:
 // 16 random bits per base (12 decide, 4 pick one of the three other bases); roots are never emitted themselves.
 __global__ void k_synth_family(uint64_t seed, uint64_t g0, uint64_t ng, uint64_t words_per, uint64_t len, uint64_t n_roots, double mu_lo,
@@ -341,6 +358,16 @@ int gs_synth_dna_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_
     uint64_t wp = (len + 31) / 32;
     if (ng * wp == 0) return GS_OK;
     hipLaunchKernelGGL(gs::k_synth_dna, dim3(c->n_cu * 8), dim3(256), 0, c->stream, seed, g0, ng, wp, len, (uint64_t *)seq_dev);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+int gs_synth_aa_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_t len, void *seq_dev)
+{
+    GS_REQUIRE(c && seq_dev, GS_ERR_INVALID, "null argument");
+    GS_CTX_LOCK(c);
+    const uint64_t wp = (len + 7) / 8;
+    if (ng * wp == 0) return GS_OK;
+    hipLaunchKernelGGL(gs::k_synth_aa, dim3(c->n_cu * 8), dim3(256), 0, c->stream, seed, g0, ng, wp, (uint64_t *)seq_dev);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

@@ -265,6 +265,9 @@ int  gs_comm_allgather_topk_dev(gs_comm *, const uint64_t *ids_dev, const float 
 /*   splitmix64 finaliser of (seed*0x9e3779b97f4a7c15 + g*0xbf58476d1ce4e5b9 + w)  (see gs_synth.hip) */
 int gs_synth_dna_dev(gs_ctx *, uint64_t seed, uint64_t first_genome, uint64_t n_genomes, uint64_t len_bases,
                      void *seq_dev /* n_genomes * ceil(len/32)*8 bytes */);
+/* proteome g of length L (residues of the 20-letter alphabet, one byte each; ceil(L/8)*8 bytes per proteome, back to back): residue j of
+ * word w = "ACDEFGHIKLMNPQRSTVWY"[byte j of the synth word of (seed ^ 0xAA5EED, g, w) mod 20] */
+int gs_synth_aa_dev(gs_ctx *, uint64_t seed, uint64_t first_proteome, uint64_t n_proteomes, uint64_t len_residues, void *seq_dev);
 /* related genomes: genome g = root genome number hash(seed,g) mod n_roots with iid substitutions at rate
  * mu(g) ~ U[mu_lo, mu_hi] (Jaccard to the root ~ p/(2-p), p=(1-mu)^k). Same layout as gs_synth_dna_dev. */
 int gs_synth_dna_family_dev(gs_ctx *, uint64_t seed, uint64_t first_genome, uint64_t n_genomes, uint64_t len_bases,

@@ -5,11 +5,12 @@ usage: pmc_condense.py <fetch_dir> <write_dir> <out_json> <out_raw_csv>"""
 import collections, csv, glob, json, os, re, sys
 
 fetch_dir, write_dir, out_json, out_raw = sys.argv[1:5]
-KERNELS = {"k_hnsw_search_dense": r"k_hnsw_search_dense", "k_hnsw_search": r"k_hnsw_search<", "k_match_join": r"k_match_join<", "k_sketch_min": r"k_sketch_min<",
-           "k_hamming_qxc": r"k_hamming_qxc<", "k_sketch_hll": r"k_sketch_hll<"}
+extra_dirs = sys.argv[5:]          # further counter directories (e.g. the passes over `bench.py --workload c5dist`)
+KERNELS = {"k_hnsw_search_dense": r"k_hnsw_search_dense", "k_hnsw_search_u64": r"k_hnsw_search<2>", "k_hnsw_search": r"k_hnsw_search<", "k_match_join": r"k_match_join<",
+           "k_sketch_min": r"k_sketch_min<", "k_hamming_qxc": r"k_hamming_qxc<", "k_sketch_hll": r"k_sketch_hll<"}
 rows = []
 vals = collections.defaultdict(list)        # (kernel, counter) -> [(grid, value)]
-for d in (fetch_dir, write_dir):
+for d in [fetch_dir, write_dir] + extra_dirs:
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
             for name, rx in KERNELS.items():
