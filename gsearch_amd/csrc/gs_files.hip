@@ -394,7 +394,7 @@ int gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t c
  * `capsid` records are skipped in both (dnafiles.rs:62-67,245). pio = files per group (`--pio`, files.rs:258-341; 0 -> 64),
  * n_threads = host threads that read / decompress / scan (0 -> hardware concurrency).
  * sig_out: HOST, n_files x sketch_size elements. n_records_out / n_symbols_out (optional, HOST, per file): records kept and bases /
- * residues that reached the sketcher. stats_out (optional, 4 doubles): host seconds spent reading+decompressing+scanning (summed over
+ * residues that reached the sketcher. stats_out (optional, 6 doubles, see include/gsearch_amd.h): host seconds spent reading+decompressing+scanning (summed over
  * threads), seconds the caller waited for PCIe copies, seconds in device pack + sketch, wall seconds of the call.
  */
 // The .gz files of a call are dealt between two pipelines as they go (see gs_sketch_files): the host pipeline claims them from the front of
@@ -479,6 +479,16 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
     void *cpin[LA_MAX + 2] = {}; size_t cpin_cap[LA_MAX + 2] = {};       // per slot, pinned: the members the DEVICE inflates
     for (int i = 0; i < NSLOT; i++) { cpin[i] = pool->p[16 + i]; cpin_cap[i] = pool->cap[16 + i]; }
     std::vector<uint64_t> dev_ctot(n_groups, 0), dev_gtot(n_groups, 0);    // per group: bytes of those members / of their texts
+    // A device group is also bounded in BYTES (a group of 6 x CUs eukaryote-sized or highly compressible members would ask for tens of GB): its
+    // texts live twice on the device (two parities) next to the packed output, its compressed bytes twice there and NSLOT times in pinned memory.
+    // Members beyond the budget stay with this pipeline's host decoders.
+    uint64_t dev_text_budget = (uint64_t)8 << 30, dev_comp_budget = (uint64_t)2 << 30;
+    if (dev_gzip) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) dev_text_budget = std::max<uint64_t>((uint64_t)256 << 20, std::min<uint64_t>((uint64_t)24 << 30, (uint64_t)fr / 8));
+        dev_comp_budget = std::max<uint64_t>((uint64_t)64 << 20, std::min<uint64_t>((uint64_t)4 << 30, dev_text_budget / 2));
+        if (const char *e = getenv("GS_GZIP_GROUP_MB")) { dev_text_budget = (uint64_t)std::max(1, atoi(e)) << 20; dev_comp_budget = std::max<uint64_t>(dev_text_budget / 2, (uint64_t)1 << 20); }
+    }
     int start_rc = GS_OK;
     // host stage of a group: its files are spread over n_threads threads (files.rs:327 par_iter over the group)
     auto start_group = [&](uint64_t g) {
@@ -514,7 +524,8 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
                     if (fz && fseek(fz, -4, SEEK_END) == 0 && fread(t4, 1, 4, fz) == 4) want = (uint64_t)t4[0] | (uint64_t)t4[1] << 8 | (uint64_t)t4[2] << 16 | (uint64_t)t4[3] << 24;
                     if (fz) fclose(fz);
                     if (want < (uint64_t)st.st_size / 2 || want > (uint64_t)st.st_size * 64 || want >= (1u << 30)) want = 0;       // not a plausible single member
-                    if (want && dev_gzip && dtot + (uint64_t)st.st_size < ((uint64_t)12 << 30)) {          // (k_inflate indexes the compressed words of a launch with 32 bits) the device's: member -> pinned compressed buffer, text -> the group's device-text region
+                    if (want && dev_gzip && dtot + (uint64_t)st.st_size < ((uint64_t)12 << 30) &&          // (k_inflate indexes the compressed words of a launch with 32 bits)
+                        gtot + want <= dev_text_budget && dtot + (uint64_t)st.st_size <= dev_comp_budget) {   // the device's: member -> pinned compressed buffer, text -> the group's device-text region
                         doff[f - f0] = dtot; dcap[f - f0] = (uint64_t)st.st_size; dtot += ((uint64_t)st.st_size + 63) / 64 * 64;
                         goff[f - f0] = gtot; cap[f - f0] = want; gtot += (want + 63) / 64 * 64;
                         continue;
@@ -533,7 +544,11 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
             if (dtot + 64 > cpin_cap[sl]) {
                 cpin[sl] = pool->ensure(16 + sl, (dtot + 64) * 5 / 4);
                 cpin_cap[sl] = pool->cap[16 + sl];
-                if (!cpin[sl]) { cpin_cap[sl] = 0; start_rc = GS_ERR_HIP; gs::set_error("hipHostMalloc of %zu bytes failed", (size_t)((dtot + 64) * 5 / 4)); }
+                if (!cpin[sl]) {          // no pinned room for the members: they stay with this pipeline's host decoders (host_stage's general path)
+                    cpin_cap[sl] = 0; (void)hipGetLastError();
+                    dev_ctot[g] = dev_gtot[g] = 0;
+                    for (uint64_t f = f0; f < f1; f++) if (dcap[f - f0]) { dcap[f - f0] = 0; cap[f - f0] = 0; }
+                }
             }
             const bool have_c = ctot == 0 || cbuf[sl].reserve(ctot + 64);
             for (uint64_t f = f0; f < f1; f++) {
@@ -641,6 +656,14 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
             for (auto &x : team) x.join();
         }
         int rc2;
+        if (dev_gtot[g] && (dtext[b].ensure(S.bytes + 64) != GS_OK || dcomp[b].ensure(dev_ctot[g] + 64) != GS_OK)) {
+            // the device has no room for this group's inflated texts: its members are handed to the host decoders (redo) instead of failing the call
+            (void)hipGetLastError();
+            for (uint64_t f = 0; f < blobs[g].size(); f++) if (blobs[g][f].gz_dev) { blobs[g][f].gz_dev = false; if (redo) redo->push_back(g * pio + f); }
+            dev_gtot[g] = dev_ctot[g] = 0;
+            S.bytes = total;
+            GS_REQUIRE(redo, GS_ERR_HIP, "device memory exhausted while staging gzip members");
+        }
         if ((rc2 = dtext[b].ensure(S.bytes + 64))) return rc2;
         if (total) GS_HIP_CHECK(hipMemcpyAsync(dtext[b].p, pinned[sl], total, hipMemcpyHostToDevice, copy_stream));
         if (dev_ctot[g]) {
@@ -821,6 +844,7 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     const bool dealing = dev_gzip && deal.n_gz >= 64 && ia.size() > n_free;
     double st_a[4] = {0, 0, 0, 0}, st_b[4] = {0, 0, 0, 0};
     if (ib.empty()) {
+        if (stats_out) stats_out[4] = stats_out[5] = 0.0;
         int rc = sketch_files_impl(c, p, paths, n_files, block_mode, pio, n_threads, sig_out, n_records_out, n_symbols_out, stats_out, false, nullptr, nullptr, 0, nullptr, false, 0);
         return rc;
     }
@@ -854,6 +878,9 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
     if (stats_out) {
         for (int i = 0; i < 3; i++) stats_out[i] = st_a[i] + st_b[i];
         stats_out[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count();
+        const uint64_t dev_members = dealing ? deal.back : ib.size();
+        stats_out[4] = (double)(dev_members - std::min<uint64_t>(dev_members, redo.size()));      // .gz members inflated by the device kernel
+        stats_out[5] = (double)redo.size();                // members it handed back to the host decoders (multi-member, trailer / CRC mismatch, no room)
     }
     return GS_OK;
 }

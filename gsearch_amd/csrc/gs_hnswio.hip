@@ -79,7 +79,17 @@ int gs_index_dump_hnswrs_ex(gs_index *ix, const char *basename, uint32_t flags)
     // PointId = (top layer, rank among the points of that layer in id order)
     std::vector<int32_t> rank(n); std::vector<std::vector<uint32_t>> by_layer(ML);
     for (uint64_t i = 0; i < n; i++) { rank[i] = (int32_t)by_layer[lv[i]].size(); by_layer[lv[i]].push_back((uint32_t)i); }
-    if (flags & GS_DUMP_TRUNCATE_255) { for (uint64_t i = 0; i < n; i++) if (d0[i] > 255) d0[i] = 255; }       // lists are (count, id)-ascending: the head is the 255 closest
+    if (flags & GS_DUMP_TRUNCATE_255) {
+        // keep the 255 CLOSEST: lists built here are (count, id)-ascending, lists that came in through gs_index_import / a loaded dump need not be
+        std::vector<uint64_t> keys;
+        for (uint64_t i = 0; i < n; i++) if (d0[i] > 255) {
+            keys.resize(d0[i]);
+            for (uint32_t t = 0; t < d0[i]; t++) keys[t] = ((uint64_t)c0[i * 2 * M + t] << 32) | n0[i * 2 * M + t];
+            std::sort(keys.begin(), keys.end());
+            for (uint32_t t = 0; t < 255; t++) { n0[i * 2 * M + t] = (uint32_t)keys[t]; c0[i * 2 * M + t] = (uint32_t)(keys[t] >> 32); }
+            d0[i] = 255;
+        }
+    }
     else for (uint64_t i = 0; i < n; i++)
         GS_REQUIRE(d0[i] <= 255, GS_ERR_UNSUPPORTED, "node %llu has %u layer-0 neighbours: hnsw_rs stores the count in one byte (dump with GS_DUMP_TRUNCATE_255, or use gs_index_save)", (unsigned long long)i, d0[i]);
     const std::string gname = std::string(basename) + ".hnsw.graph", dname = std::string(basename) + ".hnsw.data";

@@ -63,7 +63,7 @@ static __shared__ __attribute__((aligned(16))) uint8_t g_win[INF_WSIZE];
 // Canonical Huffman tables of one alphabet from its code lengths (RFC 1951 3.2.2): KIND 0 = literal/length (g_inf.lens[first ..]), 1 = distance,
 // 2 = code-length alphabet (g_inf.clens). Fills the root table (code length in bits 0-3, kind in 4-5, value from bit 8, extra-bit count from
 // bit 24; 0 = no such code), the per-length counts and the symbols sorted by (length, symbol) for the bit-by-bit walk of codes longer than the
-// root. Returns 0, or 1 when the lengths over-subscribe the code space.
+// root. Returns 0, or 1 when the lengths over-subscribe the code space or leave it incomplete (zlib's rule).
 template <int KIND>
 __device__ __noinline__ int inf_build(uint32_t first, uint32_t nsym)
 {
@@ -94,6 +94,13 @@ __device__ __noinline__ int inf_build(uint32_t first, uint32_t nsym)
     }
     if (lane == 0) cnt[0] = 0;
     if (left < 0) return 1;
+    // an INCOMPLETE set is refused too, as zlib (inftrees.c) and libdeflate do - the member then goes to the host decoder, which reports the corrupt
+    // stream: whether a malformed file is accepted must not depend on which pipeline the dealer handed it to. zlib's one exception is kept: a
+    // literal/length or distance alphabet with a single code of length 1, or no code at all
+    int maxlen = 0;
+#pragma unroll
+    for (int l = 1; l < 16; l++) if (c[l]) maxlen = l;
+    if (left > 0 && (KIND == 2 || maxlen > 1)) return 1;
     __syncthreads();
     uint32_t run[16];
 #pragma unroll
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
     INF_REFILL(B);
     INF_TAKE(B, (uint32_t)(st.in_off & 3) * 8);
     uint32_t pos = 0, status = INF_OK, blocks = 0;
+    uint32_t synced = 0;                  // GWIN: every byte of the text below this position is known to have reached L2
     auto flush_half = [&](uint32_t base) {
         if (GWIN) return;
 #pragma unroll 4
@@ -301,8 +309,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
             const uint32_t src0 = pos - dist;
             if (GWIN) {
                 // the source may be bytes this wave stored a moment ago: a store is acknowledged (vmcnt) once L2 has it, and the load below
-                // goes to L2 (agent scope: not served by the CU's L1, which does not see L2 writes)
-                if (dist < 2048) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                // goes to L2 (agent scope: not served by the CU's L1, which does not see L2 writes). Loads may overtake this wave's own stores,
+                // so every byte at or beyond `synced` (the text position at the last wait) counts as possibly in flight: wait exactly when the
+                // source reaches into that range
+                if (src0 + (dist >= len ? len : dist) > synced) { __builtin_amdgcn_s_waitcnt(0x0F70); synced = pos; }          // vmcnt(0)
                 for (uint32_t i = lane; i < len; i += 64) {
                     const uint8_t b = __hip_atomic_load(out + src0 + (dist >= len ? i : i % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     out[pos + i] = b;

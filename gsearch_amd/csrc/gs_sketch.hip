@@ -1825,7 +1825,15 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     if (list.empty()) return GS_OK;
     // cold genomes (few k-mers per register): exact walks with the permutation in per-lane global scratch
     const uint32_t nc = (uint32_t)list.size();
-    const uint32_t cw = std::min<uint32_t>(nc, (uint32_t)c->n_cu);
+    // one workgroup needs 2 x 4 x m x HL_CT bytes of per-lane scratch (205 MB at m = 100 000): as many workgroups as a quarter of the free memory
+    // (at most 16 GB) holds - they pull the cold genomes from a shared counter, fewer workgroups only take more turns
+    uint32_t cw = std::min<uint32_t>(nc, (uint32_t)c->n_cu);
+    {
+        size_t fr = 0, tot = 0;
+        uint64_t budget = (uint64_t)4 << 30;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<uint64_t>((uint64_t)16 << 30, std::max<uint64_t>((uint64_t)fr / 4, (uint64_t)64 << 20));
+        cw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cw, budget / ((uint64_t)8 * m * HL_CT)));
+    }
     PoolBuf dl(c, 26), lq(c, 27), lp(c, 37);
     if ((rc = dl.alloc(4 * (size_t)nc))) return rc;
     if ((rc = lq.alloc((size_t)4 * cw * m * HL_CT))) return rc;

@@ -130,8 +130,9 @@ int  gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t 
  * n_threads host threads (0 -> the CPUs the process may use: affinity mask and cgroup quota) while the previous group crosses PCIe from pinned memory on a copy stream and the one before is
  * filtered / 2-bit packed / sketched on the context's stream. block_mode 0: k-mers never span records (process_file_by_sequence,
  * dnafiles.rs:43-107); 1: --block, records concatenated (process_file_in_one_block, dnafiles.rs:200-262); `capsid` records skipped.
- * sig_out: HOST n_files x sketch_size. Optional per-file n_records_out / n_symbols_out (HOST) and stats_out[4] = {host read+decode+scan
- * seconds summed over threads, seconds waited for PCIe, seconds in device pack + sketch, wall seconds}. */
+ * sig_out: HOST n_files x sketch_size. Optional per-file n_records_out / n_symbols_out (HOST) and stats_out[6] = {host read+decode+scan
+ * seconds summed over threads, seconds waited for PCIe, seconds in device pack + sketch, wall seconds, .gz members inflated by the device
+ * kernel, members the device path handed back to the host decoders (multi-member files, a trailer / CRC-32 that does not check, no room)}. */
 int  gs_sketch_files(gs_ctx *, const gs_sketch_params *, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio,
                      uint32_t n_threads, void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out);
 /* gzip members inflated ON the device (gs_inflate.hip; the .gz path of gs_sketch_files, exposed for parity tests against zlib - the
