@@ -573,7 +573,23 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
     auto wait_group = [&](uint64_t g) { std::unique_lock<std::mutex> lk(team.m); team.done.wait(lk, [&] { return team.left[g] == 0; }); };
     hipStream_t copy_stream = nullptr, inflate_stream = nullptr;
     GS_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    if (dev_gzip && hipStreamCreateWithFlags(&inflate_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(copy_stream); gs::set_error("hipStreamCreate failed"); return GS_ERR_HIP; }
+    if (dev_gzip) {
+        // GS_INFLATE_FREE_CUS=n (measurement aid, default 0): a CU mask keeps n CUs out of the inflate stream's reach. Tried in round 4 against the
+        // theory that the HOST pipeline's pack / sketch launches queue behind the resident inflate workgroups: 8192 x 5 Mbp gzip -6 files ran at
+        // 3484 / 3480 / 2320 / 2856 genomes/s with 0 / 16 / 32 / 64 CUs kept free (profiles/r04_ingest_cumask.log) - residency is not what couples
+        // the two pipelines; the inflate kernel simply loses the CUs it is denied.
+        hipError_t se = hipErrorUnknown;
+        const char *fe = getenv("GS_INFLATE_FREE_CUS");
+        const int free_cus = fe ? atoi(fe) : 0;
+        if (free_cus > 0 && free_cus < c->n_cu) {
+            std::vector<uint32_t> cumask((c->n_cu + 31) / 32, 0xFFFFFFFFu);
+            for (int i = 0; i < free_cus; i++) cumask[i / 32] &= ~(1u << (i % 32));
+            if (c->n_cu % 32) cumask.back() &= (1u << (c->n_cu % 32)) - 1;
+            se = hipExtStreamCreateWithCUMask(&inflate_stream, (uint32_t)cumask.size(), cumask.data());
+            if (se != hipSuccess) { (void)hipGetLastError(); inflate_stream = nullptr; }
+        }
+        if (se != hipSuccess && hipStreamCreateWithFlags(&inflate_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(copy_stream); gs::set_error("hipStreamCreate failed"); return GS_ERR_HIP; }
+    }
     hipEvent_t ev[2] = {nullptr, nullptr}, iev[2] = {nullptr, nullptr};
     // the device's .gz members of group g are inflated on their own stream as soon as they are on the device - under the crc / scan / pack / sketch
     // of group g - 1; per buffer parity: descriptors, the files they belong to, device copies, pinned results

@@ -706,7 +706,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     const uint32_t efs = ef > knbn ? ef : knbn;
     const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
     uint32_t st_pops = 0, st_acc = 0, st_p1 = 0, st_p2 = 0;                 // work counters (workgroup-uniform): pops / accepting pops / pops before dmax reached tau, of this workgroup (< 2^32)
-    constexpr bool PHASE2 = VLDS;
+    constexpr bool PHASE2 = true;       // (round 4: also with the visited bitmap in global memory - indexes beyond ~600 k nodes: test-and-set through L2 atomics)
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;         // capacity of N: >= 2M (an empty N takes a whole expansion), one key per lane in its merge
@@ -1911,7 +1911,10 @@ static bool dense_vis_in_lds(const gs_index *ix, uint32_t knbn, uint32_t maxdeg)
     const char *e = getenv("GS_DENSE_VIS");
     if (e && !strcmp(e, "global")) return false;
     if (e && !strcmp(e, "lds")) return l <= cap;
-    return l <= cap / 2;
+    // one workgroup per CU with the bitmap in LDS still beats the global bitmap by far (300 k nodes, 10 k queries: 49 ms at three per CU,
+    // ~100 ms at one, 446 ms with the bitmap in global memory - every neighbour a memory-side atomic; profiles/r04_trav_placements.txt):
+    // the LDS placement is kept up to ~1.08 M nodes
+    return l <= cap;
 }
 static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t mat_ld, uint64_t *ids, float *dist,
                                uint32_t *count, uint64_t *evals)
