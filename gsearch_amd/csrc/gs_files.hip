@@ -241,6 +241,11 @@ struct FileBlob {       // one file after the host stage
     // .gz inflated ON the device (gs_inflate.hip): the member goes to the pinned compressed buffer (src), its text will be produced at
     // g_off of the group's device-text region; gz_dev is set by the host stage when the member is one the device path takes
     bool want_dev = false, gz_dev = false; size_t gz_hdr = 0, gz_len = 0; uint64_t g_off = 0, g_cap = 0;
+    // BGZF (bgzip: a .gz file of independent <= 64 KB members, each carrying its compressed size in a 'BC' extra field): the device inflates every
+    // member with its own wavefront. want_bgzf: a candidate (its text size is only known once the members have been walked: g_cap is set by the
+    // host stage, g_off when the group is staged); blocks: the members with data
+    struct GzBlock { uint32_t in_off, in_len, out_off, isize, trailer; };
+    bool want_bgzf = false; std::vector<GzBlock> blocks;
     std::vector<uint64_t> sb, se; int rc = GS_OK; std::string err; double read_s = 0;
 };
 static bool has_compressed_suffix(const char *path)
@@ -262,6 +267,43 @@ static int scan_records(const uint8_t *text, size_t n, std::vector<uint64_t> &sb
     sb.resize(nr); se.resize(nr);
     return GS_OK;
 }
+// BGZF signature of a gzip member header: FEXTRA set and a 'B','C' subfield of two bytes (SAM/BAM spec 4.1); returns the member's total size
+// (BSIZE + 1) and its header length, or 0
+static size_t bgzf_member(const uint8_t *p, size_t n, size_t *hdr_len)
+{
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0) || !(p[3] & 4)) return 0;
+    const size_t xlen = (size_t)p[10] | (size_t)p[11] << 8;
+    if (12 + xlen > n) return 0;
+    size_t bsize = 0;
+    for (size_t q = 12; q + 4 <= 12 + xlen;) {
+        const size_t slen = (size_t)p[q + 2] | (size_t)p[q + 3] << 8;
+        if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) bsize = ((size_t)p[q + 4] | (size_t)p[q + 5] << 8) + 1;
+        q += 4 + slen;
+    }
+    if (!bsize || (p[3] & (8 | 16 | 2))) return 0;              // (bgzip writes no name / comment / header CRC; such members go the host way)
+    *hdr_len = 12 + xlen;
+    return bsize >= *hdr_len + 8 && bsize <= n ? bsize : 0;
+}
+// a whole file as BGZF members: fills b->blocks / b->g_cap, false when the file is not exactly a sequence of BGZF members
+static bool bgzf_walk(const uint8_t *p, size_t n, FileBlob *b)
+{
+    b->blocks.clear();
+    uint64_t total = 0;
+    size_t pos = 0;
+    while (pos < n) {
+        size_t hdr = 0;
+        const size_t bs = bgzf_member(p + pos, n - pos, &hdr);
+        if (!bs) return false;
+        const uint8_t *t = p + pos + bs - 4;
+        const uint32_t isize = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        if (isize > 65536 || total + isize >= ((uint64_t)1 << 30)) return false;
+        if (isize) b->blocks.push_back({(uint32_t)(pos + hdr), (uint32_t)(bs - hdr), (uint32_t)total, isize, (uint32_t)(pos + bs - 8)});
+        total += isize;
+        pos += bs;
+    }
+    b->g_cap = total;
+    return true;
+}
 // Host stage of one file. A file without a compression suffix is read straight into its place in the pinned staging buffer (b->dst,
 // sized from stat): no intermediate allocation - hundreds of threads faulting fresh pages in contend on the process's mmap lock, which
 // is what limited the group size - and no second copy. Compressed files (by suffix, or by magic bytes after all) decompress into b->text.
@@ -280,11 +322,14 @@ static void host_stage(const char *path, FileBlob *b)
             const bool more = got == b->src_cap && fgetc(f) != EOF;
             fclose(f);
             const size_t h = more ? 0 : gzip_header_len(b->src, got);
-            if (h) {
+            if (h && !b->want_bgzf) {
                 const uint8_t *t = b->src + got - 4;
                 const uint64_t isize = (uint64_t)t[0] | (uint64_t)t[1] << 8 | (uint64_t)t[2] << 16 | (uint64_t)t[3] << 24;
-                if (isize == b->g_cap) { b->gz_dev = true; b->gz_hdr = h; b->gz_len = got; }
-            }
+                if (isize == b->g_cap) {
+                    b->gz_dev = true; b->gz_hdr = h; b->gz_len = got;
+                    b->blocks.assign(1, {(uint32_t)h, (uint32_t)(got - h), 0u, (uint32_t)isize, (uint32_t)(got - 8)});
+                }
+            } else if (h && b->want_bgzf && bgzf_walk(b->src, got, b)) { b->gz_dev = true; b->gz_hdr = h; b->gz_len = got; }
         }
         if (b->gz_dev) { b->read_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); return; }
         direct = false;                                             // the file changed under us or is not plain gzip: the general path below
@@ -512,7 +557,23 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         {   // size the plain files and give each its place in this group's pinned buffer (its previous user, group g-4, is long done)
             const int sl = (int)(g % NSLOT);
             std::vector<uint64_t> off(f1 - f0, 0), cap(f1 - f0, 0), coff(f1 - f0, 0), ccap(f1 - f0, 0), doff(f1 - f0, 0), dcap(f1 - f0, 0), goff(f1 - f0, 0);
-            uint64_t tot = 0, ctot = 0, dtot = 0, gtot = 0;
+            std::vector<uint8_t> isbg(f1 - f0, 0);
+            uint64_t tot = 0, ctot = 0, dtot = 0, gtot = 0, gtot_bgzf = 0;
+            auto fz2_is_bgzf = [](const char *path) {               // the first member's header carries the 'BC' extra field
+                uint8_t h[64]; size_t hl = 0;
+                FILE *fz = fopen(path, "rb");
+                const size_t got = fz ? fread(h, 1, sizeof h, fz) : 0;
+                if (fz) fclose(fz);
+                if (got < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+                const size_t xlen = (size_t)h[10] | (size_t)h[11] << 8;
+                (void)hl;
+                for (size_t q = 12; q + 6 <= std::min<size_t>(12 + xlen, got);) {
+                    const size_t slen = (size_t)h[q + 2] | (size_t)h[q + 3] << 8;
+                    if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) return true;
+                    q += 4 + slen;
+                }
+                return false;
+            };
             for (uint64_t f = f0; f < f1; f++) {
                 struct stat st;
                 if (stat(paths[f], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) continue;
@@ -524,6 +585,13 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
                     if (fz && fseek(fz, -4, SEEK_END) == 0 && fread(t4, 1, 4, fz) == 4) want = (uint64_t)t4[0] | (uint64_t)t4[1] << 8 | (uint64_t)t4[2] << 16 | (uint64_t)t4[3] << 24;
                     if (fz) fclose(fz);
                     if (want < (uint64_t)st.st_size / 2 || want > (uint64_t)st.st_size * 64 || want >= (1u << 30)) want = 0;       // not a plausible single member
+                    if (!want && dev_gzip && fz2_is_bgzf(paths[f]) && (uint64_t)st.st_size < ((uint64_t)1 << 30) && dtot + (uint64_t)st.st_size < ((uint64_t)12 << 30) &&
+                        gtot_bgzf + 4 * (uint64_t)st.st_size <= dev_text_budget && dtot + (uint64_t)st.st_size <= dev_comp_budget) {
+                        // bgzip: the members are found by the host stage, the text gets its place when the group is staged (4x the file as a budget guess)
+                        doff[f - f0] = dtot; dcap[f - f0] = (uint64_t)st.st_size; dtot += ((uint64_t)st.st_size + 63) / 64 * 64;
+                        gtot_bgzf += 4 * (uint64_t)st.st_size; isbg[f - f0] = 1;
+                        continue;
+                    }
                     if (want && dev_gzip && dtot + (uint64_t)st.st_size < ((uint64_t)12 << 30) &&          // (k_inflate indexes the compressed words of a launch with 32 bits)
                         gtot + want <= dev_text_budget && dtot + (uint64_t)st.st_size <= dev_comp_budget) {   // the device's: member -> pinned compressed buffer, text -> the group's device-text region
                         doff[f - f0] = dtot; dcap[f - f0] = (uint64_t)st.st_size; dtot += ((uint64_t)st.st_size + 63) / 64 * 64;
@@ -540,7 +608,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
                 pinned_cap[sl] = pool->cap[sl];
                 if (!pinned[sl]) { pinned_cap[sl] = 0; start_rc = GS_ERR_HIP; gs::set_error("hipHostMalloc of %zu bytes failed", (size_t)((tot + 64) * 5 / 4)); }
             }
-            dev_ctot[g] = dtot; dev_gtot[g] = gtot;
+            dev_ctot[g] = dtot; dev_gtot[g] = gtot; (void)gtot_bgzf;
             if (dtot + 64 > cpin_cap[sl]) {
                 cpin[sl] = pool->ensure(16 + sl, (dtot + 64) * 5 / 4);
                 cpin_cap[sl] = pool->cap[16 + sl];
@@ -554,6 +622,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
             for (uint64_t f = f0; f < f1; f++) {
                 gs::FileBlob &fb = blobs[g][f - f0];
                 fb.want_dev = dcap[f - f0] != 0 && cpin[sl] != nullptr;
+                fb.want_bgzf = fb.want_dev && isbg[f - f0];
                 if (fb.want_dev) {
                     fb.dst = nullptr; fb.dst_cap = 0;
                     fb.src = (uint8_t *)cpin[sl] + doff[f - f0]; fb.src_cap = dcap[f - f0]; fb.g_off = goff[f - f0]; fb.g_cap = cap[f - f0];
@@ -593,10 +662,11 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
     hipEvent_t ev[2] = {nullptr, nullptr}, iev[2] = {nullptr, nullptr};
     // the device's .gz members of group g are inflated on their own stream as soon as they are on the device - under the crc / scan / pack / sketch
     // of group g - 1; per buffer parity: descriptors, the files they belong to, device copies, pinned results
-    std::vector<gs::InflateStream> ist[2]; std::vector<uint64_t> iwho[2]; gs::DevBuf ids[2], idr[2]; bool ilaunched[2] = {false, false};
+    std::vector<gs::InflateStream> ist[2]; std::vector<uint64_t> iwho[2]; std::vector<const uint8_t *> itrail[2]; gs::DevBuf ids[2], idr[2]; bool ilaunched[2] = {false, false};
     gs::DevBuf dtext[2], dcomp[2], dout, drs, drl, dgo, dsig;
     std::vector<uint8_t> rows_tmp;
     double read_s = 0, copy_wait_s = 0, dev_s = 0;
+    double dsub[4] = {0, 0, 0, 0};           // GS_INGEST_TIMES: inside the device stage - wait for the inflate / crc / record scan / pack + sketch + results
     // per staged group: text bytes (H2D part, then the device-inflated texts from gbase on), record ranges per file, then flattened
     struct Staged { uint64_t bytes = 0, gbase = 0; std::vector<std::vector<uint64_t>> fsb, fse; std::vector<uint64_t> sb, se, frec; } staged[2];
     auto cleanup = [&]() {
@@ -650,6 +720,12 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
             for (size_t r = 0; r < fb.sb.size(); r++) { S.fsb[f].push_back(base[f] + fb.sb[r]); S.fse[f].push_back(base[f] + fb.se[r]); }
         }
         S.gbase = (total + 63) / 64 * 64;
+        for (size_t f = 0; f < blobs[g].size(); f++) {              // bgzip files: their text size is known now
+            auto &fb = blobs[g][f];
+            if (!fb.gz_dev || !fb.want_bgzf) continue;
+            if (dev_gtot[g] + fb.g_cap > 2 * dev_text_budget) { fb.gz_dev = false; if (redo) redo->push_back(g * pio + f); continue; }      // (far beyond the guess: host decoders)
+            fb.g_off = dev_gtot[g]; dev_gtot[g] += (fb.g_cap + 63) / 64 * 64;
+        }
         S.bytes = dev_gtot[g] ? S.gbase + dev_gtot[g] : total;
         if (total + 64 > pinned_cap[sl]) {                          // decompressed texts do not fit behind the plain files: grow, keep what is there
             void *np = nullptr; const size_t ncap = (total + 64) * 5 / 4;
@@ -695,12 +771,16 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         ilaunched[b] = false;
         if (!dev_gtot[g]) return GS_OK;
         Staged &S = staged[b];
-        ist[b].clear(); iwho[b].clear();
+        ist[b].clear(); iwho[b].clear(); itrail[b].clear();
         for (uint64_t f = 0; f < blobs[g].size(); f++) {
             const auto &fb = blobs[g][f];
             if (!fb.gz_dev) continue;
-            ist[b].push_back({(uint64_t)(fb.src - (uint8_t *)cpin[sl]) + fb.gz_hdr, fb.gz_len - fb.gz_hdr, S.gbase + fb.g_off, fb.g_cap});
-            iwho[b].push_back(f);
+            const uint64_t cbase = (uint64_t)(fb.src - (uint8_t *)cpin[sl]);
+            for (const auto &blk : fb.blocks) {                        // one wavefront per member: a single-member file has one, a bgzip file one per <= 64 KB
+                ist[b].push_back({cbase + blk.in_off, blk.in_len, S.gbase + fb.g_off + blk.out_off, blk.isize});
+                iwho[b].push_back(f);
+                itrail[b].push_back(fb.src + blk.trailer);
+            }
         }
         const size_t ns = ist[b].size();
         if (!ns) return GS_OK;
@@ -725,6 +805,8 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         GS_HIP_CHECK(hipEventSynchronize(ev[b]));
         copy_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         t0 = std::chrono::steady_clock::now();
+        auto tl = t0;
+        auto sub = [&](int k) { const auto now = std::chrono::steady_clock::now(); dsub[k] += std::chrono::duration<double>(now - tl).count(); tl = now; };
         int rc2;
         if (dev_gtot[g]) {          // inflate the group's .gz members on the device, check them against their trailers, find their records
             std::vector<gs::InflateStream> &st = ist[b]; std::vector<uint64_t> who = iwho[b];
@@ -734,27 +816,42 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
                 memcpy(res.data(), (const uint8_t *)pool->p[32 + b] + sizeof(gs::InflateStream) * st.size(), sizeof(gs::InflateResult) * st.size());
                 ilaunched[b] = false;
             }
+            sub(0);
+            // every member: inflated completely, to its ISIZE, and its CRC-32 checks; a file is good when all of its members are
             std::vector<uint64_t> toff(st.size()), tlen(st.size());
+            std::vector<uint8_t> bad(nf, 0);
             for (size_t k = 0; k < st.size(); k++) {
                 const bool ok = res[k].status == 0 && res[k].in_used + 8 == st[k].in_len && res[k].out_len == st[k].out_cap;
                 toff[k] = st[k].out_off; tlen[k] = ok ? res[k].out_len : 0;
-                if (!ok) who[k] = ~(uint64_t)0 - who[k];            // marked: host path
+                if (!ok) {
+                    if (!bad[who[k]] && getenv("GS_INGEST_VERBOSE"))
+                        fprintf(stderr, "[GS_INGEST] %s: member %zu not taken (status %u, consumed %llu of %llu - 8, produced %llu of %llu)\n", paths[f0 + who[k]], k, res[k].status,
+                                (unsigned long long)res[k].in_used, (unsigned long long)st[k].in_len, (unsigned long long)res[k].out_len, (unsigned long long)st[k].out_cap);
+                    bad[who[k]] = 1;
+                }
             }
             std::vector<uint32_t> crc(st.size());
             if ((rc2 = gs::crc32_texts_dev(c, dtext[b].p, toff.data(), tlen.data(), (uint32_t)st.size(), crc.data()))) return rc2;
+            sub(1);
             for (size_t k = 0; k < st.size(); k++) {
-                const bool marked = who[k] > nf;
-                const uint64_t f = marked ? ~(uint64_t)0 - who[k] : who[k];
-                const uint8_t *t = blobs[g][f].src + blobs[g][f].gz_len - 8;
+                const uint8_t *t = itrail[b][k];
                 const uint32_t want = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
-                if (marked || crc[k] != want) { tlen[k] = 0; if (redo) redo->push_back(f0 + f); }
+                if (tlen[k] && crc[k] != want) {
+                    if (!bad[who[k]] && getenv("GS_INGEST_VERBOSE")) fprintf(stderr, "[GS_INGEST] %s: member %zu CRC-32 %08x, trailer says %08x\n", paths[f0 + who[k]], k, crc[k], want);
+                    bad[who[k]] = 1;
+                }
+            }
+            std::vector<uint64_t> files, foff, flen;                 // the device's files of this group, their texts (a bgzip file: its members end to end)
+            for (uint64_t f = 0; f < nf; f++) {
+                const auto &fb = blobs[g][f];
+                if (!fb.gz_dev) continue;
+                files.push_back(f); foff.push_back(S.gbase + fb.g_off); flen.push_back(bad[f] ? 0 : fb.g_cap);
+                if (bad[f] && redo) redo->push_back(f0 + f);
             }
             std::vector<std::vector<uint64_t>> gsb, gse;
-            if ((rc2 = gs::fasta_scan_dev(c, dtext[b].p, toff.data(), tlen.data(), (uint32_t)st.size(), gsb, gse))) return rc2;
-            for (size_t k = 0; k < st.size(); k++) {
-                const uint64_t f = who[k] > nf ? ~(uint64_t)0 - who[k] : who[k];
-                S.fsb[f] = std::move(gsb[k]); S.fse[f] = std::move(gse[k]);
-            }
+            if ((rc2 = gs::fasta_scan_dev(c, dtext[b].p, foff.data(), flen.data(), (uint32_t)files.size(), gsb, gse))) return rc2;
+            for (size_t k = 0; k < files.size(); k++) { S.fsb[files[k]] = std::move(gsb[k]); S.fse[files[k]] = std::move(gse[k]); }
+            sub(2);
         }
         S.sb.clear(); S.se.clear(); S.frec.assign(1, 0);
         for (uint64_t f = 0; f < nf; f++) {
@@ -795,6 +892,7 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
             GS_HIP_CHECK(hipMemcpyAsync(rows_tmp.data(), dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
         } else GS_HIP_CHECK(hipMemcpyAsync((uint8_t *)sig_out + f0 * m * esz, dsig.p, nf * m * esz, hipMemcpyDeviceToHost, c->stream));
         GS_HIP_CHECK(gs::stream_wait(c));
+        sub(3);
         for (uint64_t f = 0; f < nf; f++) {
             uint64_t sym = 0;
             if (!block_mode) for (uint64_t r = S.frec[f]; r < S.frec[f + 1]; r++) sym += rl[r]; else sym = rl2[f];
@@ -824,7 +922,8 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
     { auto t0 = std::chrono::steady_clock::now(); cleanup(); tick(4, t0); }
     if (getenv("GS_INGEST_TIMES"))
         fprintf(stderr, "[GS_INGEST_TIMES] %s pipeline, %llu groups: stage %.3f s, inflate launch %.3f, start_group %.3f, device stage %.3f, cleanup %.3f\n", dev_gzip ? "device" : "host",
-                (unsigned long long)n_groups_eff, tsec[0], tsec[1], tsec[2], tsec[3], tsec[4]);
+                (unsigned long long)n_groups_eff, tsec[0], tsec[1], tsec[2], tsec[3], tsec[4]),
+        fprintf(stderr, "[GS_INGEST_TIMES]   device stage: copy wait %.3f s, inflate wait %.3f, crc %.3f, record scan %.3f, pack + sketch + results %.3f\n", copy_wait_s, dsub[0], dsub[1], dsub[2], dsub[3]);
 #undef GS_FILES_FAIL
     if (stats_out) {
         stats_out[0] = read_s; stats_out[1] = copy_wait_s; stats_out[2] = dev_s;

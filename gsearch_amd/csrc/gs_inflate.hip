@@ -399,6 +399,13 @@ __global__ __launch_bounds__(CRC_T) void k_crc32_chunks(const uint8_t *__restric
     if (t == 0) out[blockIdx.x] = part[0];
 }
 
+// The LDS-window form writes its text out in 16-byte vectors (whole ones, also at the end of the text): fine for texts that start on a 64-byte
+// boundary with padding behind them, wrong for the members of a bgzip file, which lie end to end - those take the form with byte-exact stores
+static bool inflate_needs_byte_stores(const InflateStream *st, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) if (st[i].out_off & 15) return true;
+    return false;
+}
 int inflate_streams_dev(gs_ctx *c, const void *comp_dev, const InflateStream *streams, uint32_t n, void *out_dev, InflateResult *results)
 {
     if (n == 0) return GS_OK;
@@ -408,7 +415,7 @@ int inflate_streams_dev(gs_ctx *c, const void *comp_dev, const InflateStream *st
     GS_HIP_CHECK(hipMemcpyAsync(ds.p, streams, sizeof(InflateStream) * n, hipMemcpyHostToDevice, c->stream));
     // up to four members per CU: the LDS-window form (lowest latency); more: the window-less form, whose members interleave five times as densely
     const char *w = getenv("GS_INFLATE_WINDOW");
-    const bool gwin = w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu;
+    const bool gwin = inflate_needs_byte_stores(streams, n) || (w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu);
     if (gwin) hipLaunchKernelGGL(k_inflate<true>, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)comp_dev, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
     else hipLaunchKernelGGL(k_inflate<false>, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)comp_dev, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
     GS_HIP_CHECK(hipGetLastError());
@@ -425,7 +432,7 @@ int inflate_streams_launch(gs_ctx *c, hipStream_t stream, const void *comp_dev, 
     if (n == 0) return GS_OK;
     GS_HIP_CHECK(hipMemcpyAsync(ds_dev, streams_pinned, sizeof(InflateStream) * n, hipMemcpyHostToDevice, stream));
     const char *w = getenv("GS_INFLATE_WINDOW");
-    const bool gwin = w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu;
+    const bool gwin = inflate_needs_byte_stores(streams_pinned, n) || (w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu);
     if (gwin) hipLaunchKernelGGL(k_inflate<true>, dim3(n), dim3(64), 0, stream, (const uint32_t *)comp_dev, (const InflateStream *)ds_dev, n, (uint8_t *)out_dev, (InflateResult *)dr_dev);
     else hipLaunchKernelGGL(k_inflate<false>, dim3(n), dim3(64), 0, stream, (const uint32_t *)comp_dev, (const InflateStream *)ds_dev, n, (uint8_t *)out_dev, (InflateResult *)dr_dev);
     GS_HIP_CHECK(hipGetLastError());

@@ -122,6 +122,11 @@ int hamming_blocks(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t stri
                    uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out);
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);
 
+// gs_radix.hip: stable LSD radix sort of 64-bit keys (bits [0, endbit)) between two buffers, and run-length encoding of a sorted array
+size_t radix_scratch_bytes(uint64_t n);
+int radix_sort_u64(gs_ctx *c, uint64_t *keys, uint64_t *alt, uint64_t n, int endbit, void *scratch, uint64_t **sorted_out);
+int run_length_encode_u64(gs_ctx *c, const uint64_t *sorted, uint64_t n, uint64_t *uniq, uint32_t *len, uint32_t *nruns_dev, uint32_t *pos, void *scratch);
+
 inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }
 inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 

@@ -15,7 +15,6 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
-#include <hipcub/hipcub.hpp>
 #include "gs_internal.hpp"
 #include "gs_spec.hpp"
 
@@ -1517,17 +1516,17 @@ static int run_prob_sorted(gs_ctx *c, const gs_sketch_params *p, const uint8_t *
             }
             int endbit = 64;
             if (vbits < 64) { endbit = (int)vbits; uint64_t x = ng - 1; while (x) { endbit++; x >>= 1; } if (endbit > 64) endbit = 64; }
-            size_t tb = 0;
-            GS_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, vals.as<uint64_t>(), sorted.as<uint64_t>(), (int)T, 0, endbit, c->stream));
-            if ((rc = tmp.alloc(tb))) return rc;
-            GS_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, vals.as<uint64_t>(), sorted.as<uint64_t>(), (int)T, 0, endbit, c->stream));
-            // distinct elements + multiplicities (re-use `vals` for the unique keys)
+            // multiplicities = run lengths of the sorted (genome, value) keys: own LSD radix sort + run-length encoding (gs_radix.hip)
+            PoolBuf pos(c, 47);
+            if ((rc = tmp.alloc(radix_scratch_bytes(T)))) return rc;
+            if ((rc = pos.alloc(4 * T))) return rc;
+            uint64_t *srt = nullptr;
+            if ((rc = radix_sort_u64(c, vals.as<uint64_t>(), sorted.as<uint64_t>(), T, endbit, tmp.p, &srt))) return rc;
+            // distinct elements + multiplicities: the unique keys go to the buffer the sorted keys are NOT in, which the rest of the pass calls `vals`
+            if (srt == vals.as<uint64_t>()) { std::swap(vals.p, sorted.p); std::swap(vals.bytes, sorted.bytes); }
             if ((rc = ucnt.alloc(4 * T))) return rc;
             if ((rc = nruns.alloc(64))) return rc;
-            size_t tb2 = 0;
-            GS_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, sorted.as<uint64_t>(), vals.as<uint64_t>(), ucnt.as<uint32_t>(), nruns.as<uint32_t>(), (int)T, c->stream));
-            if (tb2 > tb) { if ((rc = tmp.alloc(tb2))) return rc; }
-            GS_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb2, sorted.as<uint64_t>(), vals.as<uint64_t>(), ucnt.as<uint32_t>(), nruns.as<uint32_t>(), (int)T, c->stream));
+            if ((rc = run_length_encode_u64(c, sorted.as<uint64_t>(), T, vals.as<uint64_t>(), ucnt.as<uint32_t>(), nruns.as<uint32_t>(), pos.as<uint32_t>(), tmp.p))) return rc;
             uint32_t ne32 = 0;
             GS_HIP_CHECK(hipMemcpyAsync(&ne32, nruns.p, 4, hipMemcpyDeviceToHost, c->stream));
             GS_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -64,3 +64,18 @@ def queries_from(db, nq, seed, frac=0.1):
     other = db[rng.integers(0, len(db), nq)]
     q[mask] = other[::-1][mask] if False else np.roll(other, 1, axis=1)[mask]
     return np.ascontiguousarray(q)
+
+
+def bgzf_bytes(data, block=65280, level=6):
+    """`data` as a BGZF file (bgzip: independent gzip members of <= 64 KB of text, each with its size in a 'BC' extra field, + the EOF member)"""
+    import struct, zlib
+    out = []
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        total = 18 + len(cdata) + 8
+        out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, total - 1) + cdata +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)

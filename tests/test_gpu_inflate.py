@@ -168,3 +168,42 @@ def test_sketch_files_device_gzip_equals_host_gzip(gpu_ctx, tmp_path, monkeypatc
 
 def _bits(a):
     return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def test_sketch_files_bgzf_members_on_the_device(gpu_ctx, tmp_path):
+    """bgzip-compressed FASTA (needletail reads it like any multi-member .gz, /root/reference/src/utils/files.rs:258-341): every <= 64 KB member is
+    inflated by its own wavefront, a file's text is its members end to end; ordinary multi-member and single-member files beside them.
+    Signatures == the same texts read as plain files."""
+    import gzip
+    import gsearch_amd as G
+    import helpers as H
+    rng = np.random.default_rng(11)
+    texts = []
+    for i in range(24):
+        L = int(rng.integers(150_000, 700_000))
+        seq = H.dna_ascii(H.rand_dna(rng, L))
+        if i % 5 == 0:
+            seq = seq[:70_000] + b"NNNNNNNNNN" + seq[70_000:200_000].lower() + seq[200_000:]
+        lines = b"\n".join(seq[j:j + 70] for j in range(0, len(seq), 70))
+        if i % 4 == 1:                                              # several records, one of them a capsid (skipped)
+            cut = len(lines) // 3
+            lines = lines[:cut] + b"\n>rec2 capsid protein\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n>rec3\n" + lines[cut:]
+        texts.append(b">g%d synthetic\n" % i + lines + b"\n")
+    texts.append(b">empty\n")
+    texts.append(b"")
+    plain, comp = [], []
+    for i, t in enumerate(texts):
+        pp = tmp_path / ("p%03d.fna" % i); pp.write_bytes(t); plain.append(str(pp))
+        cp = tmp_path / ("c%03d.fna.gz" % i)
+        if i % 6 == 2: cp.write_bytes(gzip.compress(t[:len(t) // 2], 6) + gzip.compress(t[len(t) // 2:], 6))      # plain multi-member: host decoders
+        elif i % 6 == 4: cp.write_bytes(gzip.compress(t, 6))                                                        # single member
+        else: cp.write_bytes(H.bgzf_bytes(t, block=int(rng.integers(20_000, 65281))))
+        comp.append(str(cp))
+    sk = G.OptDensHashSketch.new(G.SeqSketcherParams(21, 2000, "optdens"))
+    want, nrec_w, nsym_w, _ = sk.sketch_files(plain)
+    got, nrec, nsym, st = sk.sketch_files(comp)
+    assert np.array_equal(nrec, nrec_w) and np.array_equal(nsym, nsym_w)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert st["gz_members_handed_back_to_host"] == 4             # the four ordinary multi-member files; every bgzip file stayed on the device
+    bl = sk.sketch_files(comp, block=True)[0]
+    assert np.array_equal(bl.view(np.uint32), sk.sketch_files(plain, block=True)[0].view(np.uint32))

@@ -28,6 +28,14 @@ for i in range(ndist if ndist else n):
         f.write(b">genome%d synthetic\n" % i)
         f.write(lines.tobytes())
     paths.append(p)
+if mode == "bgzf":                                              # bgzip-style members of 64 KB (the image has no bgzip: written here)
+    from multiprocessing import Pool
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import helpers as H
+    def _bg(p):
+        open(p + ".gz", "wb").write(H.bgzf_bytes(open(p, "rb").read(), level=level)); os.unlink(p); return p + ".gz"
+    with Pool(min(os.cpu_count() or 8, 16)) as pool:
+        paths = pool.map(_bg, paths)
 if mode == "gz":
     subprocess.check_call("ls %s/*.fna | xargs -P %d -n 4 gzip -%d" % (d, os.cpu_count() or 8, level), shell=True)
     paths = [p + ".gz" for p in paths]
