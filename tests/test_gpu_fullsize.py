@@ -118,3 +118,42 @@ def test_config2_request_300k(gpu_ctx, monkeypatch):
     # the exhaustive search itself against the oracle's exhaustive search on a few queries
     oi, od = O.bruteforce_topk(db, q[:4], knbn, nthreads=os.cpu_count())
     assert np.array_equal(od, bd[:4])
+
+
+@pytest.mark.parametrize("n,placement", [(700_000, "lds bitmap, one workgroup per CU"), (1_250_000, "global bitmap")])
+def test_dense_search_on_very_large_graphs(gpu_ctx, monkeypatch, n, placement):
+    """the dense traversal's visited-bitmap placements beyond the sizes the other tests reach: up to ~1.08 M nodes the bitmap stays in LDS (one
+    workgroup per CU), beyond it lives in global memory; both run the order-free second phase. A random regular graph over short signatures
+    stands in for the HNSW (search_layer does not care where the links came from): ids, distances, evaluation counts == oracle
+    (gsearch constructs Hnsw with capacity 1 500 000, /root/reference/src/bin/gsearch.rs:268-269)."""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    m, M, nq, knbn, ef = 32, 8, 96, 10, 300
+    rng = np.random.default_rng(n % 1000)
+    db = rng.integers(0, 6, (n, m)).astype(np.float32)                       # narrow value band: plenty of ties and chance agreements
+    deg = np.full(n, 2 * M, np.uint32)
+    nbr = rng.integers(0, n, (n, 2 * M)).astype(np.uint32)
+    nbr[:, 0] = (np.arange(n) + 1) % n                                      # a Hamiltonian cycle keeps the graph connected
+    cnt = (db[:, None, :] != db[nbr.astype(np.int64)]).sum(-1).astype(np.uint32) if n <= 200_000 else np.zeros((n, 2 * M), np.uint32)
+    if n > 200_000:                                                         # (in blocks: n x 16 x 32 compares)
+        for b0 in range(0, n, 100_000):
+            sl = slice(b0, min(n, b0 + 100_000))
+            cnt[sl] = (db[sl, None, :] != db[nbr[sl].astype(np.int64)]).sum(-1)
+    order = np.argsort(cnt.astype(np.uint64) << np.uint64(32) | nbr.astype(np.uint64), axis=1, kind="stable")       # lists in (count, id) order
+    nbr = np.take_along_axis(nbr, order, axis=1); cnt = np.take_along_axis(cnt, order, axis=1)
+    g = dict(levels=np.zeros(n, np.uint8), entry=0, deg0=deg, nbr0=nbr, cnt0=cnt, upidx=np.full(n, -1, np.int32), n_upper=0)
+    q = db[rng.integers(0, n, nq)].copy()
+    mk = rng.random(q.shape) < 0.3
+    q[mk] = rng.integers(0, 6, q.shape).astype(np.float32)[mk]
+    hn = G.Hnsw.new(M, n, 16, 64, G.DistHamming(), seed=1)
+    hn.import_graph(db, g)
+    hn.search_stats(reset=True)
+    got = hn.search_arrays(q, knbn, ef)
+    st = hn.search_stats(reset=True)
+    hn.close()
+    oix = O.Index(np.float32, m, M, 64, seed=1)
+    oix.import_graph(db, g, view=True)
+    want = oix.parallel_search(q, knbn, ef, nthreads=os.cpu_count())
+    for name, a, b in zip(("ids", "distances", "counts", "evaluations"), got, want):
+        assert np.array_equal(_bits(a), _bits(b)), (placement, name)
+    assert st["pops"] > 0, st                                               # the dense traversal ran (its order-free phase under both placements: test_dense_traversal_placements_and_regimes)
