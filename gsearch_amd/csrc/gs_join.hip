@@ -8,6 +8,7 @@
 //   per slot s:  for every node e:  probe cols[s][e] in an LDS hash table of the query values; every hit (q,e) -> matches[q][e] += 1
 // HBM traffic: the database once per BATCH (21.6 GB for 300 k x 18000 f32) instead of once per 128 queries; arithmetic: ~1.5 LDS
 // probes per (slot, node) instead of nq compares. Output is bit-identical to the tile kernel.
+#include <string.h>
 #include <algorithm>
 #include <chrono>
 #include <vector>
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                                                     uint32_t slot_lo, uint32_t slot_hi, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
                                                     unsigned long long *__restrict__ stats, int chunk_major, uint64_t col0, const uint16_t *__restrict__ qcl,
                                                     const uint16_t *__restrict__ nodelab, const T *__restrict__ qs, uint32_t nh, const uint32_t *__restrict__ cl_lo,
-                                                    const uint32_t *__restrict__ qlist)
+                                                    const uint32_t *__restrict__ qlist, uint32_t dedup_below)
 {
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     static_assert(!CL || SR == 1, "clusters: request batches only");
@@ -154,15 +155,11 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     const uint32_t bchunk = chunk_major ? blockIdx.y : blockIdx.x, bslot = chunk_major ? blockIdx.x : blockIdx.y;
     const uint64_t e0 = (uint64_t)bchunk * (JT * JN) + threadIdx.x;      // the lane's nodes: e0 + i * JT, i < JN
     const uint32_t s0 = slot_lo + bslot * slots_per_wg, s1 = s0 + slots_per_wg < slot_hi ? s0 + slots_per_wg : slot_hi;
-    uint32_t hotbits = 0, hotlab = 0;                             // CL: bit i = the lane's node i belongs to a cluster; label of the first such node | i << 16
-    if (CL) {
-#pragma unroll
-        for (int i = 0; i < JN; i++) {
-            const uint64_t e = e0 + (uint64_t)i * JT;
-            const uint32_t l = e < n ? nodelab[e] : 0u;
-            if (l) { if (!hotbits) hotlab = l | ((uint32_t)i << 16); hotbits |= 1u << i; }
-        }
-    }
+    // CL: the cluster ids of the lane's nodes come from a copy of the node labels laid out like the lanes' nodes ([chunk][it][lane][JU] of 16 bits:
+    // one 8-byte load per lane and group of four nodes), fetched again for every slot beside the column values - all eight labels resident would
+    // cost four more registers than the 64 this kernel may use, and a look-up at hit time stalled the wavefront on every own-cluster hit (round 4:
+    // 201 ms instead of 126 per request when a fifth of the nodes belong to clusters)
+    const uint2 *labT = CL ? (const uint2 *)nodelab + (uint64_t)bchunk * (JN / JU) * JT + threadIdx.x : nullptr;
     uint32_t sticky[JN];
     uint32_t natom = 0;                                           // memory-side atomics this lane sends (work counter for the bench's roofline)
     uint32_t nexp = 0;                                            // CL: chance matches on shared entries this wavefront expanded
@@ -193,7 +190,9 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                     const unsigned long long old = atomicCAS(&ent[h], 0ull, nw);
                     if (old == 0ull) break;
                     // same key already entered by a query of the same cluster: that entry stands for this query too
-                    if ((tw >> JTAG_CL_SHIFT) && (uint32_t)old == (uint32_t)k && ((uint32_t)(old >> 32) >> JTAG_CL_SHIFT) == (tw >> JTAG_CL_SHIFT)) {
+                    // (only clusters numbered below dedup_below - the large ones - share entries: a run of two or three equal keys is cheaper to walk
+                    // than a chance match on a shared entry is to expand)
+                    if ((tw >> JTAG_CL_SHIFT) - 1u < dedup_below - 1u && (uint32_t)old == (uint32_t)k && ((uint32_t)(old >> 32) >> JTAG_CL_SHIFT) == (tw >> JTAG_CL_SHIFT)) {
                         atomicOr((uint32_t *)&ent[h] + 1, JTAG_MULTI);
                         break;
                     }
@@ -211,6 +210,8 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
             const T *col = cols + (uint64_t)s * colcap;
 #pragma unroll
             for (int it = 0; it < JN / JU; it++) {
+                uint2 lab4 = make_uint2(0u, 0u);
+                if (CL) { uint32_t o = it * JT; asm volatile("" : "+v"(o)); lab4 = labT[o]; }      // (opaque offset: reloaded per slot, not kept live)
                 // (the four bitmap words are read unconditionally and together: behind `&&` each read sat in its own branch with its own wait)
                 T v[JU]; uint32_t hs[JU]; uint32_t pend = 0; uint32_t bw[JU];
 #pragma unroll
@@ -253,9 +254,8 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                                     bool count_it = true;
                                     if (t >> 12) {                                               // entry of a cluster
                                         const uint32_t cl = t >> JTAG_CL_SHIFT;
-                                        bool own = false;
-                                        if ((hotbits >> ni) & 1u) own = ((hotlab >> 16) == ni ? (hotlab & 0xFFFFu) : (uint32_t)nodelab[el]) == cl;
-                                        if (own) count_it = false;                               // the block compare writes this pair's counter
+                                        const uint32_t nl = ((uu & 2u ? lab4.y : lab4.x) >> ((uu & 1u) * 16)) & 0xFFFFu;      // this node's cluster
+                                        if (nl == cl) count_it = false;                          // own cluster: the block compare writes this pair's counter
                                         else if (t & JTAG_MULTI) { mitem = ((ni + 1) << 16) | cl; count_it = false; }
                                     }
                                     if (count_it) {
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                         const uint32_t ni = it * JU + uu;
                         const uint64_t el = e0 + (uint64_t)ni * JT;                          // node within this column range
                         bool count_it = true;
-                        if (CL && (t >> 12) && ((hotbits >> ni) & 1u))                       // (8-byte keys: no shared entries, only the own-cluster rule)
-                            count_it = ((hotlab >> 16) == ni ? (hotlab & 0xFFFFu) : (uint32_t)nodelab[el]) != (t >> JTAG_CL_SHIFT);
+                        if (CL && (t >> 12))                                                 // (8-byte keys: no shared entries, only the own-cluster rule)
+                            count_it = (((uu & 2u ? lab4.y : lab4.x) >> ((uu & 1u) * 16)) & 0xFFFFu) != (t >> JTAG_CL_SHIFT);
                         if (count_it) {
                             const uint64_t e = col0 + el;                                    // column of the count matrix (col0: the node range starts there)
                             uint32_t st = GS_SEL4((sticky + it * JU), uu);
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(JT) void k_match_sample(const T *__restrict__ qkey,
 constexpr uint32_t JS0 = 48, JHEAVY = 3;
 constexpr uint64_t JPAIR_CAP = (uint64_t)4 << 20;
 constexpr uint32_t JTILE_CAP = 24576;
+constexpr uint32_t JDEDUP_MINQ = 12;     // clusters of at least this many queries enter equal keys once (shared entries)
 
 // tiles of 8 consecutive counters per lane x 256 lanes; a workgroup walks many tiles, stages the heavy pairs it finds in LDS and sends them to
 // the list in blocks (a first version paid one same-address global atomic per wavefront and tile: 1.1e6 of them, 10 ms per batch)
@@ -485,7 +486,7 @@ struct JoinGeom { uint32_t chunks, log2p; size_t lds1; };
 template <int KIND, typename T, bool CL>
 static int join_launch(gs_ctx *c, const JoinGeom &g, const T *qkey, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint32_t slot_lo, uint32_t slot_hi,
                        uint16_t *out16, uint64_t ld, unsigned long long *stats, uint64_t col0, bool few_blocks, const uint16_t *qcl, const uint16_t *nodelab, const T *qs,
-                       uint32_t nh, const uint32_t *cl_lo, const uint32_t *qlist)
+                       uint32_t nh, const uint32_t *cl_lo, const uint32_t *qlist, uint32_t dedup_below = 0)
 {
     // one workgroup = JT * JN nodes x a block of slots; blocks sized so that the grid is about eight rounds of 2 workgroups per CU
     // (one round leaves the slowest workgroup's tail exposed: 145 -> 125 ms per 10 k-query request), at least 32 slots each
@@ -511,7 +512,7 @@ static int join_launch(gs_ctx *c, const JoinGeom &g, const T *qkey, uint32_t nq,
         auto kern = KERN;                                                                                                                             \
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
         hipLaunchKernelGGL(kern, jg, dim3(JT), lds, c->stream, qkey, nq, g.log2p, (const T *)cols, colcap, n, slot_lo, slot_hi, slots_per_wg, (uint32_t *)out16, ld, \
-                           stats, chunk_major, col0, qcl, nodelab, qs, nh, cl_lo, qlist);                                                             \
+                           stats, chunk_major, col0, qcl, nodelab, qs, nh, cl_lo, qlist, dedup_below);                                                             \
     } while (0)
     if (CL) GS_JOIN_GO((k_match_join<KIND, T, 1, CL>));
     else if (sr == 4) GS_JOIN_GO((k_match_join<KIND, T, 4, false>));
@@ -613,7 +614,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         hipLaunchKernelGGL(k_label_prop, dim3(c->n_cu * 4), dim3(256), 0, c->stream, pairs.as<uint2>(), ctr.as<unsigned long long>(), JPAIR_CAP, labq.as<uint32_t>(), labe.as<uint32_t>());
     GS_HIP_CHECK(hipGetLastError());
     // (pinned staging: a pageable destination makes the runtime bounce 1.2 MB through its own buffer, synchronously)
-    uint8_t *pin = (uint8_t *)pinned_pool(c)->ensure(34, 64 + 4 * ((size_t)nq + n) + 2 * ((size_t)nq + n) + 64);
+    uint8_t *pin = (uint8_t *)pinned_pool(c)->ensure(34, 64 + 4 * ((size_t)nq + n) + 2 * ((size_t)nq + 8 + (size_t)g.chunks * JT * JN) + 64);
     GS_REQUIRE(pin, GS_ERR_HIP, "match-join: pinned staging buffer");
     unsigned long long *hc = (unsigned long long *)pin;
     uint32_t *hlq = (uint32_t *)(pin + 64), *hle = hlq + nq;
@@ -624,7 +625,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     const uint64_t npairs = hc[0];
     // ---- clusters: labels with >= 2 queries and >= 1 node, largest blocks dropped while the tile budget is exceeded
     std::vector<uint32_t> cq(nq, 0), ce_(nq, 0), cid(nq, 0);
-    uint32_t K = 0, ntiles = 0, nhq = 0;
+    uint32_t K = 0, ntiles = 0, nhq = 0, dedup_below = 1;
     uint64_t nhe = 0;
     const uint32_t minq = getenv("GS_JOIN_CLUSTER_MINQ") ? (uint32_t)std::max(2, atoi(getenv("GS_JOIN_CLUSTER_MINQ"))) : (ce && atoi(ce) == 2 ? 2u : 12u);
     bool any = false;
@@ -645,10 +646,14 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         for (uint32_t l = 0; l < nq; l++) if (cq[l] >= minq && ce_[l] >= 1) order.push_back(l);
         auto tiles_of = [&](uint32_t l) { return ((cq[l] + HTILE - 1) / HTILE) * ((ce_[l] + HTILE - 1) / HTILE); };
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { const uint32_t ta = tiles_of(a), tb = tiles_of(b); return ta != tb ? ta < tb : a < b; });
+        std::vector<uint32_t> chosen;
         for (uint32_t l : order) {
-            if (K >= JCL_MAX || ntiles + tiles_of(l) > JTILE_CAP) break;                          // cheapest blocks first
-            cid[l] = ++K; ntiles += tiles_of(l); nhq += cq[l]; nhe += ce_[l];
+            if (chosen.size() >= JCL_MAX || ntiles + tiles_of(l) > JTILE_CAP) break;                          // cheapest blocks first
+            chosen.push_back(l); ntiles += tiles_of(l); nhq += cq[l]; nhe += ce_[l];
         }
+        // cluster ids: the large clusters (>= JDEDUP_MINQ queries) first - only they share table entries
+        std::stable_sort(chosen.begin(), chosen.end(), [&](uint32_t a, uint32_t b) { return (cq[a] >= JDEDUP_MINQ) > (cq[b] >= JDEDUP_MINQ); });
+        for (uint32_t l : chosen) { cid[l] = ++K; if (cq[l] >= JDEDUP_MINQ) dedup_below = K + 1; }
     }
     // (query, node) pairs the blocks take off the match-by-match path; a handful is not worth a second kernel variant and the tile launch
     uint64_t saved_pairs = 0;
@@ -676,9 +681,19 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     for (uint32_t l = 0; l < nq; l++) if (cid[l]) { cl_lo[cid[l] + 1] = cq[l]; ce_lo[cid[l] + 1] = ce_[l]; }
     for (uint32_t k = 1; k <= K + 1; k++) { cl_lo[k] += cl_lo[k - 1]; ce_lo[k] += ce_lo[k - 1]; }
     std::vector<uint32_t> qlist(nhq), elist(nhe), fq(cl_lo.begin(), cl_lo.end()), fe(ce_lo.begin(), ce_lo.end());
-    uint16_t *hqcl = (uint16_t *)(hle + n), *hnl = hqcl + nq;          // (pinned, behind the labels)
+    // node labels in the layout of the join's lanes: node e = chunk * 8192 + i * 1024 + lane sits at [chunk][i / 4][lane][i % 4] (padded to whole chunks)
+    const uint64_t npad = (uint64_t)g.chunks * JT * JN;
+    uint16_t *hqcl = (uint16_t *)(hle + n), *hnl = hqcl + ((nq + 3) & ~3u);          // (pinned, behind the labels; 8-byte aligned)
     for (uint32_t q = 0; q < nq; q++) { const uint32_t l = hlq[q]; hqcl[q] = 0; if (l < nq && cid[l]) { hqcl[q] = (uint16_t)cid[l]; qlist[fq[cid[l]]++] = q; } }
-    for (uint64_t e = 0; e < n; e++) { const uint32_t l = hle[e]; hnl[e] = 0; if (l < nq && cid[l]) { hnl[e] = (uint16_t)cid[l]; elist[fe[cid[l]]++] = (uint32_t)e; } }
+    memset(hnl, 0, 2 * npad);
+    for (uint64_t e = 0; e < n; e++) {
+        const uint32_t l = hle[e];
+        if (l < nq && cid[l]) {
+            const uint64_t ch = e / (JT * JN), w = e % (JT * JN), i = w / JT, ln = w % JT;
+            hnl[((ch * (JN / JU) + i / JU) * JT + ln) * JU + i % JU] = (uint16_t)cid[l];
+            elist[fe[cid[l]]++] = (uint32_t)e;
+        }
+    }
     std::vector<uint4> tiles;
     tiles.reserve(ntiles);
     for (uint32_t k = 1; k <= K; k++)
@@ -687,10 +702,10 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
                 tiles.push_back(make_uint4(a, std::min<uint32_t>(HTILE, cl_lo[k + 1] - a), b, std::min<uint32_t>(HTILE, ce_lo[k + 1] - b)));
     lap("host: lists");
     DevBuf &dqcl = scratch[6], &dnl = scratch[7], &dql = scratch[8], &del = scratch[9], &dtl = scratch[10], &dqs = scratch[11], &dcl = scratch[13];
-    if ((rc = dqcl.ensure(2 * (size_t)nq)) || (rc = dnl.ensure(2 * (size_t)n)) || (rc = dql.ensure(4 * (size_t)nhq)) || (rc = del.ensure(4 * (size_t)nhe)) ||
+    if ((rc = dqcl.ensure(2 * (size_t)nq)) || (rc = dnl.ensure(2 * (size_t)npad)) || (rc = dql.ensure(4 * (size_t)nhq)) || (rc = del.ensure(4 * (size_t)nhe)) ||
         (rc = dtl.ensure(16 * tiles.size())) || (rc = dqs.ensure(sizeof(T) * (size_t)m * nhq)) || (rc = dcl.ensure(4 * (size_t)(K + 2)))) return rc;
     GS_HIP_CHECK(hipMemcpyAsync(dqcl.p, hqcl, 2 * (size_t)nq, hipMemcpyHostToDevice, c->stream));
-    GS_HIP_CHECK(hipMemcpyAsync(dnl.p, hnl, 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dnl.p, hnl, 2 * (size_t)npad, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dql.p, qlist.data(), 4 * (size_t)nhq, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(del.p, elist.data(), 4 * (size_t)nhe, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dtl.p, tiles.data(), 16 * tiles.size(), hipMemcpyHostToDevice, c->stream));
@@ -700,7 +715,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     GS_HIP_CHECK(hipGetLastError());
     lap("uploads + sorted key copy");
     if ((rc = join_launch<KIND, T, true>(c, g, k0.as<T>(), nq, cols, colcap, n, JS0, m, out16, ld, stats, 0, false, dqcl.as<uint16_t>(), dnl.as<uint16_t>(), dqs.as<T>(), nhq,
-                                         dcl.as<uint32_t>(), dql.as<uint32_t>()))) return rc;
+                                         dcl.as<uint32_t>(), dql.as<uint32_t>(), dedup_below))) return rc;
     {
         ProfScope ps(c, FAM_HAMMING);
         lap("cluster-aware join");
