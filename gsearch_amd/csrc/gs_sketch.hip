@@ -1616,8 +1616,20 @@ struct HllEmit {
     // go on to the logarithm / walk; left in place, nearly every wave iteration had a lane or two in that branch and all 64 paid for it
     // (rocprofv3: 733 VALU wave-instructions per 64 k-mers, 8x the OPH sketch). Queued, the slow part runs on full wavefronts.
     uint64_t *sq; uint32_t lane; mutable uint32_t qn; mutable uint64_t cutr;
+    // Round 4: pass A also RECORDS the hashes that pass its cut (ctl[6] counts them, `surv` holds up to surv_cap of them per workgroup). The cut only
+    // ever tightens (registers only grow), so every k-mer pass B would look at is among them: pass B walks this list instead of hashing the whole
+    // genome a second time (a list that overflowed falls back to the second walk).
+    uint64_t *surv; uint32_t surv_cap;
+    __device__ __forceinline__ void record_wave(uint64_t h, uint32_t cnt) const          // the first `cnt` lanes of the wave append their h
+    {
+        if (!surv || walk) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd((uint32_t *)&S.ctl[6], cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < cnt && base + lane < surv_cap) surv[base + lane] = h;
+    }
     __device__ __forceinline__ void refresh() const { cutr = ((uint64_t)S.ctl[5] << 32) | S.ctl[4]; }
-    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { process(elem_hash<ALGO_HLL, 64>(v)); }
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { process(elem_hash<ALGO_HLL, 64>(v), true); }
     __device__ __forceinline__ void full(uint64_t v) const
     {
         const uint64_t h = elem_hash<ALGO_HLL, 64>(v);
@@ -1628,7 +1640,9 @@ struct HllEmit {
             if (pass) sq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = h;
             qn += (uint32_t)__popcll(bal);
             if (qn >= 64) {
-                process(sq[lane]);
+                const uint64_t hq = sq[lane];
+                record_wave(hq, 64u);
+                process(hq, false);
                 const uint32_t rest = qn - 64;
                 const uint64_t mv = sq[64 + lane];
                 if (lane < rest) sq[lane] = mv;
@@ -1636,13 +1650,18 @@ struct HllEmit {
             }
         }
     }
-    __device__ __forceinline__ void finish() const { if (sq && lane < qn) process(sq[lane]); qn = 0; }
-    __device__ __forceinline__ void process(uint64_t h) const
+    __device__ __forceinline__ void finish() const
+    {
+        if (sq && qn) { const uint64_t hq = lane < qn ? sq[lane] : 0; record_wave(hq, qn); if (lane < qn) process(hq, false); }
+        qn = 0;
+    }
+    __device__ __forceinline__ void process(uint64_t h, bool record) const
     {
         Rng g; g.seed(h);
         const uint64_t u52 = g.next64() >> 12;
         const uint64_t cut = ((uint64_t)S.ctl[5] << 32) | S.ctl[4];
         if (u52 > cut) return;                                    // its first point cannot reach the lower bound: nor can any later one
+        if (record && surv && !walk) { const uint32_t at = atomicAdd((uint32_t *)&S.ctl[6], 1u); if (at < surv_cap) surv[at] = h; }      // (lanes outside full waves: record boundaries)
         const uint32_t klow = S.ctl[0];
         double x = -spec_ln(1.0 - (double)u52 * 0x1.0p-52) / am;
         uint32_t k = hll_k(x, inv_lnb);
@@ -1704,7 +1723,8 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off,
         const uint64_t *__restrict__ gen_units, const uint32_t *__restrict__ list, uint32_t n_items, uint32_t k, uint32_t m, double inv_lnb,
         const uint64_t *__restrict__ ucut, uint32_t *__restrict__ lane_q, uint32_t *__restrict__ lane_perm, unsigned long long *__restrict__ counter,
-        uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig, uint32_t *__restrict__ gtab, int use_filter, uint32_t queue_off)
+        uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig, uint32_t *__restrict__ gtab, int use_filter, uint32_t queue_off,
+        uint64_t *__restrict__ surv_all, uint32_t surv_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_hll[];
     HllShared S;
@@ -1723,7 +1743,7 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         if (c >= n_items) break;
         const uint64_t g = list ? list[c] : c;
         for (uint32_t i = threadIdx.x; i < m; i += T) { S.tab[i] = 0; if (GTAB && S.filt) S.filt[i] = 0; }
-        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[3] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; }
+        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[3] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; S.ctl[6] = 0; }
         __syncthreads();
         const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
         const uint32_t nchunks = (uint32_t)std::max<uint64_t>(1, units / ((uint64_t)T * 8));
@@ -1731,7 +1751,15 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         for (int pass = 0; pass < 2 && !outgrown; pass++) {
             // (queue_off != 0: the warm instantiation has room in LDS for its survivor queues, 128 hashes per wave)
             uint64_t *sq = (!COLD && queue_off) ? (uint64_t *)(s_hll + queue_off) + (threadIdx.x >> 6) * 128 : nullptr;
-            HllEmit<COLD, GTAB> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1, sq, threadIdx.x & 63, 0u, ~(uint64_t)0};
+            uint64_t *surv = (!COLD && surv_all) ? surv_all + (uint64_t)blockIdx.x * surv_cap : nullptr;
+            HllEmit<COLD, GTAB> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, pass == 1, sq, threadIdx.x & 63, 0u, ~(uint64_t)0, surv, surv_cap};
+            if (!COLD && pass == 1 && surv && S.ctl[6] <= surv_cap) {
+                // pass B over the recorded survivors of pass A (S.ctl[6] is stable here: pass A ended with barriers)
+                const uint32_t nl = S.ctl[6];
+                for (uint32_t i = threadIdx.x; i < nl; i += T) emit.process(surv[i], false);
+                if (__syncthreads_or(S.ctl[3] != 0)) outgrown = true;
+                break;
+            }
             for (uint32_t ch = 0; ch < nchunks; ch++) {
                 emit.refresh();
                 walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, ch, nchunks, emit);
@@ -1799,8 +1827,12 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     const uint32_t queue_off = use_q ? (uint32_t)((lds0 + 15) & ~(size_t)15) : 0u;
     const size_t lds = use_q ? lds_q : lds0;
     const uint32_t wgs = (uint32_t)std::min<uint64_t>(n_genomes, (uint64_t)c->n_cu * 2);
-    PoolBuf gt(c, 19);
+    PoolBuf gt(c, 19), sv(c, 46);
     if (gtab && (rc = gt.alloc((size_t)4 * m * std::max<uint32_t>(wgs, (uint32_t)c->n_cu)))) return rc;
+    // survivor lists of pass A: 2^20 hashes (8 MB) per workgroup - ~8 % of the k-mers of a 5 Mbp genome survive the running cut; a longer genome
+    // overflows its list and takes the second walk as before (GS_HLL_SURVIVORS=n: lists of n hashes, 0 = always the second walk)
+    const uint32_t surv_cap = getenv("GS_HLL_SURVIVORS") ? (uint32_t)std::max(0, std::min(1 << 24, atoi(getenv("GS_HLL_SURVIVORS")))) : (1u << 20);
+    if (surv_cap && (rc = sv.alloc((size_t)8 * surv_cap * wgs))) return rc;
     {
         ProfScope ps(c, FAM_SKETCH);
 #define GS_LAUNCH_HLL(AAV, GV)                                                                                                 \
@@ -1809,7 +1841,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(HL_T), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, (const uint32_t *)nullptr, \
                            (uint32_t)n_genomes, p->k, m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
-                           gt.as<uint32_t>(), use_filter, queue_off);                                                          \
+                           gt.as<uint32_t>(), use_filter, queue_off, surv_cap ? sv.as<uint64_t>() : (uint64_t *)nullptr, surv_cap);   \
     } while (0)
         if (aa) { if (gtab) GS_LAUNCH_HLL(true, true); else GS_LAUNCH_HLL(true, false); }
         else { if (gtab) GS_LAUNCH_HLL(false, true); else GS_LAUNCH_HLL(false, false); }
@@ -1846,7 +1878,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(cw), dim3(HL_CT), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, p->k, m, \
                            inv_lnb, dcut.as<uint64_t>(), lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
-                           gt.as<uint32_t>(), use_filter, 0u);                                                                 \
+                           gt.as<uint32_t>(), use_filter, 0u, (uint64_t *)nullptr, 0u);                                        \
     } while (0)
     if (aa) { if (gtab) GS_LAUNCH_HLLC(true, true); else GS_LAUNCH_HLLC(true, false); }
     else { if (gtab) GS_LAUNCH_HLLC(false, true); else GS_LAUNCH_HLLC(false, false); }

@@ -931,6 +931,22 @@ def test_sketch_hll_matches_oracle(gpu_ctx, k, m, data, length):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("cap", ["0", "4096", None])
+def test_sketch_hll_survivor_lists(gpu_ctx, monkeypatch, cap):
+    """SetSketch pass B runs over the hashes pass A recorded instead of hashing the genome again (gs_sketch.hip HllEmit::record_wave): without lists
+    (0), with lists that overflow for every genome (4096 entries: the second walk is taken) and with the default lists - the same registers"""
+    import gsearch_amd as G
+    if cap is not None:
+        monkeypatch.setenv("GS_HLL_SURVIVORS", cap)
+    rng = np.random.default_rng(41)
+    genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (900_000, 400_011, 1_300_000)]
+    genomes.append([H.dna_ascii(H.rand_dna(rng, 300_000)), b"ACGTNNACGT", H.dna_ascii(H.rand_dna(rng, 350_007))])
+    sk = G.sketcher_for(G.SeqSketcherParams(21, 4000, "hll"))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(21, 4000, "hll", genomes)
+    assert got.dtype == ref.dtype and np.array_equal(got, ref)
+
+
 def test_sketch_hll_cold_path_matches_oracle(gpu_ctx):
     """few k-mers per register: the lower bound stays near 0 and elements walk hundreds of steps - the genome is flagged by the warm
     kernel and redone with the permutation in per-lane global scratch; empty and tiny inputs included"""
