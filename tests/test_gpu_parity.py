@@ -938,9 +938,10 @@ def test_sketch_hll_survivor_lists(gpu_ctx, monkeypatch, cap):
     import gsearch_amd as G
     if cap is not None:
         monkeypatch.setenv("GS_HLL_SURVIVORS", cap)
+    monkeypatch.setenv("GS_HLL_SURVIVORS_MINCHUNKS", "4")               # (default 64 chunks = 8.4 Mbp: the lists only pay for long genomes)
     rng = np.random.default_rng(41)
-    genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (900_000, 400_011, 1_300_000)]
-    genomes.append([H.dna_ascii(H.rand_dna(rng, 300_000)), b"ACGTNNACGT", H.dna_ascii(H.rand_dna(rng, 350_007))])
+    genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (1_200_000, 400_011, 2_300_000)]          # 9 / 3 / 17 chunks of 131 072 k-mers
+    genomes.append([H.dna_ascii(H.rand_dna(rng, 700_000)), b"ACGTNNACGT", H.dna_ascii(H.rand_dna(rng, 650_007))])
     sk = G.sketcher_for(G.SeqSketcherParams(21, 4000, "hll"))
     got = sk.sketch_genomes(genomes)
     ref = _oracle_sketch(21, 4000, "hll", genomes)
