@@ -227,3 +227,26 @@ def test_hnsw_export_invariants():
         assert (np.diff(keys.astype(np.int64)) > 0).all()     # sorted by (count, id)
         true = np.rint(O.hamming_qxc(db[i:i + 1], db[nb.astype(np.int64)])[0] * 100).astype(np.uint32) if d else np.zeros(0, np.uint32)
         assert np.array_equal(true, g["cnt0"][i, :d])
+
+
+def test_index_import_view_searches_like_a_copy():
+    """go_index_import_view keeps a pointer to the caller's rows (the 300 000-node GPU tests hand the oracle 21.6 GB this way): same answers as the
+    copying import, and a borrowed index refuses to grow"""
+    db = H.synth_sig_db(5, 40, 96, 3)
+    a = O.Index(np.float32, 96, 6, 30, seed=2)
+    a.parallel_insert(db, batch=16)
+    g = a.export()
+    b, c = O.Index(np.float32, 96, 6, 30, seed=2), O.Index(np.float32, 96, 6, 30, seed=2)
+    b.import_graph(db, g)
+    c.import_graph(db, g, view=True)
+    q = H.queries_from(db, 12, 5)
+    for x, y, z in zip(a.parallel_search(q, 5, 40), b.parallel_search(q, 5, 40), c.parallel_search(q, 5, 40)):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert O.lib().go_index_insert(c.h, db.ctypes.data_as(O.C.c_void_p), 1, 1) != 0
+
+
+def test_bgzf_helper_writes_valid_gzip():
+    import gzip
+    data = bytes(np.random.default_rng(0).integers(65, 70, 300_000).astype(np.uint8))
+    blob = H.bgzf_bytes(data, block=40_000)
+    assert gzip.decompress(blob) == data and blob.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
