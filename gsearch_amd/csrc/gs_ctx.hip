@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include "gs_internal.hpp"
 #include "gs_spec.hpp"
 
@@ -14,6 +15,28 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+}  // namespace gs
+
+namespace gs {
+gs_ctx *worker_ctx(gs_ctx *c)
+{
+    if (!c || c->parent) return c;
+    static const bool off = getenv("GS_THREAD_CONTEXTS") && !atoi(getenv("GS_THREAD_CONTEXTS"));
+    if (off) return c;
+    const std::thread::id me = std::this_thread::get_id();
+    std::lock_guard<std::mutex> lk(c->workers_mu);
+    if (c->owner_thread == std::thread::id{}) c->owner_thread = me;
+    if (c->owner_thread == me) return c;
+    auto it = c->workers.find(me);
+    if (it != c->workers.end()) return it->second;
+    if (c->workers.size() >= 64) return c;                          // (a thread pool that keeps respawning: stop growing, share the main context)
+    gs_ctx *w = nullptr;
+    if (gs_ctx_create(&w, c->device, nullptr) != GS_OK) return c;
+    w->parent = c;
+    w->last_sketch[0] = 0;
+    c->workers[me] = w;
+    return w;
 }
 }  // namespace gs
 
@@ -48,6 +71,8 @@ void gs_ctx_destroy(gs_ctx *c)
 {
     if (!c) return;
     if (c->child) { gs_ctx_destroy(c->child); c->child = nullptr; }
+    for (auto &w : c->workers) gs_ctx_destroy(w.second);
+    c->workers.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->prof) for (auto &p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -69,6 +94,10 @@ int gs_ctx_release_scratch(gs_ctx *c)
     c->scratch_pool = nullptr;
     delete (gs::PinnedPool *)c->pinned_pool;
     c->pinned_pool = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->workers_mu);
+        for (auto &w : c->workers) { const int rc = gs_ctx_release_scratch(w.second); if (rc) return rc; }
+    }
     if (c->child) return gs_ctx_release_scratch(c->child);
     return GS_OK;
 }

@@ -330,10 +330,11 @@ int gs_hamming_qxc(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, 
     GS_REQUIRE(c && m > 0, GS_ERR_INVALID, "bad argument");
     if (nq == 0 || nc == 0) return GS_OK;
     GS_REQUIRE(Q && C && out, GS_ERR_INVALID, "null argument");
+    c = gs::worker_ctx(c);
     GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const size_t row = gs::kind_bytes(kind) * (size_t)m;
-    gs::DevBuf dq, dc, dout;
+    gs::PoolBuf dq(c, 53), dc(c, 54), dout(c, 55);
     int rc;
     if ((rc = dq.alloc(row * nq))) return rc;
     if ((rc = dc.alloc(row * nc))) return rc;
@@ -354,10 +355,11 @@ int gs_hamming_pairs(gs_ctx *c, int kind, uint32_t m, const void *A, uint64_t na
     if (npairs == 0) return GS_OK;
     GS_REQUIRE(A && B && ia && ib && out, GS_ERR_INVALID, "null argument");
     for (uint64_t p = 0; p < npairs; p++) GS_REQUIRE(ia[p] < na && ib[p] < nb, GS_ERR_INVALID, "pair %llu out of range", (unsigned long long)p);
+    c = gs::worker_ctx(c);
     GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const size_t row = gs::kind_bytes(kind) * (size_t)m;
-    gs::DevBuf da, db, dia, dib, dout;
+    gs::PoolBuf da(c, 53), db(c, 54), dia(c, 55), dib(c, 56), dout(c, 57);
     int rc;
     if ((rc = da.alloc(row * na))) return rc;
     if ((rc = db.alloc(row * nb))) return rc;
@@ -368,7 +370,7 @@ int gs_hamming_pairs(gs_ctx *c, int kind, uint32_t m, const void *A, uint64_t na
     GS_HIP_CHECK(hipMemcpyAsync(db.p, B, row * nb, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dia.p, ia, 8 * npairs, hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dib.p, ib, 8 * npairs, hipMemcpyHostToDevice, c->stream));
-    gs::DevBuf wa, wb;
+    gs::PoolBuf wa(c, 58), wb(c, 59);
     if (kind == GS_KIND_U16) {                                   // widen once, then the u32 kernel (see k_widen_u16)
         if ((rc = wa.alloc((size_t)4 * m * na))) return rc;
         if ((rc = wb.alloc((size_t)4 * m * nb))) return rc;

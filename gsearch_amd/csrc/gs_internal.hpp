@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include "../../include/gsearch_amd.h"
@@ -54,6 +56,12 @@ struct gs_ctx {
     hipEvent_t sync_ev = nullptr;      // blocking-sync event of gs::stream_wait (a sleeping wait: the file pipelines leave the cores to the decoders)
     gs_ctx *child = nullptr;           // second context (own stream, pools) on the same device: gs_sketch_files runs its host-decoded files on it
     void *pinned_pool = nullptr;       // gs::PinnedPool: grow-only pinned host staging buffers of gs_sketch_files (hipHostMalloc costs ~0.3 s per GB)
+    // Worker contexts (gs::worker_ctx): the reference clones its sketcher into --nbthreads workers that all call it through &self
+    // (dnasketch.rs:252,305,322). The synchronous host-pointer entry points (gs_sketch_batch, gs_hamming_qxc, gs_hamming_pairs) give every calling
+    // thread other than the first its own stream + scratch on the same device, so such calls run side by side instead of queueing on one lock.
+    std::thread::id owner_thread{};
+    std::map<std::thread::id, gs_ctx *> workers; std::mutex workers_mu;
+    gs_ctx *parent = nullptr;
     uint32_t last_sketch[4] = {0, 0, 0, 0};   // gs_ctx_last_sketch_info: {filtered emitter, slot table in LDS, workgroups per genome, launches} of the last slot-min sketch call
     // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
     // and parallel_search through &self from many threads (dnasketch.rs:252,305,322): every entry point that touches the stream or the
@@ -66,6 +74,10 @@ struct gs_ctx {
 #define GS_CTX_LOCK(c) std::lock_guard<std::recursive_mutex> gs_ctx_lock_((c)->mu); (void)hipSetDevice((c)->device)
 
 namespace gs {
+
+// the context a host-pointer call of the current thread runs on: `c` itself for the thread that used it first, a per-thread worker context otherwise
+// (GS_THREAD_CONTEXTS=0: always `c` - every call of every thread queues on the one context, as before round 4)
+gs_ctx *worker_ctx(gs_ctx *c);
 
 // Wait for the context's stream WITHOUT spinning: hipStreamSynchronize busy-waits on a core, and the two pipelines of gs_sketch_files wait
 // for hundreds of milliseconds at a time (a k_inflate launch) while the host decoders want every core of the cgroup's quota.
@@ -152,7 +164,7 @@ struct DevBuf {   // owning device allocation
 // Per-context scratch: a call's temporaries come from numbered grow-only slots instead of hipMalloc/hipFree (allocating and freeing
 // multi-GB buffers costs more than the kernels that use them). A context serves one call at a time (one stream), so slots are never
 // shared; gs_ctx_release_scratch / gs_ctx_destroy give the memory back.
-enum { SCRATCH_SLOTS = 48 };
+enum { SCRATCH_SLOTS = 64 };        // 48-52: staging of gs_sketch_batch, 53-57: of gs_hamming_qxc / gs_hamming_pairs (host-pointer calls)
 struct ScratchPool { DevBuf b[SCRATCH_SLOTS]; };
 enum { PINNED_SLOTS = 36 };      // 0-15 text, 16-31 compressed members, 32-33 inflate descriptors / results
 struct PinnedPool {

@@ -1986,9 +1986,12 @@ int gs_sketch_batch(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint6
     for (uint64_t r = 0; r < n_rec; r++)
         GS_REQUIRE(rec_start[r] + rec_len[r] <= sym_cap, GS_ERR_INVALID, "record %llu exceeds the sequence buffer", (unsigned long long)r);
     GS_REQUIRE(genome_rec_off[n_genomes] <= n_rec, GS_ERR_INVALID, "genome_rec_off exceeds n_rec");
+    c = gs::worker_ctx(c);                 // (a worker thread of the host: its own stream and scratch, see gs_internal.hpp)
     GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
-    gs::DevBuf dseq, drs, drl, dgo, dsig;
+    // staging from the context's grow-only pool: a hipMalloc / hipFree pair per call costs more than a small sketch and, worse, hipFree waits for
+    // every stream of the device - which would serialise the worker contexts of other host threads
+    gs::PoolBuf dseq(c, 48), drs(c, 49), drl(c, 50), dgo(c, 51), dsig(c, 52);
     const uint64_t padded = gs::round_up(seq_bytes, 32) + 32;
     const size_t sigbytes = (size_t)n_genomes * p->sketch_size * gs_sig_elem_bytes(p);
     if ((rc = dseq.alloc(padded))) return rc;

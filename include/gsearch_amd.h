@@ -40,7 +40,11 @@ const char *gs_version(void);
 /* ---------------------------------------------------------------------------------------------- */
 /* Context: one per (process, GPU). Owns a HIP stream; every call on a context is enqueued on it.   */
 /* Every entry point that takes a context (or an index made on one) may be called concurrently from */
-/* several host threads: the context serialises them internally (one stream, one scratch pool).     */
+/* several host threads. The synchronous host-pointer calls gs_sketch_batch, gs_hamming_qxc and      */
+/* gs_hamming_pairs run side by side: every calling thread but the first gets a worker stream +      */
+/* scratch of its own on the same device (GS_THREAD_CONTEXTS=0: off). Everything else - the `_dev`   */
+/* calls, whose ordering on the context's stream the caller relies on, and the calls on an index -   */
+/* queues on the context's one stream and scratch pool behind its lock.                              */
 /* `stream` may be NULL (the context creates its own) or an existing hipStream_t to adopt.          */
 typedef struct gs_ctx gs_ctx;
 int   gs_ctx_create(gs_ctx **out, int device_id, void *stream);
@@ -91,7 +95,8 @@ int    gs_value_bits(const gs_sketch_params *);         /* width of Kmer::Val: 3
  *   genome g   = records [genome_rec_off[g], genome_rec_off[g+1]).  `--block` mode = one record/genome.
  *   sig_out    n_genomes x sketch_size elements of gs_sig_kind(), caller owned.
  * Thread-safe: callable concurrently from many host threads on ONE context, like the reference's &self sketcher cloned into
- * --nbthreads workers (dnasketch.rs:252,305,322); calls on one context queue on its stream, contexts run side by side.
+ * --nbthreads workers (dnasketch.rs:252,305,322): gs_sketch_batch calls of different threads overlap on the device (worker streams; 16 threads
+ * x 4 genomes of 2 Mbp per call: 34.7 k genomes/s against 19.2 k queued, profiles/r04_thread_contexts.log); gs_sketch_batch_dev queues on the context's stream.
  */
 int gs_sketch_batch(gs_ctx *, const gs_sketch_params *, const void *seq, uint64_t seq_bytes,
                     const uint64_t *rec_start, const uint64_t *rec_len, uint64_t n_rec,
