@@ -83,6 +83,7 @@ SYMBOLS = {
     "gs_index_parallel_insert_dev": (_i, [_vp, _vp, _u64]),
     "gs_index_parallel_insert_ids": (_i, [_vp, _vp, _vp, _u64]),
     "gs_index_parallel_insert_ids_dev": (_i, [_vp, _vp, _vp, _u64]),
+    "gs_index_sketch_and_search_dev": (_i, [_vp, _PP, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "gs_index_set_ids": (_i, [_vp, _vp, _u64]),
     "gs_index_get_ids": (_i, [_vp, _u64, _u64, _vp]),
     "gs_index_parallel_search_pid": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -608,6 +608,12 @@ class Hnsw:
         check(self.ctx.L.gs_index_count_matrix(self.h, _p(datas), datas.shape[0], _p(out)))
         return out
 
+    def sketch_and_search_dev(self, params, d_seq, seq_bytes, d_rec_start, d_rec_len, n_rec, d_genome_rec_off, n_genomes, knbn, ef, d_ids, d_dist, d_count=None,
+                              d_evals=None, d_sig=None):
+        """sketch_and_request on device-resident genomes (gs_index_sketch_and_search_dev): every d_* is a device pointer (int)"""
+        check(self.ctx.L.gs_index_sketch_and_search_dev(self.h, C.byref(params.c), d_seq, seq_bytes, d_rec_start, d_rec_len, n_rec, d_genome_rec_off, n_genomes, d_sig,
+                                                        knbn, ef, d_ids, d_dist, d_count, d_evals))
+
     def bruteforce_search(self, datas, knbn):
         datas = np.ascontiguousarray(datas, dtype=self.dtype)
         ids = np.zeros((datas.shape[0], knbn), dtype=np.uint64)

@@ -15,6 +15,7 @@
 // v_cmp + ballot/popcount against the query chunk held in registers), then apply the sequential accept rule of
 // search_layer in closed form and merge the accepted keys into R and C with one in-LDS parallel merge.
 #include <algorithm>
+#include <functional>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1680,6 +1681,9 @@ struct gs_index {
     std::vector<int32_t> pid_rank;
     uint64_t level_count[17] = {0};
     gs::DevBuf origin_d, pid_rank_d; uint64_t origin_d_n = 0, pid_rank_d_n = 0;
+    // gs_index_sketch_and_search_dev: the padded query rows are produced batch by batch while the search is under way; dense_counts asks for
+    // rows [q0, q0 + nb) of the buffer at feed_base just before it joins them
+    std::function<int(uint64_t, uint64_t)> *feed = nullptr; const uint8_t *feed_base = nullptr;
     ~gs_index()
     {
         if (jstream) { (void)hipStreamSynchronize(jstream); (void)hipStreamDestroy(jstream); }
@@ -1881,6 +1885,7 @@ static int dense_counts(gs_index *ix, const uint8_t *qrows, uint64_t nq, uint64_
     for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
         const uint64_t nb = std::min<uint64_t>(jq, nq - q0);
         int declined = 0;
+        if (ix->feed && (rc = (*ix->feed)((uint64_t)(qrows - ix->feed_base) / ix->stride + q0, nb))) return rc;
         if ((rc = match_join_counts(c, ix->ikind, ix->prm.m, qrows + q0 * ix->stride, ix->stride, nb, ix->cols.p, ix->cols_cap, n, out16 + q0 * ld, ld, ix->join_scratch,
                                     &declined, ix->stats.as<unsigned long long>(), true, 0, ix->data.p, ix->stride))) return rc;
         if (declined &&      // too many matches to record one by one (redundant queries against a redundant database): fixed-cost compare kernel
@@ -2008,6 +2013,16 @@ static int search_launch(gs_index *ix, const uint8_t *q_padded_dev, uint64_t nq,
     return GS_OK;
 }
 
+// true when search_dev takes the dense strategy for ALL nq queries at once (no gather probe first)
+static bool search_goes_dense(const gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef)
+{
+    const uint32_t efs = std::max(ef, knbn);
+    const DistMode mode = env_mode();
+    if (ix->prm.m > 65535) return false;
+    if (mode == MODE_DENSE) return true;
+    const bool eligible = mode == MODE_AUTO && ix->n >= 4096;
+    return eligible && dense_pays(ix, (double)std::min<uint64_t>(ix->n, efs) / (double)ix->n, nq);
+}
 static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
                       uint32_t *count, uint64_t *evals)
 {
@@ -2379,6 +2394,82 @@ int gs_index_parallel_search_pid_dev(gs_index *ix, const void *queries_dev, uint
                                      uint64_t *evals, uint8_t *pid_layer, int32_t *pid_rank)
 {
     return search_common(ix, queries_dev, true, nq, knbn, ef, ids, dist, count, evals, pid_layer, pid_rank);
+}
+/* sketch the request genomes, then ONE parallel_search (sketch_and_request_dir_compressedkmer, /root/reference/src/dna/dnarequest.rs:240-360) as one call:
+ * with the dense strategy and more than one join batch the sketch of batch b + 1 runs on a second stream beside the count matrix of batch b. */
+int gs_index_sketch_and_search_dev(gs_index *ix, const gs_sketch_params *p, const void *seq_dev, uint64_t seq_bytes, const uint64_t *rec_start_dev, const uint64_t *rec_len_dev,
+                                   uint64_t n_rec, const uint64_t *genome_rec_off_dev, uint64_t n_genomes, void *sig_out_dev, uint32_t knbn, uint32_t ef, uint64_t *ids, float *dist,
+                                   uint32_t *count, uint64_t *evals)
+{
+    GS_REQUIRE(ix && p, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(knbn >= 1 && ef >= 1, GS_ERR_INVALID, "knbn and ef must be positive");
+    if (n_genomes == 0) return GS_OK;
+    GS_REQUIRE(seq_dev && rec_start_dev && rec_len_dev && genome_rec_off_dev && ids && dist, GS_ERR_INVALID, "null argument");
+    GS_REQUIRE(ix->n > 0, GS_ERR_STATE, "search on an empty index");
+    int rc = gs_check_params(p);
+    if (rc) return rc;
+    GS_REQUIRE(gs_sig_kind(p) == ix->prm.kind && p->sketch_size == ix->prm.m, GS_ERR_INVALID, "the sketcher's signatures (kind %d, length %u) are not the index's (kind %d, length %u)",
+               gs_sig_kind(p), p->sketch_size, ix->prm.kind, ix->prm.m);
+    gs_ctx *c = ix->ctx;
+    GS_CTX_LOCK(c);
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    const uint64_t nq = n_genomes;
+    gs::PoolBuf dq(c, 32), sigbuf(c, 60);
+    if ((rc = dq.alloc(ix->stride * nq))) return rc;
+    uint8_t *sig = (uint8_t *)sig_out_dev;
+    if (!sig) { if ((rc = sigbuf.alloc(ix->user_rowbytes * nq))) return rc; sig = (uint8_t *)sigbuf.p; }
+    const uint64_t maxq = gs::match_join_max_queries(), parts = (nq + maxq - 1) / maxq, jq = (nq + parts - 1) / parts;
+    const char *pe = getenv("GS_REQUEST_PIPELINE");
+    const bool pipe = !(pe && !atoi(pe)) && parts >= 2 && (p->algo == GS_ALGO_OPTDENS || p->algo == GS_ALGO_REVOPTDENS) && gs::use_join(ix) &&
+                      gs::search_goes_dense(ix, nq, knbn, ef);
+    if (!pipe) {
+        if ((rc = gs::sketch_dev_impl(c, p, seq_dev, seq_bytes, rec_start_dev, rec_len_dev, n_rec, genome_rec_off_dev, nq, sig, true))) return rc;
+        if ((rc = gs::upload_user_rows(ix, dq.p, sig, nq, hipMemcpyDeviceToDevice))) return rc;
+        if ((rc = gs::search_dev(ix, dq.p, nq, knbn, ef, ids, dist, count, evals))) return rc;
+        if ((rc = gs::finish_ids(ix, ids, nq * knbn, nullptr, nullptr))) return rc;
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return GS_OK;
+    }
+    if (!c->child && (rc = gs_ctx_create(&c->child, c->device, nullptr))) return rc;
+    gs_ctx *w = c->child;
+    std::vector<hipEvent_t> ev(parts, nullptr);
+    std::vector<uint8_t> waited(parts, 0);
+    hipEvent_t ev_in = nullptr;
+    auto cleanup = [&]() { for (auto e : ev) if (e) (void)hipEventDestroy(e); if (ev_in) (void)hipEventDestroy(ev_in); };
+#define GS_FUSED_FAIL(code) do { const int rc_ = (code); (void)hipStreamSynchronize(w->stream); (void)hipStreamSynchronize(c->stream); ix->feed = nullptr; cleanup(); return rc_; } while (0)
+    // the sketches read what the caller produced on this context's stream
+    if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev_in, c->stream) != hipSuccess || hipStreamWaitEvent(w->stream, ev_in, 0) != hipSuccess) {
+        gs::set_error("event setup failed"); GS_FUSED_FAIL(GS_ERR_HIP);
+    }
+    w->profile = c->profile;
+    for (uint64_t b = 0; b < parts; b++) {
+        const uint64_t g0 = b * jq, nb = std::min<uint64_t>(jq, nq - g0);
+        // (seq_bytes only feeds the launch heuristics: this batch's share of it)
+        if ((rc = gs::sketch_dev_impl(w, p, seq_dev, std::max<uint64_t>(seq_bytes / nq * nb, 64), rec_start_dev, rec_len_dev, n_rec, genome_rec_off_dev + g0, nb, sig + g0 * ix->user_rowbytes, false))) GS_FUSED_FAIL(rc);
+        if (hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[b], w->stream) != hipSuccess) { gs::set_error("event setup failed"); GS_FUSED_FAIL(GS_ERR_HIP); }
+    }
+    std::function<int(uint64_t, uint64_t)> feed = [&](uint64_t q0, uint64_t nb) -> int {
+        for (uint64_t b = q0 / jq; b < parts && b * jq < q0 + nb; b++)
+            if (!waited[b]) { GS_HIP_CHECK(hipStreamWaitEvent(c->stream, ev[b], 0)); waited[b] = 1; }
+        return gs::upload_user_rows(ix, dq.as<uint8_t>() + q0 * ix->stride, sig + q0 * ix->user_rowbytes, nb, hipMemcpyDeviceToDevice);
+    };
+    ix->feed = &feed; ix->feed_base = dq.as<uint8_t>();
+    rc = gs::search_dev(ix, dq.p, nq, knbn, ef, ids, dist, count, evals);
+    ix->feed = nullptr;
+    if (rc) GS_FUSED_FAIL(rc);
+    if ((rc = gs::finish_ids(ix, ids, nq * knbn, nullptr, nullptr))) GS_FUSED_FAIL(rc);
+    GS_HIP_CHECK(hipStreamSynchronize(w->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    // the worker stream's kernel timings belong to this context's accounts
+    for (int f = 0; f < gs::FAM_COUNT; f++) {
+        auto &src = w->prof[f].pending;
+        c->prof[f].pending.insert(c->prof[f].pending.end(), src.begin(), src.end());
+        src.clear();
+    }
+    w->profile = false;
+    cleanup();
+#undef GS_FUSED_FAIL
+    return GS_OK;
 }
 int gs_index_set_ids(gs_index *ix, const uint64_t *ids, uint64_t n)
 {

@@ -134,6 +134,9 @@ int hamming_blocks(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t stri
                    uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out);
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);
 
+// gs_sketch.hip: the device sketch of a batch on context c's stream; sync_at_end = false leaves the results in flight (optdens / revoptdens only)
+int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint64_t seq_bytes, const uint64_t *rec_start, const uint64_t *rec_len, uint64_t n_rec,
+                    const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out, bool sync_at_end);
 // gs_radix.hip: stable LSD radix sort of 64-bit keys (bits [0, endbit)) between two buffers, and run-length encoding of a sorted array
 size_t radix_scratch_bytes(uint64_t n);
 int radix_sort_u64(gs_ctx *c, uint64_t *keys, uint64_t *alt, uint64_t n, int endbit, void *scratch, uint64_t **sorted_out);

@@ -1896,8 +1896,8 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     return GS_OK;
 }
 
-static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint64_t seq_bytes, const uint64_t *rec_start,
-                           const uint64_t *rec_len, uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out)
+int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint64_t seq_bytes, const uint64_t *rec_start,
+                    const uint64_t *rec_len, uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out, bool sync_at_end)
 {
     int rc = gs_check_params(p);
     if (rc) return rc;
@@ -1920,7 +1920,9 @@ static int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq
         rc = launch_oph(c, p, (const uint8_t *)seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(),
                         n_genomes, avg_units, table.as<uint32_t>(), win.as<uint32_t>(), (float *)sig_out);
         if (rc) return rc;
-        GS_HIP_CHECK(hipStreamSynchronize(c->stream));   // scratch lifetime
+        // (the scratch slots are only reused by later calls on this context, i.e. behind these kernels on its stream: a caller that pipelines
+        // several sketches - gs_index_sketch_and_search_dev - may leave the wait to its own events)
+        if (sync_at_end) GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         return GS_OK;
     }
     if (p->algo == GS_ALGO_SUPER || p->algo == GS_ALGO_SUPER2) {
@@ -1970,7 +1972,7 @@ int gs_sketch_batch_dev(gs_ctx *c, const gs_sketch_params *p, const void *seq_de
                         const uint64_t *rec_len_dev, uint64_t n_rec, const uint64_t *genome_rec_off_dev, uint64_t n_genomes,
                         void *sig_out_dev)
 {
-    return gs::sketch_dev_impl(c, p, seq_dev, seq_bytes, rec_start_dev, rec_len_dev, n_rec, genome_rec_off_dev, n_genomes, sig_out_dev);
+    return gs::sketch_dev_impl(c, p, seq_dev, seq_bytes, rec_start_dev, rec_len_dev, n_rec, genome_rec_off_dev, n_genomes, sig_out_dev, true);
 }
 
 int gs_sketch_batch(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint64_t seq_bytes, const uint64_t *rec_start,
@@ -2006,7 +2008,7 @@ int gs_sketch_batch(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint6
         GS_HIP_CHECK(hipMemcpyAsync(drl.p, rec_len, 8 * n_rec, hipMemcpyHostToDevice, c->stream));
     }
     GS_HIP_CHECK(hipMemcpyAsync(dgo.p, genome_rec_off, 8 * (n_genomes + 1), hipMemcpyHostToDevice, c->stream));
-    rc = gs::sketch_dev_impl(c, p, dseq.p, padded, drs.as<uint64_t>(), drl.as<uint64_t>(), n_rec, dgo.as<uint64_t>(), n_genomes, dsig.p);
+    rc = gs::sketch_dev_impl(c, p, dseq.p, padded, drs.as<uint64_t>(), drl.as<uint64_t>(), n_rec, dgo.as<uint64_t>(), n_genomes, dsig.p, true);
     if (rc) return rc;
     GS_HIP_CHECK(hipMemcpyAsync(sig_out, dsig.p, sigbytes, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -212,6 +212,12 @@ int      gs_index_parallel_search_pid(gs_index *, const void *queries, uint64_t 
 int      gs_index_parallel_search_pid_dev(gs_index *, const void *queries_dev, uint64_t nq, uint32_t knbn, uint32_t ef, uint64_t *ids_out_dev,
                                           float *dist_out_dev, uint32_t *count_out_dev, uint64_t *evals_out_dev, uint8_t *pid_layer_out_dev,
                                           int32_t *pid_rank_out_dev);
+/* sketch_and_request (sketch the request genomes, then ONE parallel_search: sketch_and_request_dir_compressedkmer, dnarequest.rs:240-360) as one call on
+ * device-resident genomes (layout of gs_sketch_batch_dev). Same answers as gs_sketch_batch_dev + gs_index_parallel_search_dev; with the dense strategy the
+ * sketch of the next <= 3276 genomes runs on a second stream beside the count matrix of the previous ones. sig_out_dev (optional): the n_genomes signatures. */
+int      gs_index_sketch_and_search_dev(gs_index *, const gs_sketch_params *, const void *seq_dev, uint64_t seq_bytes, const uint64_t *rec_start_dev,
+                                        const uint64_t *rec_len_dev, uint64_t n_rec, const uint64_t *genome_rec_off_dev, uint64_t n_genomes, void *sig_out_dev,
+                                        uint32_t knbn, uint32_t ef, uint64_t *ids_out_dev, float *dist_out_dev, uint32_t *count_out_dev, uint64_t *evals_out_dev);
 /* exact top-k by exhaustive DistHamming (recall ground truth; also what bindash.rs:120-157 computes) */
 int      gs_index_bruteforce_search(gs_index *, const void *queries, uint64_t nq, uint32_t knbn,
                                     uint64_t *ids_out, float *dist_out);

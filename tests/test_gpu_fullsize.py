@@ -157,3 +157,56 @@ def test_dense_search_on_very_large_graphs(gpu_ctx, monkeypatch, n, placement):
     for name, a, b in zip(("ids", "distances", "counts", "evaluations"), got, want):
         assert np.array_equal(_bits(a), _bits(b)), (placement, name)
     assert st["pops"] > 0, st                                               # the dense traversal ran (its order-free phase under both placements: test_dense_traversal_placements_and_regimes)
+
+
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_sketch_and_search_in_one_call(gpu_ctx, monkeypatch, pipeline):
+    """gs_index_sketch_and_search_dev (the reference's sketch_and_request_dir_compressedkmer, /root/reference/src/dna/dnarequest.rs:240-360: sketch the
+    request genomes, then one parallel_search): with several join batches the sketch of the next batch runs on a second stream beside the count matrix
+    of the previous one. Signatures, ids, distances, counts and evaluation counts == the two separate calls (which the other tests pin to the oracle)."""
+    import ctypes as C
+    import gsearch_amd as G
+    ctx, lib, chk = gpu_ctx, gpu_ctx.L, G._lib.check
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_REQUEST_PIPELINE", pipeline)
+    k, m, L, n, nq, knbn, ef = 21, 512, 60_000, 6000, 400, 10, 200
+    words = (L + 31) // 32
+    gb = words * 8
+    prm = G.SeqSketcherParams(k, m, "optdens")
+    nrec = max(n, nq)
+    d_seq = ctx.alloc(nrec * gb + 64)
+    d_rs, d_rl, d_go = ctx.alloc(8 * nrec), ctx.alloc(8 * nrec), ctx.alloc(8 * (nrec + 1))
+    d_sig, d_qsig, d_qsig2 = ctx.alloc(n * m * 4), ctx.alloc(nq * m * 4), ctx.alloc(nq * m * 4)
+    outs = [[ctx.alloc(8 * nq * knbn), ctx.alloc(4 * nq * knbn), ctx.alloc(4 * nq), ctx.alloc(8 * nq)] for _ in range(2)]
+    hn = None
+    try:
+        ctx.upload(d_rs, np.arange(nrec, dtype=np.uint64) * np.uint64(words * 32)); ctx.upload(d_rl, np.full(nrec, L, np.uint64)); ctx.upload(d_go, np.arange(nrec + 1, dtype=np.uint64))
+        chk(lib.gs_synth_dna_family_dev(ctx.h, 7, 0, n, L, 60, 0.001, 0.08, d_seq))
+        chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, n * gb + 64, d_rs, d_rl, n, d_go, n, d_sig))
+        hn = G.Hnsw.new(16, n, 16, 100, G.DistHamming(ctx), dtype=np.float32, seed=4, insert_batch=128, ctx=ctx)
+        hn.modify_level_scale(0.25); hn.set_extend_candidates(True)
+        hn._ensure(m)
+        chk(lib.gs_index_parallel_insert_dev(hn.h, d_sig, n))
+        chk(lib.gs_synth_dna_family_dev(ctx.h, 7, 1_000_000, nq, L, 60, 0.001, 0.08, d_seq))
+        monkeypatch.setenv("GS_JOIN_MAXQ", "96")                      # (after the build, whose insert batches are 128 rows) 5 join batches of 80 for 400 queries
+        # the two separate calls
+        chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, nq * gb + 64, d_rs, d_rl, nq, d_go, nq, d_qsig))
+        chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, nq, knbn, ef, *outs[0]))
+        # one call
+        hn.sketch_and_search_dev(prm, d_seq, nq * gb + 64, d_rs, d_rl, nq, d_go, nq, knbn, ef, *outs[1], d_sig=d_qsig2)
+        a = ctx.download(d_qsig, (nq, m), np.uint32); b = ctx.download(d_qsig2, (nq, m), np.uint32)
+        assert np.array_equal(a, b)
+        for (pa, pb), shape, dt in zip(zip(outs[0], outs[1]), ((nq, knbn), (nq, knbn), (nq,), (nq,)), (np.uint64, np.uint32, np.uint32, np.uint64)):
+            assert np.array_equal(ctx.download(pa, shape, dt), ctx.download(pb, shape, dt))
+        ev = ctx.download(outs[1][3], (nq,), np.uint64)
+        assert (ev >= ef).all()
+        # without a signature buffer of the caller's, and a sketcher that does not fit the index
+        hn.sketch_and_search_dev(prm, d_seq, nq * gb + 64, d_rs, d_rl, nq, d_go, nq, knbn, ef, *outs[1])
+        assert np.array_equal(ctx.download(outs[0][0], (nq, knbn), np.uint64), ctx.download(outs[1][0], (nq, knbn), np.uint64))
+        with pytest.raises(G.GsError):
+            hn.sketch_and_search_dev(G.SeqSketcherParams(k, m + 1, "optdens"), d_seq, nq * gb + 64, d_rs, d_rl, nq, d_go, nq, knbn, ef, *outs[1])
+    finally:
+        if hn is not None:
+            hn.close()
+        for p_ in [d_seq, d_rs, d_rl, d_go, d_sig, d_qsig, d_qsig2] + outs[0] + outs[1]:
+            ctx.free(p_)
