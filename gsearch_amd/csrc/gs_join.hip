@@ -129,7 +129,7 @@ __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t
 //     every member that holds the key: the wavefront expands it together, lanes over the cluster's members in the cluster-sorted key copy
 //     `qs` (cl_lo / qlist: member ranges and query numbers), one atomic per member found. (A first version queued these hits for a kernel
 //     of its own: 1.4e7 same-address queue atomics per batch and 3e8 count atomics no longer hidden under the probes - 35 % slower.)
-constexpr uint32_t JTAG_MASK = 0xFFFu, JTAG_MULTI = 0x1000u;
+constexpr uint32_t JTAG_MASK = 0xFFFu, JTAG_MULTI = 0x1000u, JTAG_MORE = 0x80000000u;
 constexpr int JTAG_CL_SHIFT = 13;
 constexpr uint32_t JCL_MAX = 2047;      // cluster ids 1..2047
 
@@ -142,12 +142,15 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
 {
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     static_assert(!CL || SR == 1, "clusters: request batches only");
-    constexpr bool DEDUP = CL && sizeof(T) == 4;                 // key + tag word in one 8-byte entry
+    constexpr bool E8 = sizeof(T) == 4 && SR == 1;               // 4-byte keys, one slot per round: key + tag word in ONE 8-byte entry (a probe step is one LDS read; an
+                                                                 // insert sees complete entries, so it can flag the entries behind which ANOTHER entry holds the same key:
+                                                                 // a hit on an entry without JTAG_MORE ends the probe instead of walking on to the next empty slot)
+    constexpr bool DEDUP = CL && E8;                             // ... and a cluster's equal keys can share one entry
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
     constexpr uint32_t BMW = (1u << JB_LOG2) / 32;                // bitmap words per slot
     uint32_t *tag = (uint32_t *)s_raw;                            // [SR][P]            (DEDUP: ent[P] of {key, tag word} first, then the bitmap)
-    uint32_t *bm = DEDUP ? (uint32_t *)(s_raw + 8 * (size_t)P) : (uint32_t *)(s_raw + 4 * (size_t)P * SR);      // [SR][BMW]
+    uint32_t *bm = E8 ? (uint32_t *)(s_raw + 8 * (size_t)P) : (uint32_t *)(s_raw + 4 * (size_t)P * SR);      // [SR][BMW]
     T *key = (T *)(s_raw + (4 * (size_t)P + (size_t)BMW * 4) * SR);   // [SR][P]
     unsigned long long *ent = (unsigned long long *)s_raw;
     // chunk_major: consecutive workgroups sweep the slot blocks of ONE node chunk, so the counters being updated at any time are
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     for (uint32_t sr = s0; sr < s1; sr += SR) {
         const uint32_t nr = s1 - sr < (uint32_t)SR ? s1 - sr : (uint32_t)SR;       // slots of this round
         join_lds_barrier();                                       // the previous round's probes are done
-        if (DEDUP) { for (uint32_t i = threadIdx.x; i < P; i += JT) ent[i] = 0ull; }
+        if (E8) { for (uint32_t i = threadIdx.x; i < P; i += JT) ent[i] = 0ull; }
         else for (uint32_t i = threadIdx.x; i < P * SR; i += JT) tag[i] = 0;
         for (uint32_t i = threadIdx.x; i < BMW * SR; i += JT) bm[i] = 0;
         join_lds_barrier();
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
             const uint32_t hq = join_hash(k);
             atomicOr(&bm[r * BMW + (hq >> (32 - JB_LOG2 + 5))], 1u << ((hq >> (32 - JB_LOG2)) & 31));
             uint32_t h = hq >> sh;
-            if (DEDUP) {
+            if (E8) {
                 const unsigned long long nw = ((unsigned long long)tw << 32) | (uint32_t)k;
                 for (;;) {
                     const unsigned long long old = atomicCAS(&ent[h], 0ull, nw);
@@ -192,10 +195,13 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                     // same key already entered by a query of the same cluster: that entry stands for this query too
                     // (only clusters numbered below dedup_below - the large ones - share entries: a run of two or three equal keys is cheaper to walk
                     // than a chance match on a shared entry is to expand)
-                    if ((tw >> JTAG_CL_SHIFT) - 1u < dedup_below - 1u && (uint32_t)old == (uint32_t)k && ((uint32_t)(old >> 32) >> JTAG_CL_SHIFT) == (tw >> JTAG_CL_SHIFT)) {
+                    if (DEDUP && (tw >> JTAG_CL_SHIFT) - 1u < dedup_below - 1u && (uint32_t)old == (uint32_t)k &&
+                        (((uint32_t)(old >> 32) >> JTAG_CL_SHIFT) & JCL_MAX) == (tw >> JTAG_CL_SHIFT)) {
                         atomicOr((uint32_t *)&ent[h] + 1, JTAG_MULTI);
                         break;
                     }
+                    // this key again, further down the run: the entry passed here is not the last one with it
+                    if ((uint32_t)old == (uint32_t)k && !((uint32_t)(old >> 32) & JTAG_MORE)) atomicOr((uint32_t *)&ent[h] + 1, JTAG_MORE);
                     h = (h + 1) & mask;
                 }
             } else {
@@ -249,11 +255,12 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                             if (t == 0u) have = false;
                             else {
                                 if ((uint32_t)en == (uint32_t)vv) {
+                                    if (!(t & JTAG_MORE)) have = false;                          // the last entry with this key
                                     const uint32_t ni = it * JU + uu;
                                     const uint64_t el = e0 + (uint64_t)ni * JT;                  // node within this column range
                                     bool count_it = true;
-                                    if (t >> 12) {                                               // entry of a cluster
-                                        const uint32_t cl = t >> JTAG_CL_SHIFT;
+                                    if ((t >> 12) & 0x7FFFFu) {                                  // entry of a cluster
+                                        const uint32_t cl = (t >> JTAG_CL_SHIFT) & JCL_MAX;
                                         const uint32_t nl = ((uu & 2u ? lab4.y : lab4.x) >> ((uu & 1u) * 16)) & 0xFFFFu;      // this node's cluster
                                         if (nl == cl) count_it = false;                          // own cluster: the block compare writes this pair's counter
                                         else if (t & JTAG_MULTI) { mitem = ((ni + 1) << 16) | cl; count_it = false; }
@@ -293,15 +300,17 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                 for (;;) {
                     if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
                     if (!have) break;
-                    const uint32_t t = tag[tb + hh];
-                    const T k = key[tb + hh];
+                    uint32_t t; T k;
+                    if (E8) { const unsigned long long en = ent[hh]; t = (uint32_t)(en >> 32); k = (T)(uint32_t)en; }
+                    else { t = tag[tb + hh]; k = key[tb + hh]; }
                     if (t == 0u) { have = false; continue; }
                     if (k == vv) {
+                        if (E8 && !(t & JTAG_MORE)) have = false;                            // the last entry with this key
                         const uint32_t ni = it * JU + uu;
                         const uint64_t el = e0 + (uint64_t)ni * JT;                          // node within this column range
                         bool count_it = true;
-                        if (CL && (t >> 12))                                                 // (8-byte keys: no shared entries, only the own-cluster rule)
-                            count_it = (((uu & 2u ? lab4.y : lab4.x) >> ((uu & 1u) * 16)) & 0xFFFFu) != (t >> JTAG_CL_SHIFT);
+                        if (CL && ((t >> 12) & 0x7FFFFu))                                    // (8-byte keys: no shared entries, only the own-cluster rule)
+                            count_it = (((uu & 2u ? lab4.y : lab4.x) >> ((uu & 1u) * 16)) & 0xFFFFu) != ((t >> JTAG_CL_SHIFT) & JCL_MAX);
                         if (count_it) {
                             const uint64_t e = col0 + el;                                    // column of the count matrix (col0: the node range starts there)
                             uint32_t st = GS_SEL4((sticky + it * JU), uu);
