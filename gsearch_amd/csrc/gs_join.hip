@@ -33,10 +33,11 @@ __device__ __forceinline__ bool never_equal(T v)      // f32 NaN != anything, it
     return false;
 }
 
-// rows (row-major, strided) -> columns: cols[s * colcap + first + i] = rows[i][s]   (32 x 32 LDS transpose)
+// rows (row-major, strided) -> columns: cols[s * colcap + first + i] = rows[i][s]   (32 x 32 LDS transpose). The column copy is private to the join, so f32
+// values are stored canonical (-0 as +0); a NaN stays what it is - no table ever holds one, so it cannot match
 template <typename T>
 __global__ __launch_bounds__(256) void k_rows_to_cols(const uint8_t *__restrict__ rows, uint64_t stride, uint64_t nrows, uint32_t m, T *__restrict__ cols,
-                                                       uint64_t colcap, uint64_t first)
+                                                       uint64_t colcap, uint64_t first, int f32)
 {
     __shared__ T tile[32][33];
     const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_rows_to_cols(const uint8_t *__restrict_
     __syncthreads();
     for (uint32_t j = ty; j < 32; j += 8) {
         const uint64_t s = s0 + j, r = r0 + tx;
-        if (s < m && r < nrows) cols[s * colcap + first + r] = tile[tx][j];
+        if (s < m && r < nrows) { const T v = tile[tx][j]; cols[s * colcap + first + r] = (f32 && v == (T)0x80000000u) ? (T)0 : v; }      // f32: -0 stored as +0 (canonical keys)
     }
 }
 
@@ -89,6 +90,14 @@ __device__ __forceinline__ void join_lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// orders the LDS traffic of ONE wavefront (its survivor queue): the LDS serves a wavefront's instructions in order, the compiler must too
+__device__ __forceinline__ void join_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // one match of (tag = query + 1) with the lane's node `slot`: run-length accumulate in the lane's "sticky" register for that node
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                                                                  // insert sees complete entries, so it can flag the entries behind which ANOTHER entry holds the same key:
                                                                  // a hit on an entry without JTAG_MORE ends the probe instead of walking on to the next empty slot)
     constexpr bool DEDUP = CL && E8;                             // ... and a cluster's equal keys can share one entry
+    constexpr bool DENSE = E8 && !CL;                            // survivors of the bitmap are compacted per wavefront and probed one per lane (below)
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
     constexpr uint32_t BMW = (1u << JB_LOG2) / 32;                // bitmap words per slot
@@ -168,9 +178,16 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
     uint32_t nexp = 0;                                            // CL: chance matches on shared entries this wavefront expanded
 #pragma unroll
     for (int i = 0; i < JN; i++) sticky[i] = 0;
-    T vn[JU];
+    // DENSE: the lane's node validity as a mask, its first node's matrix column, and the wavefront's survivor queue
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t vmask = 0;
 #pragma unroll
-    for (int u = 0; u < JU; u++) { const uint64_t e = e0 + (uint64_t)u * JT; vn[u] = (e < n && s0 < s1) ? cols[(uint64_t)s0 * colcap + e] : (T)0; }
+    for (int u = 0; u < JN; u++) vmask |= (uint32_t)(e0 + (uint64_t)u * JT < n) << u;
+    const uint64_t ebase = col0 + e0;
+    uint2 *wq = (uint2 *)(s_raw + 8 * (size_t)P + (size_t)BMW * 4) + (threadIdx.x >> 6) * 64;
+    T vn[DENSE ? JN : JU];
+#pragma unroll
+    for (int u = 0; u < (DENSE ? JN : JU); u++) { const uint64_t e = e0 + (uint64_t)u * JT; vn[u] = (e < n && s0 < s1) ? cols[(uint64_t)s0 * colcap + e] : (T)0; }
     for (uint32_t sr = s0; sr < s1; sr += SR) {
         const uint32_t nr = s1 - sr < (uint32_t)SR ? s1 - sr : (uint32_t)SR;       // slots of this round
         join_lds_barrier();                                       // the previous round's probes are done
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
             if (never_equal<KIND, T>(k)) continue;
             k = canon<KIND, T>(k);
             const uint32_t hq = join_hash(k);
-            atomicOr(&bm[r * BMW + (hq >> (32 - JB_LOG2 + 5))], 1u << ((hq >> (32 - JB_LOG2)) & 31));
+            atomicOr(&bm[r * BMW + (hq >> (32 - JB_LOG2 + 5))], (1u << ((hq >> (32 - JB_LOG2)) & 31)) | (1u << ((hq >> (27 - JB_LOG2)) & 31)));      // two bits of ONE word
             uint32_t h = hq >> sh;
             if (E8) {
                 const unsigned long long nw = ((unsigned long long)tw << 32) | (uint32_t)k;
@@ -214,6 +231,94 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
         for (uint32_t r = 0; r < nr; r++) {
             const uint32_t s = sr + r, tb = r * P, bb = r * BMW;
             const T *col = cols + (uint64_t)s * colcap;
+            if constexpr (DENSE) {
+                // The survivors of the bitmap are ~7 % of the values (6 % chance matches of unrelated genomes, 1 % false positives): probed in place, a
+                // wavefront runs the probe loop for its lane with the longest chain while a tenth of its lanes work. Instead every survivor is pushed
+                // to a 64-entry queue of the wavefront ({value, owner lane | value index | the tag its node's accumulator holds}), lanes 0..count-1
+                // probe ONE value each (static registers, no selects), send every hit but one straight to memory and hand one tag - the accumulator's
+                // own if it is among the hits, otherwise the first - back through the queue slot to the owner, whose accumulator logic then runs on a
+                // statically indexed register. Values are queued whole (all lanes that want value u, or none), so a burst - a related query makes 64
+                // consecutive nodes match in one slot - takes another trip of the loop.
+                uint32_t pend = 0;
+#pragma unroll
+                for (int u0 = 0; u0 < JN; u0 += 4) {                 // (four bitmap words in flight at a time; the columns hold canonical values)
+                    uint32_t hsd[4], bwd[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { hsd[u] = join_hash(vn[u0 + u]); bwd[u] = bm[hsd[u] >> (32 - JB_LOG2 + 5)]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t pass = (vmask >> (u0 + u)) & (bwd[u] >> ((hsd[u] >> (32 - JB_LOG2)) & 31)) & (bwd[u] >> ((hsd[u] >> (27 - JB_LOG2)) & 31)) & 1u;
+                        pend |= pass << (u0 + u);
+                    }
+                }
+                while (__any(pend != 0u)) {
+                    uint32_t qn = 0;
+                    const uint32_t pend0 = pend;
+#pragma unroll
+                    for (int u = 0; u < JN; u++) {
+                        const bool want = (pend >> u) & 1u;
+                        const unsigned long long mw = __ballot(want);
+                        const uint32_t cw = (uint32_t)__popcll(mw);
+                        if (cw != 0u && qn + cw <= 64u) {
+                            if (want) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u))] =
+                                          make_uint2((uint32_t)vn[u], lane | ((uint32_t)u << 6) | (sticky[u] << 9));
+                            qn += cw; pend &= ~(1u << u);
+                        }
+                    }
+                    join_wave_sync();
+                    if (lane < qn) {
+                        const uint2 qe = wq[lane];
+                        uint32_t st = qe.y >> 9, flp = 0;                                   // the node's accumulator: tag | run << 12, run <= 255
+                        const uint32_t eo = (qe.y & 63u) + ((qe.y >> 6) & 7u) * JT - lane;  // the owner's node, relative to this lane's first
+                        uint32_t hh = join_hash((T)qe.x) >> sh;
+                        for (;;) {
+                            const unsigned long long en = ent[hh];
+                            const uint32_t t = (uint32_t)(en >> 32);
+                            if (t == 0u) break;
+                            if ((uint32_t)en == qe.x) {
+                                // the accumulator rule of GS_JOIN_HIT as selects; what it sends to memory waits in flp - nearly every chain sends at
+                                // most one, so the address arithmetic and the atomic sit once behind the loop
+                                const uint32_t tg = t & JTAG_MASK, one = tg | 0x1000u;
+                                const bool same = (st & 0xFFFu) == tg, weak = st < 0x2000u, full = st >= 0xFF000u;
+                                const uint32_t fl = same ? (full ? st : 0u) : (weak ? st : one);
+                                st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
+                                if (fl) {
+                                    if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                                    flp = fl;
+                                }
+                                if (!(t & JTAG_MORE)) break;                                // the last entry with this key
+                            }
+                            hh = (hh + 1) & mask;
+                        }
+                        if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                        wq[lane].x = st;
+                    }
+                    join_wave_sync();
+                    // the owners take their accumulators back: queue positions are those of the push (the same ballots in the same order)
+                    const uint32_t queued = pend0 & ~pend;
+                    uint32_t qb = 0;
+#pragma unroll
+                    for (int u = 0; u < JN; u++) {
+                        const bool mine = (queued >> u) & 1u;
+                        const unsigned long long mw = __ballot(mine);
+                        if (mw != 0ull) {
+                            if (mine) sticky[u] = wq[qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u))].x;
+                            qb += (uint32_t)__popcll(mw);
+                        }
+                    }
+                    join_wave_sync();
+                }
+                // the next slot's values arrive while its table is built
+                if (s + 1 < s1) {
+                    // (the base through readfirstlane: the compiler then addresses with a scalar base + the lane's 32-bit offset instead of keeping a
+                    // per-lane 64-bit pointer alive across the slot loop - which it spilled, and whose reload waits for every atomic in flight)
+                    const uint64_t cb = (uint64_t)(col + colcap + (uint64_t)bchunk * (JT * JN));
+                    typedef const T __attribute__((address_space(1))) *gptr;       // (an integer cast alone would leave a flat pointer)
+                    const gptr cn = (gptr)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cb >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cb));      // (the builtin returns int)
+#pragma unroll
+                    for (int u = 0; u < JN; u++) { const gptr cu = cn + u * JT; vn[u] = ((vmask >> u) & 1u) ? cu[threadIdx.x] : (T)0; }
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < JN / JU; it++) {
                 uint2 lab4 = make_uint2(0u, 0u);
@@ -230,7 +335,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                 for (int u = 0; u < JU; u++) {
                     const uint64_t e = e0 + (uint64_t)(it * JU + u) * JT;
                     const uint32_t bit = hs[u] >> (32 - JB_LOG2);
-                    const uint32_t pass = (uint32_t)(e < n) & (uint32_t)!never_equal<KIND, T>(vn[u]) & (bw[u] >> (bit & 31)) & 1u;
+                    const uint32_t pass = (uint32_t)(e < n) & (uint32_t)!never_equal<KIND, T>(vn[u]) & (bw[u] >> (bit & 31)) & (bw[u] >> ((hs[u] >> (27 - JB_LOG2)) & 31)) & 1u;
                     pend |= pass << u;
                 }
                 // next values: the following nodes of this slot, or the first nodes of the next slot
@@ -322,6 +427,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                     hh = (hh + 1) & mask;
                 }
                 }
+            }
             }
         }
     }
@@ -490,7 +596,7 @@ __global__ __launch_bounds__(256) void k_query_cols_list(const uint8_t *__restri
         if (s < m && r < nh) qs[s * nh + r] = tile[tx][j];
     }
 }
-struct JoinGeom { uint32_t chunks, log2p; size_t lds1; };
+struct JoinGeom { uint32_t chunks, log2p; size_t lds1, ldsq; };
 
 template <int KIND, typename T, bool CL>
 static int join_launch(gs_ctx *c, const JoinGeom &g, const T *qkey, uint32_t nq, const void *cols, uint64_t colcap, uint64_t n, uint32_t slot_lo, uint32_t slot_hi,
@@ -514,7 +620,7 @@ static int join_launch(gs_ctx *c, const JoinGeom &g, const T *qkey, uint32_t nq,
         if (4 * g.lds1 <= 80 * 1024 && slots_per_wg >= 8) sr = 4; else if (2 * g.lds1 <= 80 * 1024 && slots_per_wg >= 4) sr = 2;
         if (getenv("GS_JOIN_SLOTS_PER_ROUND")) { const int e = atoi(getenv("GS_JOIN_SLOTS_PER_ROUND")); if (e == 1 || (e == 2 && 2 * g.lds1 <= 80 * 1024) || (e == 4 && 4 * g.lds1 <= 80 * 1024)) sr = e; }
     }
-    const size_t lds = g.lds1 * sr;
+    const size_t lds = g.lds1 * sr + (sr == 1 && !CL ? g.ldsq : 0);
     ProfScope ps(c, FAM_HAMMING);
 #define GS_JOIN_GO(KERN)                                                                                                                              \
     do {                                                                                                                                              \
@@ -585,6 +691,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     while (g.log2p < (uint32_t)JP_MAX_LOG2 && (double)(1u << g.log2p) * 0.4 < (double)nq) g.log2p++;
     g.chunks = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
     g.lds1 = (sizeof(T) + 4) * ((size_t)1 << g.log2p) + ((size_t)1 << JB_LOG2) / 8;
+    g.ldsq = sizeof(T) == 4 ? (size_t)(JT / 64) * 64 * 8 : 0;            // the wavefronts' survivor queues (one-slot rounds of 4-byte keys without clusters)
     const bool may_decline = declined && m >= 64 && n >= 4096;
     const char *ce = getenv("GS_JOIN_CLUSTER");
     // heavy blocks: request batches (the insert path passes no `declined`) large enough for phase 0 to be a small part of the work
@@ -752,8 +859,8 @@ int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t str
 {
     if (nrows == 0) return GS_OK;
     dim3 g((uint32_t)((nrows + 31) / 32), (m + 31) / 32);
-    if (kind == GS_KIND_U64) hipLaunchKernelGGL((k_rows_to_cols<uint64_t>), g, dim3(256), 0, c->stream, (const uint8_t *)rows, stride, nrows, m, (uint64_t *)cols, colcap, first);
-    else hipLaunchKernelGGL((k_rows_to_cols<uint32_t>), g, dim3(256), 0, c->stream, (const uint8_t *)rows, stride, nrows, m, (uint32_t *)cols, colcap, first);
+    if (kind == GS_KIND_U64) hipLaunchKernelGGL((k_rows_to_cols<uint64_t>), g, dim3(256), 0, c->stream, (const uint8_t *)rows, stride, nrows, m, (uint64_t *)cols, colcap, first, 0);
+    else hipLaunchKernelGGL((k_rows_to_cols<uint32_t>), g, dim3(256), 0, c->stream, (const uint8_t *)rows, stride, nrows, m, (uint32_t *)cols, colcap, first, (int)(kind == GS_KIND_F32));
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
