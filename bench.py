@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ATOMICS_PEAK = 1.86e10         # scattered no-return 32-bit atomics/s into a 2 GB working set (the count-matrix slab) measured on MI355X: tools/ubench_atomic, profiles/r02_ubench_atomic.txt
+ATOMICS_PEAK = 2.71e10         # scattered no-return 32-bit atomics/s, window resident in the Infinity Cache (<= 256 MB): the rate of the atomic units themselves, measured on MI355X
+ATOMICS_SLAB = 1.92e10         # ... uniformly random over a window of the size of a 2500-query count-matrix slab (1.43 GB): tools/ubench_atomic, profiles/r04_ubench_atomic.txt
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md:52-54: a wave64 VALU op issues in 2 cycles (SIMD-32)
 MASK64 = (1 << 64) - 1
 
@@ -491,9 +492,11 @@ def request_accounting(args, ctx, hn, lib, chk, torch, D, r):
         if join:
             col_bytes = float(N) * row_bytes                                   # the column store is streamed once per launch
             atom = st.get("join_atomics", 0)
-            kd.update({"class": "atomics", "algorithmic_bytes_per_launch": col_bytes + 2.0 * pairs_total / tile_n,
+            kd.update({"class": "valu + atomics (SQ counters: VALU issue 0.67 busy; without the atomics the kernel runs 0.8 of its time - profiles/r04_join_dense_pmc.txt, r04_join_without_atomics.log)",
+                       "algorithmic_bytes_per_launch": col_bytes + 2.0 * pairs_total / tile_n,
                        "column_stream_GBps": col_bytes * tile_n / (tile_ms * 1e-3) / 1e9, "atomics_per_launch": atom / tile_n,
                        "atomics_per_sec": atom / (tile_ms * 1e-3), "atomics_peak_per_sec": ATOMICS_PEAK, "frac_of_atomics_ceiling": atom / (tile_ms * 1e-3) / ATOMICS_PEAK,
+                       "atomics_uniform_random_slab_per_sec": ATOMICS_SLAB,
                        "traffic": pmc_traffic("k_match_join")})
             kd["achieved_GBps"] = kd["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
         else:

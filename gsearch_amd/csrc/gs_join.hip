@@ -155,7 +155,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                                                                  // insert sees complete entries, so it can flag the entries behind which ANOTHER entry holds the same key:
                                                                  // a hit on an entry without JTAG_MORE ends the probe instead of walking on to the next empty slot)
     constexpr bool DEDUP = CL && E8;                             // ... and a cluster's equal keys can share one entry
-    constexpr bool DENSE = E8 && !CL;                            // survivors of the bitmap are compacted per wavefront and probed one per lane (below)
+    constexpr bool DENSE = E8;                                   // survivors of the bitmap are compacted per wavefront and probed one per lane (below)
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
     constexpr uint32_t BMW = (1u << JB_LOG2) / 32;                // bitmap words per slot
@@ -184,22 +184,42 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
 #pragma unroll
     for (int u = 0; u < JN; u++) vmask |= (uint32_t)(e0 + (uint64_t)u * JT < n) << u;
     const uint64_t ebase = col0 + e0;
+    uint32_t labmask = 0;                                         // CL: which of the lane's nodes belong to a cluster at all (labels do not change from slot to slot)
+    if (CL && DENSE) {
+#pragma unroll
+        for (int it = 0; it < JN / JU; it++) {
+            const uint2 l4 = labT[it * JT];
+            labmask |= ((uint32_t)((l4.x & 0xFFFFu) != 0u) | (uint32_t)((l4.x >> 16) != 0u) << 1 | (uint32_t)((l4.y & 0xFFFFu) != 0u) << 2 | (uint32_t)((l4.y >> 16) != 0u) << 3) << (it * JU);
+        }
+    }
     uint2 *wq = (uint2 *)(s_raw + 8 * (size_t)P + (size_t)BMW * 4) + (threadIdx.x >> 6) * 64;
     T vn[DENSE ? JN : JU];
 #pragma unroll
     for (int u = 0; u < (DENSE ? JN : JU); u++) { const uint64_t e = e0 + (uint64_t)u * JT; vn[u] = (e < n && s0 < s1) ? cols[(uint64_t)s0 * colcap + e] : (T)0; }
     for (uint32_t sr = s0; sr < s1; sr += SR) {
         const uint32_t nr = s1 - sr < (uint32_t)SR ? s1 - sr : (uint32_t)SR;       // slots of this round
+        // one-slot rounds: the lane's query keys of this slot (at most JQ: nq <= 0.4 * 2^JP_MAX_LOG2) are requested together and before the barriers -
+        // loaded one by one inside the insert loop, each cost the workgroup a trip to memory with nothing else to do
+        // (scalar bases + an offset the compiler cannot hoist: kept across the slot loop, the four per-lane offsets were spilled and every reload waited)
+        constexpr int JQ = DENSE ? (int)((((1u << JP_MAX_LOG2) * 2) / 5 + JT - 1) / JT) : 1;
+        T kq[JQ];
+        if (DENSE) {
+            typedef const T __attribute__((address_space(1))) *gptr;
+            const uint64_t qb = (uint64_t)(qkey + (uint64_t)sr * nq);
+            const gptr qk = (gptr)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(qb >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)qb));
+            uint32_t o = threadIdx.x;
+            asm volatile("" : "+v"(o));
+#pragma unroll
+            for (int j = 0; j < JQ; j++) { const gptr qj = qk + j * JT; kq[j] = o + (uint32_t)j * JT < nq ? qj[o] : (T)0; }
+        }
         join_lds_barrier();                                       // the previous round's probes are done
         if (E8) { for (uint32_t i = threadIdx.x; i < P; i += JT) ent[i] = 0ull; }
         else for (uint32_t i = threadIdx.x; i < P * SR; i += JT) tag[i] = 0;
         for (uint32_t i = threadIdx.x; i < BMW * SR; i += JT) bm[i] = 0;
         join_lds_barrier();
-        for (uint32_t i = threadIdx.x; i < nq * nr; i += JT) {
-            const uint32_t r = SR == 1 ? 0 : i / nq, q = SR == 1 ? i : i - r * nq;
-            T k = qkey[(uint64_t)(sr + r) * nq + q];
+        auto insert_key = [&](const uint32_t r, const uint32_t q, T k) {
             const uint32_t tw = CL ? (q + 1) | ((uint32_t)qcl[q] << JTAG_CL_SHIFT) : q + 1;
-            if (never_equal<KIND, T>(k)) continue;
+            if (never_equal<KIND, T>(k)) return;
             k = canon<KIND, T>(k);
             const uint32_t hq = join_hash(k);
             atomicOr(&bm[r * BMW + (hq >> (32 - JB_LOG2 + 5))], (1u << ((hq >> (32 - JB_LOG2)) & 31)) | (1u << ((hq >> (27 - JB_LOG2)) & 31)));      // two bits of ONE word
@@ -225,6 +245,12 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                 while (atomicCAS(&tag[r * P + h], 0u, tw) != 0u) h = (h + 1) & mask;
                 key[r * P + h] = k;
             }
+        };
+        if (DENSE) {
+#pragma unroll
+            for (int j = 0; j < JQ; j++) { const uint32_t i = threadIdx.x + (uint32_t)j * JT; if (i < nq) insert_key(0u, i, kq[j]); }
+        } else {
+            for (uint32_t i = threadIdx.x; i < nq * nr; i += JT) { const uint32_t r = i / nq, q = i - r * nq; insert_key(r, q, qkey[(uint64_t)(sr + r) * nq + q]); }
         }
         join_lds_barrier();
 #pragma unroll 1
@@ -261,11 +287,79 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                         const uint32_t cw = (uint32_t)__popcll(mw);
                         if (cw != 0u && qn + cw <= 64u) {
                             if (want) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u))] =
-                                          make_uint2((uint32_t)vn[u], lane | ((uint32_t)u << 6) | (sticky[u] << 9));
+                                          make_uint2((uint32_t)vn[u], lane | ((uint32_t)u << 6) | (sticky[u] << 9) | (CL ? ((labmask >> u) & 1u) << 29 : 0u));
                             qn += cw; pend &= ~(1u << u);
                         }
                     }
                     join_wave_sync();
+                    if constexpr (CL) {
+                        // clusters: the same probe, but the wavefront stays together until its last lane is done, so that all 64 lanes can expand a
+                        // chance match on a shared entry. The node's own cluster is looked up (L2) only when the node has one AND the entry hit
+                        // belongs to a cluster: a percent of the nodes.
+                        bool have = lane < qn;
+                        uint2 qe = make_uint2(0u, 0u);
+                        if (have) qe = wq[lane];
+                        uint32_t st = (qe.y >> 9) & 0xFFFFFu, flp = 0;
+                        const uint32_t eloc = (qe.y & 63u) + ((qe.y >> 6) & 7u) * JT;                   // the owner's node, relative to the wavefront's first
+                        uint32_t hh = join_hash((T)qe.x) >> sh;
+                        for (;;) {
+                            uint32_t mitem = 0;                                                         // cluster of this lane's pending expansion
+                            if (have) {
+                                const unsigned long long en = ent[hh];
+                                const uint32_t t = (uint32_t)(en >> 32);
+                                if (t == 0u) have = false;
+                                else {
+                                    if ((uint32_t)en == qe.x) {
+                                        if (!(t & JTAG_MORE)) have = false;                             // the last entry with this key
+                                        bool count_it = true;
+                                        if ((t >> 12) & 0x7FFFFu) {                                     // entry of a cluster
+                                            const uint32_t cl = (t >> JTAG_CL_SHIFT) & JCL_MAX;
+                                            uint32_t nl = 0;
+                                            if ((qe.y >> 29) & 1u) {
+                                                const uint32_t uo = (qe.y >> 6) & 7u, to = threadIdx.x - lane + (qe.y & 63u);
+                                                nl = nodelab[(((uint64_t)bchunk * (JN / JU) + (uo >> 2)) * JT + to) * JU + (uo & 3u)];
+                                            }
+                                            if (nl == cl) count_it = false;                             // own cluster: the block compare writes this pair's counter
+                                            else if (t & JTAG_MULTI) { mitem = cl; count_it = false; }
+                                        }
+                                        if (count_it) {
+                                            const uint32_t tg = t & JTAG_MASK, one = tg | 0x1000u;
+                                            const bool same = (st & 0xFFFu) == tg, weak = st < 0x2000u, full = st >= 0xFF000u;
+                                            const uint32_t fl = same ? (full ? st : 0u) : (weak ? st : one);
+                                            st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
+                                            if (fl) {
+                                                if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom++; }
+                                                flp = fl;
+                                            }
+                                        }
+                                    }
+                                    hh = (hh + 1) & mask;
+                                }
+                            }
+                            unsigned long long pm = __ballot(mitem != 0u);
+                            while (pm) {
+                                const int src = __ffsll((long long)pm) - 1;
+                                pm &= pm - 1;
+                                nexp++;
+                                const uint32_t cl = __builtin_amdgcn_readlane(mitem, src), vsrc = __builtin_amdgcn_readlane(qe.x, src);
+                                const uint64_t e = ebase - lane + __builtin_amdgcn_readlane(eloc, src);
+                                const uint32_t lo = cl_lo[cl], hi = cl_lo[cl + 1];
+                                for (uint32_t pos = lo + lane; pos < hi; pos += 64) {
+                                    const T k2 = qs[(uint64_t)s * nh + pos];
+                                    if (!never_equal<KIND, T>(k2) && (uint32_t)canon<KIND, T>(k2) == vsrc) {
+                                        const uint64_t idx = (uint64_t)qlist[pos] * ld + e;
+                                        atomicSub(&mm32[idx >> 1], 1u << ((idx & 1) * 16));
+                                        natom++;
+                                    }
+                                }
+                            }
+                            if (!__any(have)) break;
+                        }
+                        if (lane < qn) {
+                            if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom++; }
+                            wq[lane].x = st;
+                        }
+                    } else
                     if (lane < qn) {
                         const uint2 qe = wq[lane];
                         uint32_t st = qe.y >> 9, flp = 0;                                   // the node's accumulator: tag | run << 12, run <= 255
@@ -347,61 +441,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                     vn[u] = (e < n && (!wrap || s + 1 < s1)) ? src[e] : (T)0;
                 }
                 uint32_t hh = 0, uu = 0; T vv = 0; bool have = false;
-                if constexpr (DEDUP) {
-                    // the same state machine, but the wavefront stays together until its last lane is done, so that all 64 lanes can expand
-                    // a chance match on a shared entry
-                    uint32_t mitem = 0;                              // (node index + 1) << 16 | cluster of this lane's pending expansion
-                    for (;;) {
-                        if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
-                        if (!__any(have)) break;
-                        if (have) {
-                            const unsigned long long en = ent[hh];
-                            const uint32_t t = (uint32_t)(en >> 32);
-                            if (t == 0u) have = false;
-                            else {
-                                if ((uint32_t)en == (uint32_t)vv) {
-                                    if (!(t & JTAG_MORE)) have = false;                          // the last entry with this key
-                                    const uint32_t ni = it * JU + uu;
-                                    const uint64_t el = e0 + (uint64_t)ni * JT;                  // node within this column range
-                                    bool count_it = true;
-                                    if ((t >> 12) & 0x7FFFFu) {                                  // entry of a cluster
-                                        const uint32_t cl = (t >> JTAG_CL_SHIFT) & JCL_MAX;
-                                        const uint32_t nl = ((uu & 2u ? lab4.y : lab4.x) >> ((uu & 1u) * 16)) & 0xFFFFu;      // this node's cluster
-                                        if (nl == cl) count_it = false;                          // own cluster: the block compare writes this pair's counter
-                                        else if (t & JTAG_MULTI) { mitem = ((ni + 1) << 16) | cl; count_it = false; }
-                                    }
-                                    if (count_it) {
-                                        uint32_t st = GS_SEL4((sticky + it * JU), uu);
-                                        GS_JOIN_HIT(st, t & JTAG_MASK, col0 + el);
-#pragma unroll
-                                        for (int u = 0; u < JU; u++) if (uu == (uint32_t)u) sticky[it * JU + u] = st;
-                                    }
-                                }
-                                hh = (hh + 1) & mask;
-                            }
-                        }
-                        unsigned long long pm = __ballot(mitem != 0u);
-                        while (pm) {
-                            const int src = __ffsll((long long)pm) - 1;
-                            pm &= pm - 1;
-                            nexp++;
-                            const uint32_t mi = __builtin_amdgcn_readlane(mitem, src);
-                            const uint32_t vsrc = __builtin_amdgcn_readlane((uint32_t)vv, src);
-                            const uint32_t cl = mi & 0xFFFFu, lane = threadIdx.x & 63;
-                            const uint64_t e = col0 + (e0 - lane + (uint32_t)src) + (uint64_t)((mi >> 16) - 1) * JT;
-                            const uint32_t lo = cl_lo[cl], hi = cl_lo[cl + 1];
-                            for (uint32_t pos = lo + lane; pos < hi; pos += 64) {
-                                const T k2 = qs[(uint64_t)s * nh + pos];
-                                if (!never_equal<KIND, T>(k2) && (uint32_t)canon<KIND, T>(k2) == vsrc) {
-                                    const uint64_t idx = (uint64_t)qlist[pos] * ld + e;
-                                    atomicSub(&mm32[idx >> 1], 1u << ((idx & 1) * 16));
-                                    natom++;
-                                }
-                            }
-                        }
-                        mitem = 0;
-                    }
-                } else {
+                {
                 for (;;) {
                     if (!have && pend) { uu = (uint32_t)__ffs((int)pend) - 1; pend &= pend - 1; vv = GS_SEL4(v, uu); hh = GS_SEL4(hs, uu) >> sh; have = true; }
                     if (!have) break;
@@ -620,7 +660,7 @@ static int join_launch(gs_ctx *c, const JoinGeom &g, const T *qkey, uint32_t nq,
         if (4 * g.lds1 <= 80 * 1024 && slots_per_wg >= 8) sr = 4; else if (2 * g.lds1 <= 80 * 1024 && slots_per_wg >= 4) sr = 2;
         if (getenv("GS_JOIN_SLOTS_PER_ROUND")) { const int e = atoi(getenv("GS_JOIN_SLOTS_PER_ROUND")); if (e == 1 || (e == 2 && 2 * g.lds1 <= 80 * 1024) || (e == 4 && 4 * g.lds1 <= 80 * 1024)) sr = e; }
     }
-    const size_t lds = g.lds1 * sr + (sr == 1 && !CL ? g.ldsq : 0);
+    const size_t lds = g.lds1 * sr + (sr == 1 ? g.ldsq : 0);
     ProfScope ps(c, FAM_HAMMING);
 #define GS_JOIN_GO(KERN)                                                                                                                              \
     do {                                                                                                                                              \
