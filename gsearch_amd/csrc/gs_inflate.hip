@@ -338,6 +338,195 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
     if (status == INF_OK && used > st.in_len) status = INF_E_INPUT;
     if (lane == 0) { InflateResult r; r.status = status; r.blocks = blocks; r.in_used = used; r.out_len = pos; res[blockIdx.x] = r; }
 }
+
+// ---- the window-less form with several matches in flight (round 4) ---------------------------------------------------------------------
+// What bounded k_inflate<true>: a member's 32 KB of history lives in the text it has written, 20 members per CU keep ~20 MB of history per
+// XCD alive against 4 MB of L2, so the source bytes of a match come back from the Infinity Cache / HBM (~1.5-2 us) - and the wave waited
+// for every one of them before it stored the copy and went on (gzip -6 of DNA is one match per ~5 bytes: ~4 900 cycles per symbol and wave,
+// 5 waves per SIMD). Decoding does not depend on the copied bytes, only later copies may: here the wave keeps decoding while up to P
+// matches have their source loads in flight and stores the P copies after ONE wait. A match whose source reaches into text that is not known
+// to have arrived in L2 (`synced`: the start of the oldest copy whose loads had not been waited for at the last wait - this batch's and the
+// previous batch's destinations lie above it) drains everything first; so do matches longer than one load per lane (64 bytes).
+template <int KIND>
+__device__ __forceinline__ uint32_t inf_walk_inl(uint64_t buf)
+{
+    const uint16_t *cnt = KIND == 0 ? g_inf.lcnt : g_inf.dcnt;
+    const uint16_t *sorted = KIND == 0 ? g_inf.lsorted : g_inf.dsorted;
+    uint32_t code = 0, first = 0, index = 0, r = 0;
+#pragma unroll 1
+    for (uint32_t l = 1; l <= 15; l++) {
+        code |= (uint32_t)(buf >> (l - 1)) & 1u;
+        const uint32_t c = cnt[l];
+        if (code < first + c) { r = inf_entry<KIND>(sorted[index + (code - first)], l); break; }
+        index += c; first = (first + c) << 1; code <<= 1;
+    }
+    return r;
+}
+// The root tables of a block in REGISTERS: entry i lives in lane i & 63 of register i >> 6 (16 registers for the 10-bit literal/length table, 4
+// for the 8-bit distance table). A look-up is an indexed register read with a wave-uniform index plus v_readlane - a few cycles - where the LDS
+// read + wait + v_readfirstlane of the other forms is ~140: at 1.5 members per SIMD (a group of 6 x CUs members) the decode is one wave's
+// dependent chain, and the two look-ups of a match were a third of it.
+typedef uint32_t inf_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t inf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t inf_lut16(const inf_u32x16 &t, uint32_t idx) { const uint32_t v = t[idx >> 6]; return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u)); }
+__device__ __forceinline__ uint32_t inf_lut4(const inf_u32x4 &t, uint32_t idx) { const uint32_t v = t[idx >> 6]; return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u)); }
+template <int P>
+__global__ __launch_bounds__(64) void k_inflate_pipe(const uint32_t *__restrict__ comp, const InflateStream *__restrict__ sts, uint32_t n, uint8_t *__restrict__ out_all,
+                                                     InflateResult *__restrict__ res)
+{
+    const uint32_t lane = threadIdx.x;
+    const InflateStream st = sts[blockIdx.x];
+    uint8_t *out = out_all + st.out_off;
+    const uint32_t cap = (uint32_t)st.out_cap;
+    const uint64_t in_end = st.in_off + st.in_len;
+    const uint32_t nwords = (uint32_t)((in_end + 3) >> 2);
+    InfBits B;
+    B.wi = (uint32_t)(st.in_off >> 2);
+    { const uint32_t b0 = B.wi & ~63u; B.cur = b0 + lane < nwords ? comp[b0 + lane] : 0; B.nxt = b0 + 64 + lane < nwords ? comp[b0 + 64 + lane] : 0; }
+    B.buf = 0; B.cnt = 0;
+    INF_REFILL(B);
+    INF_TAKE(B, (uint32_t)(st.in_off & 3) * 8);
+    uint32_t pos = 0, status = INF_OK, blocks = 0;
+    uint32_t synced = 0;                  // every byte of the text below this position has reached L2
+    // the history is read through a buffer resource (raw byte loads with the sc1 bit; the compiler counts them in vmcnt, so the wait sits where a
+    // loaded byte is first used - an agent-scope atomic byte load is widened and masked right behind the load, which waits for it there)
+    const __amdgpu_buffer_rsrc_t hist = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)cap, 0x00020000);
+    for (bool last = false; !last && status == INF_OK;) {
+        INF_REFILL(B);
+        last = B.buf & 1;
+        const uint32_t btype = (uint32_t)(B.buf >> 1) & 3;
+        INF_TAKE(B, 3);
+        blocks++;
+        if (btype == 3) { status = INF_E_BTYPE; break; }
+        if (btype == 0) {                                     // stored
+            INF_TAKE(B, B.cnt & 7);
+            INF_REFILL(B);
+            const uint32_t len = (uint32_t)B.buf & 0xFFFFu, nlen = (uint32_t)(B.buf >> 16) & 0xFFFFu;
+            INF_TAKE(B, 32);
+            if ((len ^ 0xFFFFu) != nlen) { status = INF_E_STORED; break; }
+            if (len > cap - pos) { status = INF_E_OUTPUT; break; }
+            for (uint32_t i = 0; i < len; i++) {
+                INF_REFILL(B);
+                if (lane == 0) out[pos] = (uint8_t)B.buf;
+                INF_TAKE(B, 8);
+                pos++;
+            }
+            continue;
+        }
+        if (btype == 1) {                                     // fixed codes (RFC 1951 3.2.6)
+            for (uint32_t i = lane; i < 288; i += 64) g_inf.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            if (lane < 32) g_inf.lens[288 + lane] = 5;
+            __syncthreads();
+            (void)inf_build<0>(0, 288);
+            (void)inf_build<1>(288, 32);
+        } else {
+            uint32_t hst;
+            B = inf_dynamic_header(B, comp, nwords, &hst);
+            hst = inf_uni(hst);                                // (it comes back through memory: without this the compiler takes `status`, and every
+            if (hst != INF_OK) { status = hst; break; }       //  variable assigned under a test of it, for lane-dependent)
+        }
+        B.buf = inf_uni64(B.buf); B.cnt = inf_uni(B.cnt); B.wi = inf_uni(B.wi);
+        INF_REFILL(B);
+        inf_u32x16 LT; inf_u32x4 DT;
+#pragma unroll
+        for (int r = 0; r < 16; r++) LT[r] = g_inf.llut[r * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++) DT[r] = g_inf.dlut[r * 64 + lane];
+        uint32_t e = inf_lut16(LT, (uint32_t)B.buf & ((1u << INF_LROOT) - 1));
+        bool eob = false;
+        uint32_t pv[P], pd[P], pl[P], nl = 0;                 // the batch whose source loads are in flight: loaded byte (per lane), destination, length
+#pragma unroll
+        for (int j = 0; j < P; j++) { pv[j] = 0; pd[j] = 0; pl[j] = 0; }
+        while (!eob && status == INF_OK) {
+            uint32_t qa[P], qd[P], ql[P];                     // the batch being decoded: source offset (per lane), destination, length
+            uint32_t nq = 0, slow_len = 0, slow_dist = 0;
+            // (unrolled over the slots of the batch: a slot's registers are named at compile time. A plain loop that described the matches in the
+            // lanes of a few registers and built addresses / issued loads from v_readlane afterwards was a third of the code and 25 % SLOWER: a
+            // member's decode is one wave's dependent instruction chain, and every instruction added to it shows)
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                qa[j] = 0; qd[j] = 0; ql[j] = 0;
+                if (eob || status != INF_OK || slow_len) continue;
+                uint32_t kind = 0;
+                for (;;) {                                    // literals, until something else turns up
+                    e = inf_uni(e); B.buf = inf_uni64(B.buf); B.cnt = inf_uni(B.cnt); B.wi = inf_uni(B.wi); pos = inf_uni(pos);
+                    if (e == INF_LONG) e = inf_uni(inf_walk_inl<0>(B.buf));
+                    const uint32_t nb = e & 15;
+                    if (!nb) { status = INF_E_CODE; break; }
+                    if (B.wi > nwords + 2) { status = INF_E_INPUT; break; }      // past the end of the member: the zeros fed from there on may decode for ever
+                    INF_TAKE(B, nb);
+                    kind = (e >> 4) & 3;
+                    if (kind) break;
+                    if (pos >= cap) { status = INF_E_OUTPUT; break; }
+                    if (lane == 0) out[pos] = (uint8_t)(e >> 8);
+                    pos++;
+                    INF_REFILL(B);
+                    e = inf_lut16(LT, inf_uni((uint32_t)B.buf) & ((1u << INF_LROOT) - 1));
+                }
+                if (status != INF_OK) continue;
+                if (kind == 2) { eob = true; continue; }
+                uint32_t eb = (e >> 24) & 15;
+                const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)B.buf & ((1u << eb) - 1));
+                INF_TAKE(B, eb);
+                INF_REFILL(B);
+                uint32_t d = inf_lut4(DT, inf_uni((uint32_t)B.buf) & ((1u << INF_DROOT) - 1));
+                if (d == INF_LONG) d = inf_uni(inf_walk_inl<1>(B.buf));
+                const uint32_t nbd = d & 15;
+                if (!nbd) { status = INF_E_CODE; continue; }
+                INF_TAKE(B, nbd);
+                eb = (d >> 24) & 15;
+                const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)B.buf & ((1u << eb) - 1));
+                INF_TAKE(B, eb);
+                if (dist > pos) { status = INF_E_DIST; continue; }
+                if (len > cap - pos) { status = INF_E_OUTPUT; continue; }
+                INF_REFILL(B);
+                e = inf_lut16(LT, inf_uni((uint32_t)B.buf) & ((1u << INF_LROOT) - 1));
+                const uint32_t src0 = pos - dist;
+                if (len <= 64 && src0 + (dist >= len ? len : dist) <= inf_uni(synced)) {
+                    uint32_t idx = lane;
+                    if (dist < len) idx = lane % dist;        // the source runs into the target: the last `dist` bytes repeat
+                    qa[j] = src0 + idx; qd[j] = pos; ql[j] = len; nq = (uint32_t)j + 1;
+                    pos += len;
+                } else { slow_len = len; slow_dist = dist; }
+            }
+            // the copies of the batch decoded one round ago: their loads have had this round's decoding to come back (one wait, said once in front
+            // of all the stores: the compiler would put its own vmcnt(0) in front of every one, behind the store before it; it also covers every
+            // store issued before it) ...
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+            for (int j = 0; j < P; j++) if ((uint32_t)j < nl && lane < pl[j]) out[pd[j] + lane] = (uint8_t)pv[j];
+            // ... and the loads of this round's batch go out together. When they do, everything stored before the wait above has reached L2: all
+            // text except the destinations of the batch just stored and of this one - so the NEXT round's sources have to lie below this batch
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                if ((uint32_t)j < nq && lane < ql[j]) pv[j] = __builtin_amdgcn_raw_buffer_load_b8(hist, qa[j], 0, 16);      // (sc1: from L2, not from this CU's L1)
+                pd[j] = qd[j]; pl[j] = ql[j];
+            }
+            nl = nq;
+            synced = nq ? qd[0] : pos;
+            if (slow_len || eob || status != INF_OK) {       // drain: a block ends, or a match wants text that is still on its way
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                for (int j = 0; j < P; j++) if ((uint32_t)j < nl && lane < pl[j]) out[pd[j] + lane] = (uint8_t)pv[j];
+                nl = 0;
+                if (slow_len) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): everything stored so far is in L2
+                    const uint32_t src0 = pos - slow_dist;
+                    for (uint32_t i = lane; i < slow_len; i += 64) {
+                        const uint8_t b = __hip_atomic_load(out + src0 + (slow_dist >= slow_len ? i : i % slow_dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        out[pos + i] = b;
+                    }
+                    pos += slow_len;
+                }
+                synced = pos;
+            }
+        }
+    }
+    INF_TAKE(B, B.cnt & 7);
+    const uint64_t used = (uint64_t)B.wi * 4 - B.cnt / 8 - st.in_off;
+    if (status == INF_OK && used > st.in_len) status = INF_E_INPUT;
+    if (lane == 0) { InflateResult r; r.status = status; r.blocks = blocks; r.in_used = used; r.out_len = pos; res[blockIdx.x] = r; }
+}
 #undef INF_REFILL
 #undef INF_TAKE
 
@@ -406,6 +595,22 @@ static bool inflate_needs_byte_stores(const InflateStream *st, uint32_t n)
     for (uint32_t i = 0; i < n; i++) if (st[i].out_off & 15) return true;
     return false;
 }
+// GS_INFLATE_WINDOW = lds | global | pipe picks the form (measurement aid / tests); by default up to four members per CU take the LDS-window form
+// (lowest latency per symbol), more take the window-less form with several matches in flight, whose members interleave five times as densely
+constexpr int INF_PIPE = 8;
+static void inflate_launch_form(gs_ctx *c, hipStream_t stream, const uint32_t *comp, const InflateStream *streams_host, const InflateStream *ds, uint32_t n, uint8_t *out,
+                                InflateResult *dr)
+{
+    const char *w = getenv("GS_INFLATE_WINDOW");
+    int form = n > 4u * (uint32_t)c->n_cu ? 2 : 0;                      // 0 = LDS window, 1 = window-less (one match at a time), 2 = window-less, pipelined
+    if (w && !strcmp(w, "lds")) form = 0;
+    else if (w && !strcmp(w, "global")) form = 1;
+    else if (w && !strcmp(w, "pipe")) form = 2;
+    if (form == 0 && inflate_needs_byte_stores(streams_host, n)) form = 2;
+    if (form == 2) hipLaunchKernelGGL(k_inflate_pipe<INF_PIPE>, dim3(n), dim3(64), 0, stream, comp, ds, n, out, dr);
+    else if (form == 1) hipLaunchKernelGGL(k_inflate<true>, dim3(n), dim3(64), 0, stream, comp, ds, n, out, dr);
+    else hipLaunchKernelGGL(k_inflate<false>, dim3(n), dim3(64), 0, stream, comp, ds, n, out, dr);
+}
 int inflate_streams_dev(gs_ctx *c, const void *comp_dev, const InflateStream *streams, uint32_t n, void *out_dev, InflateResult *results)
 {
     if (n == 0) return GS_OK;
@@ -413,11 +618,7 @@ int inflate_streams_dev(gs_ctx *c, const void *comp_dev, const InflateStream *st
     int rc;
     if ((rc = ds.alloc(sizeof(InflateStream) * n)) || (rc = dr.alloc(sizeof(InflateResult) * n))) return rc;
     GS_HIP_CHECK(hipMemcpyAsync(ds.p, streams, sizeof(InflateStream) * n, hipMemcpyHostToDevice, c->stream));
-    // up to four members per CU: the LDS-window form (lowest latency); more: the window-less form, whose members interleave five times as densely
-    const char *w = getenv("GS_INFLATE_WINDOW");
-    const bool gwin = inflate_needs_byte_stores(streams, n) || (w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu);
-    if (gwin) hipLaunchKernelGGL(k_inflate<true>, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)comp_dev, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
-    else hipLaunchKernelGGL(k_inflate<false>, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)comp_dev, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
+    inflate_launch_form(c, c->stream, (const uint32_t *)comp_dev, streams, ds.as<InflateStream>(), n, (uint8_t *)out_dev, dr.as<InflateResult>());
     GS_HIP_CHECK(hipGetLastError());
     GS_HIP_CHECK(hipMemcpyAsync(results, dr.p, sizeof(InflateResult) * n, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(gs::stream_wait(c));
@@ -431,10 +632,7 @@ int inflate_streams_launch(gs_ctx *c, hipStream_t stream, const void *comp_dev, 
 {
     if (n == 0) return GS_OK;
     GS_HIP_CHECK(hipMemcpyAsync(ds_dev, streams_pinned, sizeof(InflateStream) * n, hipMemcpyHostToDevice, stream));
-    const char *w = getenv("GS_INFLATE_WINDOW");
-    const bool gwin = inflate_needs_byte_stores(streams_pinned, n) || (w ? !strcmp(w, "global") : n > 4u * (uint32_t)c->n_cu);
-    if (gwin) hipLaunchKernelGGL(k_inflate<true>, dim3(n), dim3(64), 0, stream, (const uint32_t *)comp_dev, (const InflateStream *)ds_dev, n, (uint8_t *)out_dev, (InflateResult *)dr_dev);
-    else hipLaunchKernelGGL(k_inflate<false>, dim3(n), dim3(64), 0, stream, (const uint32_t *)comp_dev, (const InflateStream *)ds_dev, n, (uint8_t *)out_dev, (InflateResult *)dr_dev);
+    inflate_launch_form(c, stream, (const uint32_t *)comp_dev, streams_pinned, (const InflateStream *)ds_dev, n, (uint8_t *)out_dev, (InflateResult *)dr_dev);
     GS_HIP_CHECK(hipGetLastError());
     GS_HIP_CHECK(hipMemcpyAsync(results_pinned, dr_dev, sizeof(InflateResult) * n, hipMemcpyDeviceToHost, stream));
     return GS_OK;

@@ -51,9 +51,10 @@ def _cases():
     return cases
 
 
-@pytest.mark.parametrize("window", ["lds", "global"])
+@pytest.mark.parametrize("window", ["lds", "global", "pipe"])
 def test_inflate_matches_zlib(gpu_ctx, monkeypatch, window):
-    """both forms of k_inflate: history window in LDS (up to four members per CU) / no window, history read back from the text in HBM"""
+    """the forms of k_inflate: history window in LDS (up to four members per CU) / no window, history read back from the text in HBM, one match
+    at a time (global) or several in flight (pipe)"""
     import gsearch_amd as G
     monkeypatch.setenv("GS_INFLATE_WINDOW", window)
     cases = _cases()
@@ -65,7 +66,7 @@ def test_inflate_matches_zlib(gpu_ctx, monkeypatch, window):
         assert text == want, k
 
 
-@pytest.mark.parametrize("window", ["lds", "global", ""])
+@pytest.mark.parametrize("window", ["lds", "global", "pipe", ""])
 def test_inflate_large_members_and_many_streams(gpu_ctx, monkeypatch, window):
     """more streams than the device holds at once (4 per CU), each several window wraps long; "" = the launcher's own choice"""
     import gsearch_amd as G
@@ -85,7 +86,7 @@ def test_inflate_large_members_and_many_streams(gpu_ctx, monkeypatch, window):
         assert text == wants[j % len(wants)], j
 
 
-@pytest.mark.parametrize("window", ["lds", "global"])
+@pytest.mark.parametrize("window", ["lds", "global", "pipe"])
 def test_inflate_reports_damage(gpu_ctx, monkeypatch, window):
     import gsearch_amd as G
     monkeypatch.setenv("GS_INFLATE_WINDOW", window)
