@@ -363,13 +363,11 @@ __device__ __forceinline__ uint32_t inf_walk_inl(uint64_t buf)
     return r;
 }
 // The root tables of a block in REGISTERS: entry i lives in lane i & 63 of register i >> 6 (16 registers for the 10-bit literal/length table, 4
-// for the 8-bit distance table). A look-up is an indexed register read with a wave-uniform index plus v_readlane - a few cycles - where the LDS
+// of 16 for the 8-bit distance table). A look-up is an indexed register read with a wave-uniform index plus v_readlane - a few cycles - where the LDS
 // read + wait + v_readfirstlane of the other forms is ~140: at 1.5 members per SIMD (a group of 6 x CUs members) the decode is one wave's
 // dependent chain, and the two look-ups of a match were a third of it.
 typedef uint32_t inf_u32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t inf_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t inf_lut16(const inf_u32x16 &t, uint32_t idx) { const uint32_t v = t[idx >> 6]; return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u)); }
-__device__ __forceinline__ uint32_t inf_lut4(const inf_u32x4 &t, uint32_t idx) { const uint32_t v = t[idx >> 6]; return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u)); }
 template <int P>
 __global__ __launch_bounds__(64) void k_inflate_pipe(const uint32_t *__restrict__ comp, const InflateStream *__restrict__ sts, uint32_t n, uint8_t *__restrict__ out_all,
                                                      InflateResult *__restrict__ res)
@@ -427,11 +425,11 @@ __global__ __launch_bounds__(64) void k_inflate_pipe(const uint32_t *__restrict_
         }
         B.buf = inf_uni64(B.buf); B.cnt = inf_uni(B.cnt); B.wi = inf_uni(B.wi);
         INF_REFILL(B);
-        inf_u32x16 LT; inf_u32x4 DT;
+        inf_u32x16 LT, DT;                                   // (DT: four registers used; a 16-vector so that the look-up is an indexed read, not a select chain)
 #pragma unroll
         for (int r = 0; r < 16; r++) LT[r] = g_inf.llut[r * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; r++) DT[r] = g_inf.dlut[r * 64 + lane];
+        for (int r = 0; r < 16; r++) DT[r] = r < 4 ? g_inf.dlut[(r & 3) * 64 + lane] : 0u;
         uint32_t e = inf_lut16(LT, (uint32_t)B.buf & ((1u << INF_LROOT) - 1));
         bool eob = false;
         uint32_t pv[P], pd[P], pl[P], nl = 0;                 // the batch whose source loads are in flight: loaded byte (per lane), destination, length
@@ -444,16 +442,21 @@ __global__ __launch_bounds__(64) void k_inflate_pipe(const uint32_t *__restrict_
             // lanes of a few registers and built addresses / issued loads from v_readlane afterwards was a third of the code and 25 % SLOWER: a
             // member's decode is one wave's dependent instruction chain, and every instruction added to it shows)
 #pragma unroll
-            for (int j = 0; j < P; j++) {
-                qa[j] = 0; qd[j] = 0; ql[j] = 0;
-                if (eob || status != INF_OK || slow_len) continue;
+            for (int j = 0; j < P; j++) { qa[j] = 0; qd[j] = 0; ql[j] = 0; }
+#pragma unroll
+            for (int j = 0; j < P; j++) {                     // (every event - end of block, error, a match for the slow path - leaves the batch)
                 uint32_t kind = 0;
+                // (no end-of-input test per symbol as in k_inflate: past the member's end the reader feeds zeros, and every symbol either advances `pos`,
+                // which `cap` bounds, or ends the block - and a block header of zeros is a stored block whose LEN / NLEN do not check. The overrun is
+                // reported from the bytes used, behind the loop.)
                 for (;;) {                                    // literals, until something else turns up
                     e = inf_uni(e); B.buf = inf_uni64(B.buf); B.cnt = inf_uni(B.cnt); B.wi = inf_uni(B.wi); pos = inf_uni(pos);
-                    if (e == INF_LONG) e = inf_uni(inf_walk_inl<0>(B.buf));
-                    const uint32_t nb = e & 15;
-                    if (!nb) { status = INF_E_CODE; break; }
-                    if (B.wi > nwords + 2) { status = INF_E_INPUT; break; }      // past the end of the member: the zeros fed from there on may decode for ever
+                    uint32_t nb = e & 15;
+                    if (!nb) {                                // rare: a code longer than the root (INF_LONG has no length), or no such code
+                        if (e == INF_LONG) e = inf_uni(inf_walk_inl<0>(B.buf));
+                        nb = e & 15;
+                        if (!nb) { status = INF_E_CODE; break; }
+                    }
                     INF_TAKE(B, nb);
                     kind = (e >> 4) & 3;
                     if (kind) break;
@@ -463,22 +466,25 @@ __global__ __launch_bounds__(64) void k_inflate_pipe(const uint32_t *__restrict_
                     INF_REFILL(B);
                     e = inf_lut16(LT, inf_uni((uint32_t)B.buf) & ((1u << INF_LROOT) - 1));
                 }
-                if (status != INF_OK) continue;
-                if (kind == 2) { eob = true; continue; }
+                if (status != INF_OK) break;
+                if (kind == 2) { eob = true; break; }
                 uint32_t eb = (e >> 24) & 15;
                 const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)B.buf & ((1u << eb) - 1));
                 INF_TAKE(B, eb);
                 INF_REFILL(B);
-                uint32_t d = inf_lut4(DT, inf_uni((uint32_t)B.buf) & ((1u << INF_DROOT) - 1));
-                if (d == INF_LONG) d = inf_uni(inf_walk_inl<1>(B.buf));
-                const uint32_t nbd = d & 15;
-                if (!nbd) { status = INF_E_CODE; continue; }
+                uint32_t d = inf_lut16(DT, inf_uni((uint32_t)B.buf) & ((1u << INF_DROOT) - 1));
+                uint32_t nbd = d & 15;
+                if (!nbd) {
+                    if (d == INF_LONG) d = inf_uni(inf_walk_inl<1>(B.buf));
+                    nbd = d & 15;
+                    if (!nbd) { status = INF_E_CODE; break; }
+                }
                 INF_TAKE(B, nbd);
                 eb = (d >> 24) & 15;
                 const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)B.buf & ((1u << eb) - 1));
                 INF_TAKE(B, eb);
-                if (dist > pos) { status = INF_E_DIST; continue; }
-                if (len > cap - pos) { status = INF_E_OUTPUT; continue; }
+                if (dist > pos) { status = INF_E_DIST; break; }
+                if (len > cap - pos) { status = INF_E_OUTPUT; break; }
                 INF_REFILL(B);
                 e = inf_lut16(LT, inf_uni((uint32_t)B.buf) & ((1u << INF_LROOT) - 1));
                 const uint32_t src0 = pos - dist;
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(64) void k_inflate_pipe(const uint32_t *__restrict_
                     if (dist < len) idx = lane % dist;        // the source runs into the target: the last `dist` bytes repeat
                     qa[j] = src0 + idx; qd[j] = pos; ql[j] = len; nq = (uint32_t)j + 1;
                     pos += len;
-                } else { slow_len = len; slow_dist = dist; }
+                } else { slow_len = len; slow_dist = dist; break; }
             }
             // the copies of the batch decoded one round ago: their loads have had this round's decoding to come back (one wait, said once in front
             // of all the stores: the compiler would put its own vmcnt(0) in front of every one, behind the store before it; it also covers every
