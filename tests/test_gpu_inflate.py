@@ -42,6 +42,11 @@ def _cases():
         "random_stored": _gz(bytes(rng.integers(0, 256, 150_000, dtype=np.uint8)), 6),     # incompressible -> stored blocks
         "level0_stored": _gz(dna[:70_000], 0),
         "window_edge": _gz(bytes(rng.integers(0, 256, 32_768, dtype=np.uint8)) * 3, 9),    # matches at distance 32768
+        # copies whose source lies in text that the pipelined form has not stored yet (destinations of the batch in flight / being decoded):
+        # two-symbol noise (short distances, every length), short periods, and mutated repeats a few dozen bytes back
+        "two_symbols": _gz(bytes(rng.integers(0, 2, 200_000, dtype=np.uint8) + 65), 6),
+        "period_7_and_13": _gz(bytes(rng.integers(65, 91, 7, dtype=np.uint8)) * 9000 + bytes(rng.integers(65, 91, 13, dtype=np.uint8)) * 5000, 9),
+        "near_repeats": _gz(b"".join(bytes(rng.integers(65, 69, 24, dtype=np.uint8)) * int(rng.integers(2, 5)) for _ in range(4000)), 6),
         "protein": _gz(b">p1\n" + bytes(rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8), 200_000)) + b"\n", 6),
     }
     bio = io.BytesIO()
