@@ -760,7 +760,10 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
         if (total) GS_HIP_CHECK(hipMemcpyAsync(dtext[b].p, pinned[sl], total, hipMemcpyHostToDevice, copy_stream));
         if (dev_ctot[g]) {
             if ((rc2 = dcomp[b].ensure(dev_ctot[g] + 64))) return rc2;
-            GS_HIP_CHECK(hipMemcpyAsync(dcomp[b].p, cpin[sl], dev_ctot[g], hipMemcpyHostToDevice, copy_stream));
+            // in pieces: one multi-GB copy command holds the copy engine while the OTHER pipeline's 300 MB text copies queue behind it
+            static const uint64_t piece = [] { const char *e = getenv("GS_COPY_CHUNK_MB"); return (uint64_t)std::max(1, e ? atoi(e) : 64) << 20; }();
+            for (uint64_t o = 0; o < dev_ctot[g]; o += piece)
+                GS_HIP_CHECK(hipMemcpyAsync((uint8_t *)dcomp[b].p + o, (const uint8_t *)cpin[sl] + o, std::min<uint64_t>(piece, dev_ctot[g] - o), hipMemcpyHostToDevice, copy_stream));
         }
         GS_HIP_CHECK(hipEventRecord(ev[b], copy_stream));
         return GS_OK;
