@@ -968,14 +968,22 @@ __global__ __launch_bounds__(PBK_T) void k_prob_partition(const uint8_t *__restr
     }
 }
 // per genome: bucket sizes / starts, per-part scatter bases (hist is rewritten in place), thr = max_b q[b]
+// Two-level form (g_shc != nullptr): the scatter goes through COARSE buckets first (the top lgc = lg / 2 bits of the bucket number, k_prob_partition<., 1> with
+// these shifts and bases) and k_prob_refine spreads every (coarse bucket, part) slice over its fine buckets. Here: ccur[part][c] = where part `part` writes its
+// values of coarse bucket c (coarse bucket c starts where its first fine bucket does; inside it the parts follow each other), ccnt = how many.
+constexpr uint32_t PB_CCMAX = 8192;                            // parts x coarse buckets of a genome that the scan kernel can total in LDS
 __global__ __launch_bounds__(1024) void k_prob_scan(uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff, uint32_t parts, uint32_t *__restrict__ hist,
                                                      uint32_t *__restrict__ bstart, uint32_t *__restrict__ bsize, uint32_t *__restrict__ bgen, const uint64_t *__restrict__ q, uint32_t m,
-                                                     uint64_t *__restrict__ thr)
+                                                     uint64_t *__restrict__ thr, const uint32_t *__restrict__ g_shc, const uint32_t *__restrict__ g_coff, uint32_t *__restrict__ ccur,
+                                                     uint32_t *__restrict__ ccnt)
 {
     __shared__ uint32_t s_w[16]; __shared__ unsigned long long s_mx;
+    __shared__ uint32_t s_cc[PB_CCMAX], s_cs[256];
     const uint32_t gl = blockIdx.x, sh = g_sh[gl], NB = 1u << (vbits - sh);
     const uint32_t b0 = g_boff[gl];
     uint32_t *hg = hist + (uint64_t)b0 * parts;
+    const uint32_t fsh = g_shc ? g_shc[gl] - sh : 0, NC = NB >> fsh;      // fine buckets per coarse one = 1 << fsh
+    if (g_shc) { for (uint32_t i = threadIdx.x; i < parts * NC; i += 1024) s_cc[i] = 0; }
     const uint32_t CH = (NB + 1023) / 1024;                    // consecutive buckets per lane
     uint32_t loc = 0;
     for (uint32_t c = 0; c < CH; c++) { const uint32_t b = threadIdx.x * CH + c; if (b < NB) for (uint32_t p = 0; p < parts; p++) loc += hg[(uint64_t)p * NB + b]; }
@@ -992,9 +1000,23 @@ __global__ __launch_bounds__(1024) void k_prob_scan(uint32_t vbits, const uint32
         const uint32_t b = threadIdx.x * CH + c;
         if (b >= NB) break;
         bstart[b0 + b] = run; bgen[b0 + b] = gl;
+        if (g_shc && (b & ((1u << fsh) - 1u)) == 0) s_cs[b >> fsh] = run;
         uint32_t tot = 0;
-        for (uint32_t p = 0; p < parts; p++) { const uint32_t x = hg[(uint64_t)p * NB + b]; hg[(uint64_t)p * NB + b] = run + tot; tot += x; }
+        for (uint32_t p = 0; p < parts; p++) {
+            const uint32_t x = hg[(uint64_t)p * NB + b]; hg[(uint64_t)p * NB + b] = run + tot; tot += x;
+            if (g_shc && x) atomicAdd(&s_cc[p * NC + (b >> fsh)], x);
+        }
         bsize[b0 + b] = tot; run += tot;
+    }
+    if (g_shc) {
+        __syncthreads();
+        const uint32_t c0 = g_coff[gl];
+        for (uint32_t i = threadIdx.x; i < parts * NC; i += 1024) {
+            const uint32_t p = i / NC, cb = i % NC;
+            uint32_t base = s_cs[cb];
+            for (uint32_t p2 = 0; p2 < p; p2++) base += s_cc[p2 * NC + cb];
+            ccur[(uint64_t)c0 * parts + i] = base; ccnt[(uint64_t)c0 * parts + i] = s_cc[i];
+        }
     }
     unsigned long long mx = 0;
     for (uint32_t i = threadIdx.x; i < m; i += 1024) { const unsigned long long x = q[(uint64_t)gl * m + i]; mx = x > mx ? x : mx; }
@@ -1003,6 +1025,79 @@ __global__ __launch_bounds__(1024) void k_prob_scan(uint32_t vbits, const uint32
     if (lane == 0) atomicMax(&s_mx, mx);
     __syncthreads();
     if (threadIdx.x == 0) thr[gl] = s_mx;
+}
+// second level of the partition: one workgroup per (coarse bucket, part) slice of a genome. The slice is read front to back (coalesced) and each value is
+// appended to its fine bucket through an LDS cursor that starts at that part's place in the bucket (the same per-(part, bucket) bases the one-level
+// scatter used). A workgroup writes to at most 128 open streams of a few hundred consecutive values each: the L2 completes their lines before they are
+// evicted, where the one-level scatter's 4096 streams per workgroup left it as 32-byte sector writes (WRITE_SIZE 3.9x the values, profiles/r03_prob_pmc.txt).
+constexpr int PBR_T = 512, PBR_V = 8, PBR_TILE = PBR_T * PBR_V;
+__global__ __launch_bounds__(PBR_T) void k_prob_refine(const uint64_t *__restrict__ tmp, uint64_t *__restrict__ vals, const uint64_t *__restrict__ g_vbase, uint32_t vbits,
+                                                       const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff, const uint32_t *__restrict__ g_shc,
+                                                       const uint32_t *__restrict__ g_coff, uint32_t parts, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ ccur,
+                                                       const uint32_t *__restrict__ ccnt, uint32_t store32)
+{
+    // store32: every genome's in-bucket id fits 4 bytes - the id (low sh bits of the hashed value) is what k_prob_buckets keeps in its table, so that is
+    // what is written, element i of the chunk at ((uint32_t *)vals)[i]
+    // a tile of 4096 values is counting-sorted by fine bucket in LDS and written out run by run: consecutive lanes store consecutive values of one
+    // bucket (8-byte stores scattered over 64 streams were bound by the number of write requests, not by bytes: 8.7 ms per 1.3e9 values)
+    __shared__ uint64_t s_val[PBR_TILE];
+    __shared__ uint8_t s_bk[PBR_TILE];
+    __shared__ uint32_t s_cur[256], s_cnt[256], s_start[256];
+    const uint32_t gl = blockIdx.y, sh = g_sh[gl], shc = g_shc[gl], fsh = shc - sh, NB = 1u << (vbits - sh), NC = NB >> fsh, NF = 1u << fsh;
+    const uint32_t cb = blockIdx.x / parts, part = blockIdx.x % parts;
+    if (cb >= NC) return;
+    const uint32_t *hg = hist + (uint64_t)g_boff[gl] * parts + (uint64_t)part * NB + (uint64_t)cb * NF;
+    for (uint32_t f = threadIdx.x; f < NF; f += PBR_T) s_cur[f] = hg[f];
+    const uint64_t ci = (uint64_t)g_coff[gl] * parts + (uint64_t)part * NC + cb;
+    const uint32_t n = ccnt[ci];
+    const uint64_t *src = tmp + g_vbase[gl] + ccur[ci];
+    uint64_t *dst = vals + g_vbase[gl];
+    uint32_t *dst32 = (uint32_t *)vals + g_vbase[gl];
+    const uint64_t vmask = vbits >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << vbits) - 1);
+    const uint64_t idmask = sh >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << sh) - 1);
+    for (uint32_t i0 = 0; i0 < n; i0 += PBR_TILE) {
+        const uint32_t tn = n - i0 < (uint32_t)PBR_TILE ? n - i0 : (uint32_t)PBR_TILE;
+        uint64_t v[PBR_V]; uint32_t f[PBR_V], rk[PBR_V];
+#pragma unroll
+        for (int u = 0; u < PBR_V; u++) { const uint32_t i = u * PBR_T + threadIdx.x; v[u] = i < tn ? src[i0 + i] : 0; }
+        if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PBR_V; u++) {
+            const uint32_t i = u * PBR_T + threadIdx.x;
+            f[u] = pb_bucket(v[u], vmask, sh) & (NF - 1u);
+            rk[u] = i < tn ? atomicAdd(&s_cnt[f[u]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                                   // exclusive prefix of the <= 256 bucket counts: four per lane of one wavefront
+            uint32_t c4[4], loc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { c4[j] = s_cnt[threadIdx.x * 4 + j]; loc += c4[j]; }
+            uint32_t inc = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += y; }
+            uint32_t run = inc - loc;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { s_start[threadIdx.x * 4 + j] = run; run += c4[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PBR_V; u++) {
+            const uint32_t i = u * PBR_T + threadIdx.x;
+            if (i < tn) { const uint32_t pos = s_start[f[u]] + rk[u]; s_val[pos] = v[u]; s_bk[pos] = (uint8_t)f[u]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PBR_V; u++) {
+            const uint32_t i = u * PBR_T + threadIdx.x;
+            if (i < tn) {
+                const uint32_t fb = s_bk[i]; const uint32_t at = s_cur[fb] + (i - s_start[fb]);
+                if (store32) dst32[at] = (uint32_t)(pb_hash(s_val[i], vmask) & idmask); else dst[at] = s_val[i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) s_cur[threadIdx.x] += s_cnt[threadIdx.x];
+    }
 }
 struct PbLists {
     uint64_t *cand_v, *cand_h, *cand_gb; uint32_t cand_cap, ovf_cap; uint32_t *n_cand, *seg_n;      // [0, cand_cap): per-workgroup segments; [cand_cap, + ovf_cap): shared overflow
@@ -1016,8 +1111,10 @@ __global__ __launch_bounds__(PB2_T, 6) void k_prob_buckets(const uint64_t *__res
                                                            const uint32_t *__restrict__ bsize, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff,
                                                            uint32_t ng, uint32_t lg_max, uint32_t m, uint64_t zone,
                                                            ProbConst pc, uint64_t *__restrict__ q, uint64_t *__restrict__ thr, uint32_t *__restrict__ wmax, PbLists L,
-                                                           uint32_t *__restrict__ ovf)
+                                                           uint32_t *__restrict__ ovf, uint32_t stored32)
 {
+    // stored32 (KT = uint32_t only): the partition left the 4-byte in-bucket ids in `vals` (element i of the chunk at ((uint32_t *)vals)[i]) instead of
+    // the 8-byte values - half the bytes written by the refinement and read here; the value comes back through the inverse multiplication
     // LDS per workgroup (4-byte ids): 16 kB table + 8 kB duplicate counts + 6 kB queue + 5 kB candidates = 35 kB. What the kernel spends
     // its time on (GS_PROB_PROFILE, cycles per bucket of 1220 keys on 512 lanes, before / after this form): LDS atomics of the insert
     // 6360 / see DESIGN (one 32-bit CAS per k-mer instead of a 64-bit CAS plus an add: the LDS pipeline is shared by the whole CU, so
@@ -1061,11 +1158,13 @@ __global__ __launch_bounds__(PB2_T, 6) void k_prob_buckets(const uint64_t *__res
     for (; item < n_items; item += gridDim.x) {
         const uint32_t gl = n_gl, n = n_n, jpos = n_pos, sh = n_sh, bk = n_bk;
         const uint64_t *keys = vals + n_vb + n_st;
+        const uint32_t *keys32 = (const uint32_t *)vals + n_vb + n_st;
+        const bool st32 = sizeof(KT) == 4 && stored32;
         uint64_t *qg = q + (uint64_t)gl * m;
         uint64_t thr_b = n_thr;
         uint64_t kreg[KPL];
 #pragma unroll
-        for (int u = 0; u < KPL; u++) { const uint32_t i = u * PB2_T + threadIdx.x; kreg[u] = i < n ? keys[i] : EMPTY64; }
+        for (int u = 0; u < KPL; u++) { const uint32_t i = u * PB2_T + threadIdx.x; kreg[u] = i < n ? (st32 ? (uint64_t)keys32[i] : keys[i]) : EMPTY64; }      // st32: the id, for now
         describe(item + gridDim.x, n_gl, n_n, n_st, n_vb, n_pos, n_sh, n_bk, n_thr);
         if (n == 0) continue;                                      // (workgroup-uniform) nothing of this genome at this position
         const bool pf = L.prof && blockIdx.x == 0 && threadIdx.x == 0;
@@ -1105,9 +1204,7 @@ __global__ __launch_bounds__(PB2_T, 6) void k_prob_buckets(const uint64_t *__res
         bool over = false;
         uint32_t own[KPL]; double x0r[KPL];
         const uint64_t idmask = sizeof(KT) == 4 ? (((uint64_t)1 << sh) - 1) : ~(uint64_t)0;
-        auto insert = [&](uint64_t v) -> uint32_t {
-            const KT id = sizeof(KT) == 4 ? (KT)(pb_hash(v, vmask) & idmask) : (KT)v;
-            uint32_t s = (uint32_t)((v * 0xD6E8FEB86659FD93ULL) >> 40) & (PB_TAB - 1);
+        auto insert_at = [&](KT id, uint32_t s) -> uint32_t {
             for (uint32_t probe = 0; probe < PB_TAB; probe++) {
                 const KT old = atomicCAS(&tab[s], EMPTY, id);
                 if (old == EMPTY) return s;
@@ -1121,6 +1218,13 @@ __global__ __launch_bounds__(PB2_T, 6) void k_prob_buckets(const uint64_t *__res
             over = true;
             return 0xFFFFFFFFu;
         };
+        auto insert = [&](uint64_t v) -> uint32_t {
+            const KT id = sizeof(KT) == 4 ? (KT)(pb_hash(v, vmask) & idmask) : (KT)v;
+            return insert_at(id, (uint32_t)((v * 0xD6E8FEB86659FD93ULL) >> 40) & (PB_TAB - 1));
+        };
+        // stored ids: the table slot comes from the id's own top bits (inside a bucket the ids are a bijection of the values and the upper bits of a
+        // multiplicative hash's window are its best mixed) - no second multiplication, and the value is only needed for the draw
+        auto insert_id = [&](uint32_t id) -> uint32_t { return insert_at((KT)id, (sh > 12 ? id >> (sh - 12) : id) & (uint32_t)(PB_TAB - 1)); };
         auto first_draw = [&](uint64_t v) -> double {             // x = c1 * U64f from two of the four state words; when x < 1 it IS the truncated exponential (SPEC 3.3)
             const uint64_t s0 = splitmix_mix(v + GS_GAMMA), s3 = splitmix_mix(v + 4 * GS_GAMMA);
             return pc.c1 * ((double)((rotl64(s0 + s3, 23) + s0) >> 12) * 0x1.0p-52);
@@ -1128,11 +1232,14 @@ __global__ __launch_bounds__(PB2_T, 6) void k_prob_buckets(const uint64_t *__res
 #pragma unroll
         for (int u = 0; u < KPL; u++) {
             own[u] = 0xFFFFFFFFu; x0r[u] = 0.0;
-            if ((uint32_t)(u * PB2_T) + threadIdx.x < n) { own[u] = insert(kreg[u]); x0r[u] = first_draw(kreg[u]); }
+            if ((uint32_t)(u * PB2_T) + threadIdx.x < n) {
+                if (st32) { const uint32_t id = (uint32_t)kreg[u]; own[u] = insert_id(id); x0r[u] = first_draw(pb_unhash(((uint64_t)bk << sh) | (uint64_t)id, vmask)); }
+                else { own[u] = insert(kreg[u]); x0r[u] = first_draw(kreg[u]); }
+            }
         }
         // (buckets beyond KPL * PB2_T keys - heavy repeats - : the tail's owners are found by the table sweep below)
         const bool tail = n > (uint32_t)(KPL * PB2_T);
-        for (uint32_t i = KPL * PB2_T + threadIdx.x; i < n; i += PB2_T) (void)insert(keys[i]);
+        for (uint32_t i = KPL * PB2_T + threadIdx.x; i < n; i += PB2_T) { if (st32) (void)insert_id(keys32[i]); else (void)insert(keys[i]); }
         if (over) ovf[gl] = 1;                                  // table full or a count wrapped: the host redoes this genome the sorted way
         __syncthreads();
         GS_PSTAMP(1);
@@ -1156,14 +1263,15 @@ __global__ __launch_bounds__(PB2_T, 6) void k_prob_buckets(const uint64_t *__res
                 const uint64_t hb = (uint64_t)__double_as_longlong(h);
                 uint64_t *slot = qg + b;
                 if (hb <= __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    const uint64_t old = atomicMin((unsigned long long *)slot, (unsigned long long)hb);
-                    if (hb <= old) {                             // the slot's minimum (or tied with it) at this moment: a possible winner
-                        const uint32_t sp = atomicAdd(&s_nc, 1u);
-                        if (sp < (uint32_t)PB_CST) { sc_v[sp] = v; sc_h[sp] = hb; sc_b[sp] = b; }
-                        else {                                   // staging full (first buckets of a genome): the shared overflow region behind the segments
-                            const uint32_t pos = atomicAdd(L.n_cand, 1u);
-                            if (pos < L.ovf_cap) { const uint32_t o = L.cand_cap + pos; L.cand_v[o] = v; L.cand_h[o] = hb; L.cand_gb[o] = (uint64_t)gl * m + b; }
-                        }
+                    // not above the slot's minimum a moment ago: a possible winner. The atomicMin's answer is not waited for (a second memory round trip per
+                    // bucket): whoever passes the read is listed - a superset of those the atomic would confirm, and the claim only takes candidates whose
+                    // point equals the slot's final minimum
+                    (void)__hip_atomic_fetch_min((unsigned long long *)slot, (unsigned long long)hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t sp = atomicAdd(&s_nc, 1u);
+                    if (sp < (uint32_t)PB_CST) { sc_v[sp] = v; sc_h[sp] = hb; sc_b[sp] = b; }
+                    else {                                       // staging full (first buckets of a genome): the shared overflow region behind the segments
+                        const uint32_t pos = atomicAdd(L.n_cand, 1u);
+                        if (pos < L.ovf_cap) { const uint32_t o = L.cand_cap + pos; L.cand_v[o] = v; L.cand_h[o] = hb; L.cand_gb[o] = (uint64_t)gl * m + b; }
                     }
                 }
             }
@@ -1293,13 +1401,28 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
     }
     const bool id32 = shmax <= 31 && !getenv("GS_PROB_ID64");       // every genome's in-bucket id fits 4 bytes (with ~0 left over for "empty")
     boff[ng] = nbt;
+    // two-level partition: coarse buckets = the top half of the bucket bits
+    std::vector<uint32_t> cinfo(2 * (size_t)ng + 1);                // [0, ng): coarse shifts, [ng, 2 ng]: flat coarse-bucket offsets
+    uint32_t nct = 0, ncmax = 1, nfmax = 1;
+    for (uint32_t i = 0; i < ng; i++) {
+        const uint32_t lg = vbits - sh[i], lgc = lg / 2;
+        cinfo[i] = sh[i] + (lg - lgc); cinfo[ng + i] = nct; nct += 1u << lgc; ncmax = std::max(ncmax, 1u << lgc); nfmax = std::max(nfmax, 1u << (lg - lgc));
+    }
+    cinfo[2 * (size_t)ng] = nct;
     const uint64_t avg_units = maxk / 32 + 1;
     const uint32_t parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(avg_units / ((uint64_t)PBK_T * PBK_WPL) + 1, std::max<uint64_t>(1, (2 * (uint64_t)c->n_cu + ng - 1) / ng)));
     PoolBuf dsh(c, 0), dboff(c, 1), dvb(c, 2), hist(c, 3), bst(c, 4), bsz(c, 5), bgn(c, 6), vals(c, 8), q(c, 9), qprev(c, 10), sig(c, 11), sigpass(c, 12), thr(c, 13), wmax(c, 14),
         qmax(c, 15), ctr(c, 7);
     PoolBuf cv(c, 16), chh(c, 17), cgb(c, 18), akey(c, 19), agl(c, 24), acnt(c, 25), astate(c, 26), ph(c, 27), pb(c, 37), ovf(c, 38);
     const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)ng * m * 16 + 65536, (uint64_t)1 << 30), ovf_cap = cand_cap / 4, act_cap = 1u << 24;
-    PoolBuf segn(c, 28);
+    PoolBuf segn(c, 28), tmpv(c, 61), dcin(c, 62);
+    const bool two_level = !getenv("GS_PROB_ONELEVEL") && (uint64_t)parts * ncmax <= PB_CCMAX && ncmax <= 256 && nfmax <= 256;
+    uint32_t *d_shc = nullptr, *d_coff = nullptr, *d_ccur = nullptr, *d_ccnt = nullptr;
+    if (two_level) {
+        if ((rc = tmpv.alloc(8 * (size_t)T + 64)) || (rc = dcin.alloc(4 * (cinfo.size() + 2 * (size_t)nct * parts) + 64))) return rc;
+        d_shc = dcin.as<uint32_t>(); d_coff = d_shc + ng; d_ccur = d_coff + ng + 1; d_ccnt = d_ccur + (size_t)nct * parts;
+        GS_HIP_CHECK(hipMemcpyAsync(dcin.p, cinfo.data(), 4 * cinfo.size(), hipMemcpyHostToDevice, c->stream));
+    }
     if ((rc = dsh.alloc(4 * (size_t)ng)) || (rc = dboff.alloc(4 * (size_t)(ng + 1))) || (rc = dvb.alloc(8 * (size_t)ng)) || (rc = hist.alloc((size_t)4 * nbt * parts)) ||
         (rc = bst.alloc((size_t)4 * nbt)) || (rc = bsz.alloc((size_t)4 * nbt)) || (rc = bgn.alloc((size_t)4 * nbt)) || (rc = vals.alloc(8 * (size_t)T + 64)) ||
         (rc = q.alloc((size_t)8 * ng * m)) || (rc = qprev.alloc((size_t)8 * ng * m)) || (rc = sig.alloc((size_t)8 * ng * m)) || (rc = sigpass.alloc((size_t)8 * ng * m)) ||
@@ -1333,8 +1456,19 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
     } while (0)
         if (aa) GS_LAUNCH_PBP(true, 0); else GS_LAUNCH_PBP(false, 0);
         hipLaunchKernelGGL(k_prob_scan, dim3(ng), dim3(1024), 0, c->stream, vbits, dsh.as<uint32_t>(), dboff.as<uint32_t>(), parts, hist.as<uint32_t>(), bst.as<uint32_t>(), bsz.as<uint32_t>(),
-                           bgn.as<uint32_t>(), q.as<uint64_t>(), m, thr.as<uint64_t>());
-        if (aa) GS_LAUNCH_PBP(true, 1); else GS_LAUNCH_PBP(false, 1);
+                           bgn.as<uint32_t>(), q.as<uint64_t>(), m, thr.as<uint64_t>(), d_shc, d_coff, d_ccur, d_ccnt);
+        if (!two_level) { if (aa) GS_LAUNCH_PBP(true, 1); else GS_LAUNCH_PBP(false, 1); }
+        else {
+            // coarse scatter: the same kernel with the coarse shifts, offsets and per-part bases, into the intermediate copy; then the refinement
+            const size_t lds_c = (size_t)4 * ncmax;
+#define GS_LAUNCH_PBC(AAV)                                                                                                   \
+    hipLaunchKernelGGL((k_prob_partition<AAV, 1>), grid, block, lds_c, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, k, vbits, d_shc, d_coff, parts, \
+                       d_ccur, q.as<uint64_t>(), m, zone, pc, tmpv.as<uint64_t>(), dvb.as<uint64_t>())
+            if (aa) GS_LAUNCH_PBC(true); else GS_LAUNCH_PBC(false);
+#undef GS_LAUNCH_PBC
+            hipLaunchKernelGGL(k_prob_refine, dim3(parts * ncmax, ng), dim3(PBR_T), 0, c->stream, tmpv.as<uint64_t>(), vals.as<uint64_t>(), dvb.as<uint64_t>(), vbits, dsh.as<uint32_t>(),
+                               dboff.as<uint32_t>(), d_shc, d_coff, parts, hist.as<uint32_t>(), d_ccur, d_ccnt, (uint32_t)id32);
+        }
 #undef GS_LAUNCH_PBP
         GS_HIP_CHECK(hipGetLastError());
         if ((rc = akey.alloc((size_t)8 * act_cap)) || (rc = agl.alloc((size_t)4 * act_cap)) || (rc = acnt.alloc((size_t)4 * act_cap)) || (rc = astate.alloc((size_t)32 * act_cap))) return rc;
@@ -1349,7 +1483,8 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
         const uint32_t wgs = (uint32_t)std::min<uint64_t>((uint64_t)ng << lg_max, (uint64_t)c->n_cu * std::min(std::max(per_cu, 1), 8));     // resident workgroups only: the items are dealt statically
 #define GS_LAUNCH_PBB(KT)                                                                                                     \
         hipLaunchKernelGGL(k_prob_buckets<KT>, dim3(wgs), dim3(PB2_T), 0, c->stream, vals.as<uint64_t>(), dvb.as<uint64_t>(), bst.as<uint32_t>(), bsz.as<uint32_t>(), vbits, \
-                           dsh.as<uint32_t>(), dboff.as<uint32_t>(), ng, lg_max, m, zone, pc, q.as<uint64_t>(), thr.as<uint64_t>(), wmax.as<uint32_t>(), L, ovf.as<uint32_t>())
+                           dsh.as<uint32_t>(), dboff.as<uint32_t>(), ng, lg_max, m, zone, pc, q.as<uint64_t>(), thr.as<uint64_t>(), wmax.as<uint32_t>(), L, ovf.as<uint32_t>(), \
+                           (uint32_t)(two_level && id32))
         if (id32) GS_LAUNCH_PBB(uint32_t); else GS_LAUNCH_PBB(uint64_t);
 #undef GS_LAUNCH_PBB
         if (L.prof) {
