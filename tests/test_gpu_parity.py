@@ -335,15 +335,18 @@ def test_sketch_prob_matches_oracle(gpu_ctx, k, m, data):
 
 
 @pytest.mark.parametrize("k,m,data,length", [(21, 1000, "dna", 200000), (16, 512, "dna", 90000), (32, 700, "dna", 120000), (7, 600, "aa", 100000), (21, 18000, "dna", 1600000)])
-@pytest.mark.parametrize("impl", ["buckets", "sort"])
+@pytest.mark.parametrize("impl", ["buckets", "buckets_one_level", "sort"])
 def test_sketch_prob_bucketed_form_matches_oracle(gpu_ctx, monkeypatch, k, m, data, length, impl):
     """ProbMinHash3a on genomes with >= 64 k-mers per slot, which take the bucketed form (partition by hash bits -> LDS hash -> (value,
-    multiplicity) -> first points under a running rejection threshold): repeats of multiplicity 2..40 (pass 2 and later over the active
+    multiplicity) -> first points under a running rejection threshold; the partition in two levels - coarse scatter + LDS-sorted refinement that
+    leaves 4-byte ids, 8-byte values for k = 32 - or in one): repeats of multiplicity 2..40 (pass 2 and later over the active
     list), a genome in two parts workgroups split, multi-record genomes, and small genomes in the same batch (sorted form) - bit-exact
     against the oracle, and the sorted form (GS_PROB_IMPL=sort) gives the same signatures"""
     import gsearch_amd as G
     if impl == "sort":
         monkeypatch.setenv("GS_PROB_IMPL", "sort")
+    if impl == "buckets_one_level":                               # the round-3 partition (one scatter over all buckets, 8-byte values): kept for A/B
+        monkeypatch.setenv("GS_PROB_ONELEVEL", "1")
     rng = np.random.default_rng(k * 131 + m)
     if data == "dna":
         fam = H.family(rng, length, [0.01, 0.05])
