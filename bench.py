@@ -690,6 +690,7 @@ def extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff):
         rates[algo] = {"genomes": ng, "kmers_per_sec": (L - k + 1) * ng / best, "genomes_per_sec": ng / best, "wall_ms": best * 1e3,
                        "bit_exact_vs_oracle_genome0": bool(np.array_equal(ref[0].view(np.uint8), sig[0].view(np.uint8)))}
         ctx.free(d_sig)
+        chk(lib.gs_ctx_release_scratch(ctx.h))                  # the sketchers' scratch (ProbMinHash: two copies of a chunk's k-mers) is not needed by the next leg
     out["other_sketchers_k21_s18000"] = rates
     # ---- (2) BASELINE configs[4]: AA k=7 s=24000 super2 -> u64 signatures, all 50 000 proteomes (75 GB of residues generated in HBM, gs_synth_aa_dev)
     kaa, maa, Laa, NP = 7, 24000, 1_500_000, args.c5_proteomes

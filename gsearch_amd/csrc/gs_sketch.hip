@@ -1416,10 +1416,13 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
     PoolBuf cv(c, 16), chh(c, 17), cgb(c, 18), akey(c, 19), agl(c, 24), acnt(c, 25), astate(c, 26), ph(c, 27), pb(c, 37), ovf(c, 38);
     const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)ng * m * 16 + 65536, (uint64_t)1 << 30), ovf_cap = cand_cap / 4, act_cap = 1u << 24;
     PoolBuf segn(c, 28), tmpv(c, 61), dcin(c, 62);
-    const bool two_level = !getenv("GS_PROB_ONELEVEL") && (uint64_t)parts * ncmax <= PB_CCMAX && ncmax <= 256 && nfmax <= 256;
+    bool two_level = !getenv("GS_PROB_ONELEVEL") && (uint64_t)parts * ncmax <= PB_CCMAX && ncmax <= 256 && nfmax <= 256;
+    // the second copy of the values is the price of the two levels: a device that has no room for it (an index with its pair cache beside the
+    // sketcher, say) partitions in one level as in round 3
+    if (two_level && tmpv.alloc(8 * (size_t)T + 64) != GS_OK) { (void)hipGetLastError(); two_level = false; }
     uint32_t *d_shc = nullptr, *d_coff = nullptr, *d_ccur = nullptr, *d_ccnt = nullptr;
     if (two_level) {
-        if ((rc = tmpv.alloc(8 * (size_t)T + 64)) || (rc = dcin.alloc(4 * (cinfo.size() + 2 * (size_t)nct * parts) + 64))) return rc;
+        if ((rc = dcin.alloc(4 * (cinfo.size() + 2 * (size_t)nct * parts) + 64))) return rc;
         d_shc = dcin.as<uint32_t>(); d_coff = d_shc + ng; d_ccur = d_coff + ng + 1; d_ccnt = d_ccur + (size_t)nct * parts;
         GS_HIP_CHECK(hipMemcpyAsync(dcin.p, cinfo.data(), 4 * cinfo.size(), hipMemcpyHostToDevice, c->stream));
     }
