@@ -2,7 +2,7 @@
 # Runs ON the GPU box: rocprofv3 kernel trace of `bench.py --steps 1 --warmup 1`, condensed to the kernels of the LAST request step (everything after the
 # last k_sketch_min launch starts): name, launches, total ms - what a 10 000-query request consists of, launch by launch.
 R=$(pwd); export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/steptrace -o st -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/steptrace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/steptrace -o st -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/steptrace.log 2>&1
 cd $R
 python - <<'P'
 import csv, glob, collections
@@ -25,10 +25,10 @@ for r in seg:
     k = r["Kernel_Name"].split("(")[0][:70]
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 busy = sum(v[1] for v in agg.values())
-with open("gpurun_out/r03_request_step_trace.txt", "w") as f:
+with open("gpurun_out/r04_request_step_trace.txt", "w") as f:
     f.write("one 10 000-query request (bench.py step), rocprofv3 --kernel-trace: %d launches, %.2f ms from first start to last end, %.2f ms inside kernels\n" % (len(seg), (t1 - t0) / 1e6, busy))
     for k, (n, ms) in sorted(agg.items(), key=lambda x: -x[1][1]):
         f.write("%8.3f ms  %4d x  %s\n" % (ms, n, k))
-print(open("gpurun_out/r03_request_step_trace.txt").read())
+print(open("gpurun_out/r04_request_step_trace.txt").read())
 P
 rm -rf gpurun_out/steptrace
