@@ -814,7 +814,12 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     // (query, node) pairs the blocks take off the match-by-match path; a handful is not worth a second kernel variant and the tile launch
     uint64_t saved_pairs = 0;
     for (uint32_t l = 0; l < nq; l++) if (cid[l]) saved_pairs += (uint64_t)(cq[l] - 1) * ce_[l];
-    const uint64_t min_saved = getenv("GS_JOIN_CLUSTER_MIN") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MIN")) : (ce && atoi(ce) == 2 ? 0 : (uint64_t)nq * 8);
+    // (the cluster-aware kernel costs ~7 ms more than the plain one per 2500 queries x 300 k nodes - in proportion to queries x nodes - whatever it saves:
+    // 32 pairs per query at 300 k nodes is where the two meet since the survivor queue made the plain kernel faster. 2500-query batches of isolates of 300
+    // species - a handful of 12-query components by chance - ran 137 ms clustered against 125 plain; 200 species and fewer cluster as before:
+    // profiles/r04_join_cluster_sweep.txt, bottom)
+    const uint64_t min_scaled = (uint64_t)((double)nq * 32.0 * (double)n / 3.0e5);
+    const uint64_t min_saved = getenv("GS_JOIN_CLUSTER_MIN") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MIN")) : (ce && atoi(ce) == 2 ? 0 : std::max<uint64_t>((uint64_t)nq * 8, min_scaled));
     if (verbose)
         fprintf(stderr, "[GS_JOIN] nq=%u n=%llu heavy pairs %llu (matches in the first %u slots %llu): %u clusters, %u queries x %llu nodes in %u tiles, %llu pairs off the atomics%s\n", nq,
                 (unsigned long long)n, (unsigned long long)npairs, JS0, hc[1], K, nhq, (unsigned long long)nhe, ntiles, (unsigned long long)saved_pairs,
