@@ -342,11 +342,13 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ com
 // ---- the window-less form with several matches in flight (round 4) ---------------------------------------------------------------------
 // What bounded k_inflate<true>: a member's 32 KB of history lives in the text it has written, 20 members per CU keep ~20 MB of history per
 // XCD alive against 4 MB of L2, so the source bytes of a match come back from the Infinity Cache / HBM (~1.5-2 us) - and the wave waited
-// for every one of them before it stored the copy and went on (gzip -6 of DNA is one match per ~5 bytes: ~4 900 cycles per symbol and wave,
-// 5 waves per SIMD). Decoding does not depend on the copied bytes, only later copies may: here the wave keeps decoding while up to P
-// matches have their source loads in flight and stores the P copies after ONE wait. A match whose source reaches into text that is not known
-// to have arrived in L2 (`synced`: the start of the oldest copy whose loads had not been waited for at the last wait - this batch's and the
-// previous batch's destinations lie above it) drains everything first; so do matches longer than one load per lane (64 bytes).
+// for every one of them before it stored the copy and went on (gzip -6 of DNA is one match per ~5 bytes: ~1 460 cycles per symbol and wave
+// at the 1.5 waves per SIMD of a 6 x CUs group). Decoding does not depend on the copied bytes, only later copies may: here the wave decodes a
+// batch of up to P matches, stores the copies of the PREVIOUS batch after one wait and then issues this batch's source loads, which have the
+// next round of decoding to come back. A match whose source reaches into text that is not known to have arrived in L2 (`synced`: the first
+// destination of the batch in flight - everything below it had been stored before the last wait) drains both batches first; so do matches
+// longer than one load per lane (64 bytes). Measured: 587 -> 383 ms per 1536 x 5 Mbp members, most of it from the instructions this
+// restructuring took off the per-symbol chain - the kernel executes 70 scalar + 14 vector instructions per symbol.
 template <int KIND>
 __device__ __forceinline__ uint32_t inf_walk_inl(uint64_t buf)
 {
@@ -364,8 +366,8 @@ __device__ __forceinline__ uint32_t inf_walk_inl(uint64_t buf)
 }
 // The root tables of a block in REGISTERS: entry i lives in lane i & 63 of register i >> 6 (16 registers for the 10-bit literal/length table, 4
 // of 16 for the 8-bit distance table). A look-up is an indexed register read with a wave-uniform index plus v_readlane - a few cycles - where the LDS
-// read + wait + v_readfirstlane of the other forms is ~140: at 1.5 members per SIMD (a group of 6 x CUs members) the decode is one wave's
-// dependent chain, and the two look-ups of a match were a third of it.
+// read + wait + v_readfirstlane of the other forms is ~140 (by itself this changed nothing measurable: 434.7 vs 434.7 ms - what it buys is one LDS
+// instruction per nine symbols instead of three per symbol on a chain that is bound by its instruction count).
 typedef uint32_t inf_u32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ uint32_t inf_lut16(const inf_u32x16 &t, uint32_t idx) { const uint32_t v = t[idx >> 6]; return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u)); }
 template <int P>
