@@ -10,7 +10,7 @@ SO_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsearch_amd.s
 
 GS_OK, GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_UNSUPPORTED, GS_ERR_STATE, GS_ERR_IO = 0, -1, -2, -3, -4, -5
 ALGO = {"prob": 0, "super": 1, "super2": 2, "hll": 3, "optdens": 4, "revoptdens": 5}
-DATA = {"dna": 0, "aa": 1}
+DATA = {"dna": 0, "aa": 1, "dna_fwd": 2}   # dna_fwd: forward window, no reverse-complement minimum (bindash.rs:346-354, k <= 14)
 KIND_U16, KIND_U32, KIND_U64, KIND_F32 = 0, 1, 2, 3
 
 

@@ -243,7 +243,7 @@ class _SeqSketcher:
         return out
 
     def _pack(self, records):
-        if self.params.c.data_t == DATA["dna"]:
+        if self.params.c.data_t != DATA["aa"]:
             return pack_dna_records(records)
         return filter_aa_records(records)
 
@@ -451,6 +451,15 @@ class DistHamming:
 def ani(distance, kmer_size, model=1):
     """reformat.rs:80-86 calculate_ani."""
     return _lib.load().gs_ani(float(distance), int(kmer_size), int(model))
+
+
+def bindash_sketch_params(kmer_size, sketch_size, dens=0):
+    """The sketcher bindash-rs builds for (kmer_size, dens): OptDens (dens = 0) or RevOptDens (dens = 1) over f32 (bindash.rs:182-226), with the
+    k-mer closure of its three branches - k <= 14: the forward window, NOT canonical (bindash.rs:346-354); k = 16 and 17..32: canonical
+    (bindash.rs:366-377, 388-397)."""
+    if dens not in (0, 1):
+        raise ValueError("Only densification = 0 or 1 are supported!")          # bindash.rs:227-229
+    return SeqSketcherParams(kmer_size, sketch_size, "optdens" if dens == 0 else "revoptdens", "dna_fwd" if kmer_size <= 14 else "dna")
 
 
 def bindash_distance(hamming_distance, kmer_size):

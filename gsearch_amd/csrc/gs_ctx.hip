@@ -212,7 +212,7 @@ int gs_check_params(const gs_sketch_params *p)
     GS_REQUIRE(p, GS_ERR_INVALID, "null params");
     GS_REQUIRE(p->sketch_size >= 2, GS_ERR_INVALID, "sketch_size must be >= 2");
     GS_REQUIRE(p->algo <= GS_ALGO_REVOPTDENS, GS_ERR_INVALID, "unknown sketch algo %u", p->algo);
-    if (p->data_t == GS_DATA_DNA) {
+    if (p->data_t == GS_DATA_DNA || p->data_t == GS_DATA_DNA_FWD) {
         GS_REQUIRE(p->k >= 1 && p->k <= 32, GS_ERR_INVALID, "DNA kmer size must be in 1..32");
         GS_REQUIRE(p->k != 15, GS_ERR_INVALID, "kmer size 15 is rejected (dnarequest.rs:451-454)");
     } else if (p->data_t == GS_DATA_AA) {
@@ -224,7 +224,7 @@ int gs_check_params(const gs_sketch_params *p)
 }
 int gs_value_bits(const gs_sketch_params *p)
 {
-    if (p->data_t == GS_DATA_DNA) return (p->k <= 14 || p->k == 16) ? 32 : 64;
+    if (p->data_t != GS_DATA_AA) return (p->k <= 14 || p->k == 16) ? 32 : 64;
     return p->k <= 6 ? 32 : 64;
 }
 int gs_sig_kind(const gs_sketch_params *p)

@@ -169,7 +169,7 @@ template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_
 template <bool AA, class Emit>
 __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
                                           const uint64_t *__restrict__ rec_upre, uint64_t r0, uint64_t r1, uint64_t f, uint32_t k, uint64_t mask, uint32_t rcshift,
-                                          const Emit &emit)
+                                          uint64_t rc_or, const Emit &emit)
 {
     {
         // record owning flat unit f: last r in [r0,r1) with rec_upre[r] <= f
@@ -188,7 +188,7 @@ __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const
                 for (uint32_t j = 0; j + 1 < k; j++) {
                     uint64_t c = p >> 62; p <<= 2;
                     fwd = ((fwd << 2) | c) & mask;
-                    rc = (rc >> 2) | ((3 - c) << rcshift);
+                    rc = (rc >> 2) | ((3 - c) << rcshift) | rc_or;
                 }
             }
             // (rc never exceeds 2k bits and fwd is masked every step: the minimum needs no further mask.) When every lane of the wave
@@ -201,7 +201,7 @@ __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const
                 for (uint32_t j = 0; j < 32; j++) {
                     uint64_t c = w >> 62; w <<= 2;
                     fwd = ((fwd << 2) | c) & mask;
-                    rc = (rc >> 2) | ((3 - c) << rcshift);
+                    rc = (rc >> 2) | ((3 - c) << rcshift) | rc_or;
                     emit_full_wave(emit, fwd < rc ? fwd : rc, lo, a0 + j);
                 }
                 emit_word_done(emit);
@@ -210,7 +210,7 @@ __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const
                 for (uint32_t j = 0; j < 32; j++) {
                     uint64_t c = w >> 62; w <<= 2;
                     fwd = ((fwd << 2) | c) & mask;
-                    rc = (rc >> 2) | ((3 - c) << rcshift);
+                    rc = (rc >> 2) | ((3 - c) << rcshift) | rc_or;
                     emit(fwd < rc ? fwd : rc, lo, a0 + j);
                 }
             } else {
@@ -218,7 +218,7 @@ __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const
                 for (uint32_t j = 0; j < 32; j++) {
                     uint64_t c = w >> 62; w <<= 2;
                     fwd = ((fwd << 2) | c) & mask;
-                    rc = (rc >> 2) | ((3 - c) << rcshift);
+                    rc = (rc >> 2) | ((3 - c) << rcshift) | rc_or;
                     uint64_t a = a0 + j;
                     if (a >= first_valid && a < re) emit(fwd < rc ? fwd : rc, lo, a);
                 }
@@ -248,17 +248,26 @@ __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const
         }
     }
 }
+// Kernels that walk sequences take `kq` = k | KQ_FWD: bit 8 set means GS_DATA_DNA_FWD - the k-mer is the forward window itself, no
+// reverse-complement minimum (the k <= 14 closure of /root/reference/src/bin/bindash.rs:346-354: `kmer.get_compressed_value() & mask`).
+// The walkers keep ONE code path: rc_or = ~0 pins the reverse-complement register at all ones, so `min(fwd, rc)` is fwd (the OR folds into the
+// v_or3 that already merges the shifted halves - no instruction more on the canonical path).
+enum { KQ_FWD = 0x100 };
+__device__ __forceinline__ uint32_t kq_k(uint32_t kq) { return kq & 0xFFu; }
+__device__ __forceinline__ uint64_t kq_rc_or(uint32_t kq) { return (kq & KQ_FWD) ? ~(uint64_t)0 : (uint64_t)0; }
+static inline uint32_t kq_of(const gs_sketch_params *p) { return p->k | (p->data_t == GS_DATA_DNA_FWD ? (uint32_t)KQ_FWD : 0u); }
 __device__ __forceinline__ uint64_t kmer_mask(bool aa, uint32_t k) { return aa ? (((uint64_t)1 << (5 * k)) - 1) : (k == 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1)); }
 template <bool AA, class Emit>
 __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
                                             const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
-                                            uint64_t r0, uint64_t r1, uint64_t units, uint32_t k, uint32_t part,
+                                            uint64_t r0, uint64_t r1, uint64_t units, uint32_t kq, uint32_t part,
                                             uint32_t parts, const Emit &emit)
 {
-    const uint64_t mask = kmer_mask(AA, k);
+    const uint32_t k = kq_k(kq);
+    const uint64_t mask = kmer_mask(AA, k), rc_or = kq_rc_or(kq);
     const uint32_t rcshift = 2 * (k - 1);
     for (uint64_t f = (uint64_t)part * blockDim.x + threadIdx.x; f < units; f += (uint64_t)parts * blockDim.x)
-        walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, emit);
+        walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, emit);
     emit_finish(emit);
 }
 
@@ -403,8 +412,10 @@ struct SmhSeqEmit {
     }
 };
 template <bool AA, class Emit>
-__device__ void walk_genome_seq(const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len, uint64_t r0, uint64_t r1, uint32_t k, const Emit &emit)
+__device__ void walk_genome_seq(const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len, uint64_t r0, uint64_t r1, uint32_t kq, const Emit &emit)
 {
+    const uint32_t k = kq_k(kq);
+    const uint64_t rc_or = kq_rc_or(kq);
     for (uint64_t r = r0; r < r1; r++) {
         const uint64_t rb = rec_start[r], len = rec_len[r];
         if (len < k) continue;
@@ -415,7 +426,7 @@ __device__ void walk_genome_seq(const uint8_t *seq, const uint64_t *rec_start, c
                 const uint64_t a = rb + i;
                 const uint64_t c = (seq[a >> 2] >> (6 - 2 * (a & 3))) & 3;
                 fwd = ((fwd << 2) | c) & mask;
-                rc = (rc >> 2) | ((3 - c) << (2 * (k - 1)));
+                rc = (rc >> 2) | ((3 - c) << (2 * (k - 1))) | rc_or;
                 if (i + 1 >= k) emit((fwd < rc ? fwd : rc) & mask);
             }
         } else {
@@ -588,7 +599,7 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
         auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T, FV>;                                                        \
         const size_t l = LDSV ? (FV ? lds_f : lds) : ((size_t)2 * m + 15) & ~(size_t)15;      /* slot table (+ survivor queues), or its 2-byte filter */  \
         if (l > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
-        hipLaunchKernelGGL(kern, grid, block, l, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, p->k, m, zone, tab); \
+        hipLaunchKernelGGL(kern, grid, block, l, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, kq_of(p), m, zone, tab); \
     } while (0)
         if (aa) { if (ge.use_lds) GS_LAUNCH_MIN(true, true, false); else GS_LAUNCH_MIN(true, false, false); }
         else if (!ge.use_lds) GS_LAUNCH_MIN(false, false, false);
@@ -637,7 +648,7 @@ static int run_smh(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     do {                                                                                                                       \
         auto kern = k_smh_cold_wg<AAV, ALGO, VBITS, T>;                                                                        \
         if (lds_wg > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg)); \
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(CW_T), lds_wg, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, p->k, m, \
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(CW_T), lds_wg, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, kq_of(p), m, \
                            lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), sig_out);                       \
     } while (0)
         if (aa) GS_LAUNCH_COLDWG(true); else GS_LAUNCH_COLDWG(false);
@@ -655,8 +666,8 @@ static int run_smh(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if ((rc = dl.alloc(4 * (size_t)nc))) return rc;
         if ((rc = scratch.alloc((size_t)nc * 32 * m))) return rc;
         GS_HIP_CHECK(hipMemcpyAsync(dl.p, list.data() + l0, 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
-        if (aa) hipLaunchKernelGGL((k_smh_cold<true, ALGO, VBITS, T>), dim3((nc + 63) / 64), dim3(64), 0, c->stream, seq, rec_start, rec_len, genome_rec_off, dl.as<uint32_t>(), nc, p->k, m, scratch.as<uint8_t>(), sig_out);
-        else hipLaunchKernelGGL((k_smh_cold<false, ALGO, VBITS, T>), dim3((nc + 63) / 64), dim3(64), 0, c->stream, seq, rec_start, rec_len, genome_rec_off, dl.as<uint32_t>(), nc, p->k, m, scratch.as<uint8_t>(), sig_out);
+        if (aa) hipLaunchKernelGGL((k_smh_cold<true, ALGO, VBITS, T>), dim3((nc + 63) / 64), dim3(64), 0, c->stream, seq, rec_start, rec_len, genome_rec_off, dl.as<uint32_t>(), nc, kq_of(p), m, scratch.as<uint8_t>(), sig_out);
+        else hipLaunchKernelGGL((k_smh_cold<false, ALGO, VBITS, T>), dim3((nc + 63) / 64), dim3(64), 0, c->stream, seq, rec_start, rec_len, genome_rec_off, dl.as<uint32_t>(), nc, kq_of(p), m, scratch.as<uint8_t>(), sig_out);
         GS_HIP_CHECK(hipGetLastError());
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
@@ -748,7 +759,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_emit_values(const uint8_t *__res
                                                              const uint64_t *__restrict__ gen_base, uint64_t g0, uint32_t k, uint32_t vbits, uint64_t *__restrict__ out)
 {
     const uint64_t gl = blockIdx.y, g = g0 + gl;
-    ValueEmit emit{out, rec_start, rec_kpre, gen_base[gl], vbits >= 64 ? 0 : (gl << vbits), k};
+    ValueEmit emit{out, rec_start, rec_kpre, gen_base[gl], vbits >= 64 ? 0 : (gl << vbits), kq_k(k)};
     walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, blockIdx.x, gridDim.x, emit);
 }
 __global__ void k_prob_init(uint64_t *q, uint64_t *qprev, uint64_t *sig, uint64_t *sigpass, uint64_t n)
@@ -936,7 +947,7 @@ struct PbScatterEmit {
 template <bool AA, int MODE>
 __global__ __launch_bounds__(PBK_T) void k_prob_partition(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
                                                            const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
-                                                           uint64_t g0, uint32_t k, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff, uint32_t parts,
+                                                           uint64_t g0, uint32_t kq, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff, uint32_t parts,
                                                            uint32_t *__restrict__ hist, uint64_t *__restrict__ q, uint32_t m, uint64_t zone, ProbConst pc,
                                                            uint64_t *__restrict__ vals, const uint64_t *__restrict__ g_vbase)
 {
@@ -948,7 +959,8 @@ __global__ __launch_bounds__(PBK_T) void k_prob_partition(const uint8_t *__restr
     for (uint32_t b = threadIdx.x; b < NB; b += PBK_T) s_pb[b] = MODE == 0 ? 0u : hg[b];
     __syncthreads();
     const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
-    const uint64_t mask = kmer_mask(AA, k);
+    const uint32_t k = kq_k(kq);
+    const uint64_t mask = kmer_mask(AA, k), rc_or = kq_rc_or(kq);
     const uint32_t rcshift = 2 * (k - 1);
     const uint64_t TILE = (uint64_t)PBK_T * PBK_WPL;
     for (uint64_t t0 = (uint64_t)part * TILE; t0 < units; t0 += (uint64_t)parts * TILE) {
@@ -957,9 +969,9 @@ __global__ __launch_bounds__(PBK_T) void k_prob_partition(const uint8_t *__restr
             const uint64_t f = t0 + (uint64_t)j * PBK_T + threadIdx.x;
             if (f >= units) continue;
             if (MODE == 0) {
-                if (t0 == (uint64_t)part * TILE) { PbWarmEmit e{s_pb, sh, mask, q + (uint64_t)gl * m, m, zone, pc}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, e); }
-                else { PbCountEmit e{s_pb, sh, mask}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, e); }
-            } else { PbScatterEmit e{s_pb, sh, mask, vals + g_vbase[gl]}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, e); }
+                if (t0 == (uint64_t)part * TILE) { PbWarmEmit e{s_pb, sh, mask, q + (uint64_t)gl * m, m, zone, pc}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, e); }
+                else { PbCountEmit e{s_pb, sh, mask}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, e); }
+            } else { PbScatterEmit e{s_pb, sh, mask, vals + g_vbase[gl]}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, e); }
         }
     }
     if (MODE == 0) {
@@ -1454,7 +1466,7 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
     do {                                                                                                                      \
         auto kern = k_prob_partition<AAV, MODE>;                                                                              \
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, block, lds, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, k, vbits, dsh.as<uint32_t>(), dboff.as<uint32_t>(), parts, \
+        hipLaunchKernelGGL(kern, grid, block, lds, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, kq_of(p), vbits, dsh.as<uint32_t>(), dboff.as<uint32_t>(), parts, \
                            hist.as<uint32_t>(), q.as<uint64_t>(), m, zone, pc, vals.as<uint64_t>(), dvb.as<uint64_t>());      \
     } while (0)
         if (aa) GS_LAUNCH_PBP(true, 0); else GS_LAUNCH_PBP(false, 0);
@@ -1465,7 +1477,7 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
             // coarse scatter: the same kernel with the coarse shifts, offsets and per-part bases, into the intermediate copy; then the refinement
             const size_t lds_c = (size_t)4 * ncmax;
 #define GS_LAUNCH_PBC(AAV)                                                                                                   \
-    hipLaunchKernelGGL((k_prob_partition<AAV, 1>), grid, block, lds_c, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, k, vbits, d_shc, d_coff, parts, \
+    hipLaunchKernelGGL((k_prob_partition<AAV, 1>), grid, block, lds_c, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, kq_of(p), vbits, d_shc, d_coff, parts, \
                        d_ccur, q.as<uint64_t>(), m, zone, pc, tmpv.as<uint64_t>(), dvb.as<uint64_t>())
             if (aa) GS_LAUNCH_PBC(true); else GS_LAUNCH_PBC(false);
 #undef GS_LAUNCH_PBC
@@ -1648,8 +1660,8 @@ static int run_prob_sorted(gs_ctx *c, const gs_sketch_params *p, const uint8_t *
             {
                 ProfScope ps(c, FAM_SKETCH);
                 dim3 grid(parts, (uint32_t)ng), block(SK_THREADS);
-                if (aa) hipLaunchKernelGGL(k_emit_values<true>, grid, block, 0, c->stream, seq, rec_start, rec_len, upre.as<uint64_t>(), kpre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), dbase.as<uint64_t>(), g0, k, vbits, vals.as<uint64_t>());
-                else hipLaunchKernelGGL(k_emit_values<false>, grid, block, 0, c->stream, seq, rec_start, rec_len, upre.as<uint64_t>(), kpre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), dbase.as<uint64_t>(), g0, k, vbits, vals.as<uint64_t>());
+                if (aa) hipLaunchKernelGGL(k_emit_values<true>, grid, block, 0, c->stream, seq, rec_start, rec_len, upre.as<uint64_t>(), kpre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), dbase.as<uint64_t>(), g0, kq_of(p), vbits, vals.as<uint64_t>());
+                else hipLaunchKernelGGL(k_emit_values<false>, grid, block, 0, c->stream, seq, rec_start, rec_len, upre.as<uint64_t>(), kpre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), dbase.as<uint64_t>(), g0, kq_of(p), vbits, vals.as<uint64_t>());
                 GS_HIP_CHECK(hipGetLastError());
             }
             int endbit = 64;
@@ -1986,7 +1998,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         auto kern = k_sketch_hll<AAV, false, GV>;                                                                              \
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(HL_T), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, (const uint32_t *)nullptr, \
-                           (uint32_t)n_genomes, p->k, m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
+                           (uint32_t)n_genomes, kq_of(p), m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
                            gt.as<uint32_t>(), use_filter, queue_off, surv_cap ? sv.as<uint64_t>() : (uint64_t *)nullptr, surv_cap, surv_minch); \
     } while (0)
         if (aa) { if (gtab) GS_LAUNCH_HLL(true, true); else GS_LAUNCH_HLL(true, false); }
@@ -2022,7 +2034,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     do {                                                                                                                       \
         auto kern = k_sketch_hll<AAV, true, GV>;                                                                               \
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(cw), dim3(HL_CT), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, p->k, m, \
+        hipLaunchKernelGGL(kern, dim3(cw), dim3(HL_CT), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, kq_of(p), m, \
                            inv_lnb, dcut.as<uint64_t>(), lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
                            gt.as<uint32_t>(), use_filter, 0u, (uint64_t *)nullptr, 0u, 0u);                                    \
     } while (0)

@@ -30,7 +30,10 @@ enum {
 };
 /* kmerutils::sketcharg::SketchAlgo / DataType as parsed at src/bin/gsearch.rs:181-196,258-263 */
 enum { GS_ALGO_PROB3A = 0, GS_ALGO_SUPER = 1, GS_ALGO_SUPER2 = 2, GS_ALGO_HLL = 3, GS_ALGO_OPTDENS = 4, GS_ALGO_REVOPTDENS = 5 };
-enum { GS_DATA_DNA = 0, GS_DATA_AA = 1 };
+/* GS_DATA_DNA_FWD: DNA whose k-mer value is the forward window itself, WITHOUT the reverse-complement minimum - the closure bindash-rs passes
+ * for k <= 14 (`kmer.get_compressed_value() & mask`, src/bin/bindash.rs:346-354; its k = 16 and k > 16 closures, :366-377,:388-397, and every
+ * closure of gsearch itself, dnasketch.rs:164-169, are canonical = GS_DATA_DNA). Accepted for every k and algo; same (k -> Kmer::Val, Sig) table as DNA. */
+enum { GS_DATA_DNA = 0, GS_DATA_AA = 1, GS_DATA_DNA_FWD = 2 };
 /* signature element type (table SURVEY 2.2; src/dna/dnasketch.rs:499-642, src/aa/aasketch.rs:455-550) */
 enum { GS_KIND_U16 = 0, GS_KIND_U32 = 1, GS_KIND_U64 = 2, GS_KIND_F32 = 3 };
 

@@ -39,7 +39,7 @@ private:
 };
 
 enum class SketchAlgo : uint32_t { PROB3A = GS_ALGO_PROB3A, SUPER = GS_ALGO_SUPER, SUPER2 = GS_ALGO_SUPER2, HLL = GS_ALGO_HLL, OPTDENS = GS_ALGO_OPTDENS, REVOPTDENS = GS_ALGO_REVOPTDENS };
-enum class DataType : uint32_t { DNA = GS_DATA_DNA, AA = GS_DATA_AA };
+enum class DataType : uint32_t { DNA = GS_DATA_DNA, AA = GS_DATA_AA, DNA_FWD = GS_DATA_DNA_FWD /* bindash.rs:346-354: k <= 14, no reverse-complement minimum */ };
 
 // kmerutils::sketcharg::SeqSketcherParams::new(kmer_size, sketch_size, algo, data_t)  (src/bin/gsearch.rs:258-263)
 class SeqSketcherParams {

@@ -102,7 +102,7 @@ int go_check_params(const go_params *p)
     if (!p || p->sketch_size < 2) return -1;
     if (p->algo > GO_ALGO_REVOPTDENS) return -2;
     if (p->algo == GO_ALGO_HLL && p->sketch_size > 65535u * 16u) return -1;
-    if (p->data_t == GO_DATA_DNA) {
+    if (p->data_t == GO_DATA_DNA || p->data_t == GO_DATA_DNA_FWD) {
         if (p->k < 1 || p->k > 32 || p->k == 15) return -3;   /* dnarequest.rs:451-454, README.md:676 */
     } else if (p->data_t == GO_DATA_AA) {
         if (p->k < 1 || p->k > 12) return -3;                 /* aasketch.rs:457-466 */
@@ -111,7 +111,7 @@ int go_check_params(const go_params *p)
 }
 int go_value_bits(const go_params *p)
 {
-    if (p->data_t == GO_DATA_DNA) return (p->k <= 14 || p->k == 16) ? 32 : 64;  /* dnasketch.rs:499-518 */
+    if (p->data_t != GO_DATA_AA) return (p->k <= 14 || p->k == 16) ? 32 : 64;  /* dnasketch.rs:499-518 */
     return p->k <= 6 ? 32 : 64;                                                  /* aasketch.rs:455-467 */
 }
 int go_sig_kind(const go_params *p)
@@ -177,7 +177,15 @@ static void for_each_kmer(const go_params *p, const uint8_t *seq, uint64_t start
 {
     uint32_t k = p->k;
     if (len < k) return;
-    if (p->data_t == GO_DATA_DNA) {
+    if (p->data_t == GO_DATA_DNA_FWD) {
+        /* bindash.rs:346-354 (k <= 14): `kmer.get_compressed_value() & mask` - the window as read, no reverse complement */
+        uint64_t mask = (k == 32) ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1);
+        uint64_t fwd = 0;
+        for (uint64_t i = 0; i < len; i++) {
+            fwd = ((fwd << 2) | (uint64_t)dna_at(seq, start + i)) & mask;
+            if (i + 1 >= k) f(ctx, fwd);
+        }
+    } else if (p->data_t == GO_DATA_DNA) {
         uint64_t mask = (k == 32) ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1);
         uint64_t fwd = 0, rc = 0;
         for (uint64_t i = 0; i < len; i++) {

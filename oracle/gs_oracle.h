@@ -22,7 +22,7 @@ extern "C" {
 
 /* SketchAlgo / DataType as in kmerutils::sketcharg (used at src/bin/gsearch.rs:181-196,258-263) */
 enum { GO_ALGO_PROB3A = 0, GO_ALGO_SUPER = 1, GO_ALGO_SUPER2 = 2, GO_ALGO_HLL = 3, GO_ALGO_OPTDENS = 4, GO_ALGO_REVOPTDENS = 5 };
-enum { GO_DATA_DNA = 0, GO_DATA_AA = 1 };
+enum { GO_DATA_DNA = 0, GO_DATA_AA = 1, GO_DATA_DNA_FWD = 2 /* forward window, no reverse-complement minimum: bindash.rs:346-354 */ };
 enum { GO_KIND_U16 = 0, GO_KIND_U32 = 1, GO_KIND_U64 = 2, GO_KIND_F32 = 3 };
 
 typedef struct { uint32_t k, sketch_size, algo, data_t; } go_params;

@@ -14,7 +14,7 @@ _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _SO = os.path.join(_ORACLE_DIR, "libgs_oracle.so")
 
 ALGO = {"prob": 0, "super": 1, "super2": 2, "hll": 3, "optdens": 4, "revoptdens": 5}
-DATA = {"dna": 0, "aa": 1}
+DATA = {"dna": 0, "aa": 1, "dna_fwd": 2}
 KIND_U16, KIND_U32, KIND_U64, KIND_F32 = 0, 1, 2, 3
 KIND_DTYPE = {KIND_U16: np.uint16, KIND_U32: np.uint32, KIND_U64: np.uint64, KIND_F32: np.float32}
 

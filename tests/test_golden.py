@@ -11,6 +11,7 @@ G_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gol
 
 
 G2_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2_hll.npz")
+G3_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v3_fwd.npz")
 
 
 def _load():
@@ -29,7 +30,15 @@ def _load():
     for key in z2.files:
         _, data, k, m, algo = key.split("_")
         cases.append((data, int(k[1:]), int(m[1:]), algo, z2[key]))
+    z3 = np.load(G3_PATH)                       # forward-only k-mers (bindash.rs:346-354) of the same DNA genomes (make_golden_fwd.py)
+    genomes["dnafwd"] = genomes["dna"]
+    for key in z3.files:
+        _, data, k, m, algo = key.split("_")
+        cases.append((data, int(k[1:]), int(m[1:]), algo, z3[key]))
     return z, genomes, cases
+
+
+DATA_OF = {"dna": "dna", "aa": "aa", "dnafwd": "dna_fwd"}
 
 
 def _bits(a):
@@ -38,12 +47,12 @@ def _bits(a):
 
 def test_oracle_reproduces_golden_sketches():
     z, genomes, cases = _load()
-    assert len(cases) == 36 + 8
+    assert len(cases) == 36 + 8 + 8
     for data, k, m, algo, want in cases:
         recs = [r for g in genomes[data] for r in g]
         goff = np.cumsum([0] + [len(g) for g in genomes[data]]).astype(np.uint64)
-        seq, rs, rl = O.pack_dna(recs) if data == "dna" else O.filter_aa(recs)
-        got = O.sketch_batch(O.params(k, m, algo, data), seq, rs, rl, goff)
+        seq, rs, rl = O.pack_dna(recs) if data != "aa" else O.filter_aa(recs)
+        got = O.sketch_batch(O.params(k, m, algo, DATA_OF[data]), seq, rs, rl, goff)
         assert got.dtype == want.dtype and np.array_equal(_bits(got), _bits(want)), (data, k, m, algo)
 
 
@@ -65,7 +74,7 @@ def test_gpu_reproduces_golden_sketches(gpu_ctx):
     import gsearch_amd as G
     z, genomes, cases = _load()
     for data, k, m, algo, want in cases:
-        got = G.sketcher_for(G.SeqSketcherParams(k, m, algo, data)).sketch_genomes(genomes[data])
+        got = G.sketcher_for(G.SeqSketcherParams(k, m, algo, DATA_OF[data])).sketch_genomes(genomes[data])
         assert got.dtype == want.dtype and np.array_equal(_bits(got), _bits(want)), (data, k, m, algo)
 
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def _oracle_sketch(k, m, algo, genomes, data="dna"):
     recs = [r for g in genomes for r in g]
     goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
-    if data == "dna":
+    if data != "aa":
         seq, rs, rl = O.pack_dna(recs)
     else:
         seq, rs, rl = O.filter_aa(recs)
@@ -40,6 +40,51 @@ def test_sketch_dna_matches_oracle(gpu_ctx, k, m, algo):
     ref = _oracle_sketch(k, m, algo, genomes)
     assert got.dtype == ref.dtype
     assert np.array_equal(_bits(got), _bits(ref))
+
+
+@pytest.mark.parametrize("k,m,algo", [(12, 512, "optdens"), (14, 2000, "optdens"), (12, 700, "revoptdens"), (14, 1024, "revoptdens"), (21, 1000, "optdens"),
+                                      (12, 300, "super2"), (14, 600, "super"), (12, 400, "prob"), (14, 512, "hll")])
+def test_sketch_forward_only_kmers_match_oracle(gpu_ctx, k, m, algo):
+    """a15: bindash-rs hashes the window as read for k <= 14 (bindash.rs:346-354) - GS_DATA_DNA_FWD. Both closures on the same genomes: each equals
+    its oracle, the two differ, and the forward-only sketch of the reverse strand differs from the forward strand's (the canonical one does not).
+    Genomes long enough for the filtered emitter (optdens) and with record boundaries / N runs / short records for the bounds-tested words."""
+    import gsearch_amd as G
+    rng = np.random.default_rng(k * 100 + m)
+    big = H.dna_ascii(H.rand_dna(rng, 260_000))
+    fam = H.family(rng, 40000, [0.001, 0.02])
+    genomes = [[H.dna_ascii(g)] for g in fam] + [[big], [H.revcomp_ascii(big)]]
+    g0 = H.dna_ascii(fam[0])
+    genomes.append([g0[:7000] + b"NNNNnnnn" + g0[7000:9000].lower(), b"ACGT", b"", g0[9000:9031], g0[20000:35003]])
+    genomes.append([b"ACGTN"])
+    out = {}
+    for data in ("dna_fwd", "dna"):
+        sk = G.sketcher_for(G.SeqSketcherParams(k, m, algo, data))
+        got = sk.sketch_genomes(genomes)
+        ref = _oracle_sketch(k, m, algo, genomes, data)
+        assert got.dtype == ref.dtype and np.array_equal(_bits(got), _bits(ref)), data
+        out[data] = got
+    nb = len(fam)
+    assert not np.array_equal(_bits(out["dna_fwd"][nb]), _bits(out["dna_fwd"][nb + 1]))      # strand specific
+    assert np.array_equal(_bits(out["dna"][nb]), _bits(out["dna"][nb + 1]))                  # strand invariant
+    assert not np.array_equal(_bits(out["dna_fwd"][nb]), _bits(out["dna"][nb]))
+
+
+def test_bindash_closure_by_kmer_size(gpu_ctx):
+    """bindash_sketch_params picks the closure bindash.rs:340-400 picks: k <= 14 forward only, k = 16 / 17..32 canonical; dens 0 / 1 = OptDens / RevOptDens"""
+    import gsearch_amd as G
+    assert G.bindash_sketch_params(12, 1000).c.data_t == 2 and G.bindash_sketch_params(14, 1000, 1).c.data_t == 2
+    assert G.bindash_sketch_params(16, 1000).c.data_t == 0 and G.bindash_sketch_params(21, 1000).c.data_t == 0
+    assert G.bindash_sketch_params(12, 1000, 1).c.algo == 5 and G.bindash_sketch_params(12, 1000, 0).c.algo == 4
+    with pytest.raises(ValueError):
+        G.bindash_sketch_params(12, 1000, 2)
+    rng = np.random.default_rng(1)
+    a = H.rand_dna(rng, 30000)
+    genomes = [[H.dna_ascii(a)], [H.dna_ascii(H.mutate(rng, a, 0.02))]]
+    p = G.bindash_sketch_params(12, 2000)
+    sig = G.sketcher_for(p).sketch_genomes(genomes)
+    assert np.array_equal(_bits(sig), _bits(_oracle_sketch(12, 2000, "optdens", genomes, "dna_fwd")))
+    d = G.DistHamming().eval_qxc(sig[:1], sig)
+    assert d[0, 0] == 0.0 and 0.0 < G.bindash_distance(d[0, 1], 12) < 1.0
 
 
 @pytest.mark.parametrize("algo,m", [("optdens", 2000), ("revoptdens", 1500), ("super", 2000), ("super2", 1200)])

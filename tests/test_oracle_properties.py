@@ -81,7 +81,7 @@ def test_parameter_dispatch_follows_reference_tables():
 def _sketch(algo, k, m, genomes, data="dna"):
     recs = [r for g in genomes for r in g]
     goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
-    seq, rs, rl = (O.pack_dna(recs) if data == "dna" else O.filter_aa(recs))
+    seq, rs, rl = (O.pack_dna(recs) if data != "aa" else O.filter_aa(recs))
     return O.sketch_batch(O.params(k, m, algo, data), seq, rs, rl, goff)
 
 
@@ -97,6 +97,36 @@ def test_identical_and_reverse_complement_invariance(algo):
     assert np.array_equal(S[3], S[4])
     if algo != "prob":                                # prob is multiset sensitive, the others are set sketches
         assert np.array_equal(S[0], S[3])
+
+
+@pytest.mark.parametrize("k", [12, 14, 16, 21])
+def test_forward_only_kmers_are_the_windows_as_read(k):
+    """GS_DATA_DNA_FWD = the k <= 14 closure of bindash.rs:346-354 (`kmer.get_compressed_value() & mask`): the value is the 2-bit window itself
+    (pure-Python restatement, SPEC 1.2), the canonical value is min(window, reverse complement of the window)."""
+    rng = np.random.default_rng(k)
+    g = H.dna_ascii(H.rand_dna(rng, 3000))
+    seq, rs, rl = O.pack_dna([g])
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    c = [code[b] for b in g]
+    fwd = [sum(c[i + j] << (2 * (k - 1 - j)) for j in range(k)) for i in range(len(c) - k + 1)]
+    rcv = [sum((3 - c[i + k - 1 - j]) << (2 * (k - 1 - j)) for j in range(k)) for i in range(len(c) - k + 1)]
+    assert O.kmers(O.params(k, 64, "optdens", "dna_fwd"), seq, rs[0], rl[0]).tolist() == fwd
+    assert O.kmers(O.params(k, 64, "optdens", "dna"), seq, rs[0], rl[0]).tolist() == [min(a, b) for a, b in zip(fwd, rcv)]
+
+
+@pytest.mark.parametrize("algo", SET_ALGOS)
+def test_forward_only_sketch_is_strand_specific(algo):
+    """the non-canonical closure must NOT be strand invariant (a sketcher that canonicalised anyway would pass every other property), must still
+    ignore record order, and must differ from the canonical sketch of the same genome"""
+    rng = np.random.default_rng(5)
+    g = H.dna_ascii(H.rand_dna(rng, 20000))
+    genomes = [[g], [H.revcomp_ascii(g)], [g[:9000], g[9000 - 11:]], [g[9000 - 11:], g[:9000]]]
+    F = _sketch(algo, 12, 512, genomes, "dna_fwd")
+    Cn = _sketch(algo, 12, 512, genomes[:1], "dna")
+    assert not np.array_equal(F[0], F[1])
+    assert np.array_equal(F[2], F[3]) and np.array_equal(F[0], F[2])
+    assert not np.array_equal(F[0], Cn[0])
+    assert F.dtype == Cn.dtype                        # same (k -> Kmer::Val, Sig) table as canonical DNA
 
 
 @pytest.mark.parametrize("algo", ALGOS)
