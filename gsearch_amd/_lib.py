@@ -68,6 +68,7 @@ SYMBOLS = {
     "gs_host_free": (None, [_vp]),
     "gs_list_fasta_files": (_i, [C.c_char_p, _i, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "gs_sketch_files": (_i, [_vp, _PP, C.POINTER(C.c_char_p), _u64, _i, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "gs_sketch_files_ex": (_i, [_vp, _PP, C.POINTER(C.c_char_p), _u64, _i, _u32, _u32, _vp, _vp, _vp, _vp, _u32]),
     "gs_gunzip_batch": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "gs_pack_dna": (_u64, [_vp, _u64, _vp, _u64]),
     "gs_filter_aa": (_u64, [_vp, _u64, _vp]),

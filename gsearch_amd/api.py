@@ -266,7 +266,7 @@ class _SeqSketcher:
         arr = (C.c_char_p * max(n, 1))(*paths)
         out = np.zeros((n, self.params.c.sketch_size), dtype=self.sig_dtype())
         nrec, nsym, st = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(6, np.float64)
-        check(self.ctx.L.gs_sketch_files(self.ctx.h, C.byref(self.params.c), arr, n, int(bool(block)), int(pio), int(threads), _p(out), _p(nrec), _p(nsym), _p(st)))
+        check(self.ctx.L.gs_sketch_files_ex(self.ctx.h, C.byref(self.params.c), arr, n, int(bool(block)), int(pio), int(threads), _p(out), _p(nrec), _p(nsym), _p(st), len(st)))
         return out, nrec[:n], nsym[:n], {"host_read_decode_scan_s": st[0], "pcie_wait_s": st[1], "device_s": st[2], "wall_s": st[3],
                                          "gz_members_inflated_on_device": int(st[4]), "gz_members_handed_back_to_host": int(st[5])}
 

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "gs_internal.hpp"
 #include "gs_spec.hpp"
 
@@ -19,24 +20,107 @@ void set_error(const char *fmt, ...)
 }  // namespace gs
 
 namespace gs {
+// ---- worker contexts: life cycle ---------------------------------------------------------------------------------------------
+// A worker belongs to (parent context, host thread). It is given back (a) when its thread exits - a thread_local registry whose destructor
+// runs at thread exit, checked against the set of live parents so that a parent destroyed first is not touched -, (b) when the table is full:
+// the least recently used idle worker is evicted for the newcomer (a thread pool that keeps respawning therefore recycles 64 workers instead
+// of leaking them and then silently sharing the parent), and (c) its scratch whenever a worker's call fails on the device: on_worker_failed()
+// releases the pools of every idle worker and the caller repeats the call on the parent, where it queues as all calls did before round 4.
+static std::mutex &reg_mu() { static std::mutex *m = new std::mutex(); return *m; }                      // leaked on purpose: used from thread-exit destructors
+static std::vector<gs_ctx *> &live_parents() { static std::vector<gs_ctx *> *v = new std::vector<gs_ctx *>(); return *v; }
+static void destroy_worker(gs_ctx *w) { gs_ctx_destroy(w); }        // (parent stays set: gs_ctx_destroy then leaves the registry alone - its lock may be held here)
+struct ThreadWorkers {
+    std::vector<gs_ctx *> parents;
+    ~ThreadWorkers()
+    {
+        const std::thread::id me = std::this_thread::get_id();
+        std::lock_guard<std::mutex> rk(reg_mu());
+        for (gs_ctx *c : parents) {
+            bool live = false;
+            for (gs_ctx *x : live_parents()) live |= (x == c);
+            if (!live) continue;
+            gs_ctx *w = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(c->workers_mu);
+                auto it = c->workers.find(me);
+                if (it != c->workers.end()) { w = it->second; c->workers.erase(it); }
+            }
+            if (w) { std::lock_guard<std::recursive_mutex> wl(w->mu); }      // (nobody else can hold it: only this thread used it; taken for the memory order)
+            if (w) destroy_worker(w);
+        }
+    }
+};
+static thread_local ThreadWorkers t_workers;
+void register_parent(gs_ctx *c) { std::lock_guard<std::mutex> rk(reg_mu()); live_parents().push_back(c); }
+void unregister_parent(gs_ctx *c)
+{
+    std::lock_guard<std::mutex> rk(reg_mu());
+    auto &v = live_parents();
+    for (size_t i = 0; i < v.size(); i++) if (v[i] == c) { v[i] = v.back(); v.pop_back(); break; }
+}
 gs_ctx *worker_ctx(gs_ctx *c)
 {
     if (!c || c->parent) return c;
     static const bool off = getenv("GS_THREAD_CONTEXTS") && !atoi(getenv("GS_THREAD_CONTEXTS"));
     if (off) return c;
+    static const size_t cap = getenv("GS_THREAD_CONTEXTS_MAX") ? (size_t)std::max(1, atoi(getenv("GS_THREAD_CONTEXTS_MAX"))) : 64;
     const std::thread::id me = std::this_thread::get_id();
-    std::lock_guard<std::mutex> lk(c->workers_mu);
-    if (c->owner_thread == std::thread::id{}) c->owner_thread = me;
-    if (c->owner_thread == me) return c;
-    auto it = c->workers.find(me);
-    if (it != c->workers.end()) return it->second;
-    if (c->workers.size() >= 64) return c;                          // (a thread pool that keeps respawning: stop growing, share the main context)
+    gs_ctx *evicted = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->workers_mu);
+        if (c->owner_thread == std::thread::id{}) c->owner_thread = me;
+        if (c->owner_thread == me) return c;
+        auto it = c->workers.find(me);
+        if (it != c->workers.end()) { it->second->last_use = ++c->use_tick; return it->second; }
+        if (c->workers.size() >= cap) {
+            // full: evict the least recently used worker nobody is inside of (try_lock), else share the main context for this call
+            auto victim = c->workers.end();
+            for (auto jt = c->workers.begin(); jt != c->workers.end(); ++jt)
+                if (victim == c->workers.end() || jt->second->last_use < victim->second->last_use) victim = jt;
+            if (victim == c->workers.end() || !victim->second->mu.try_lock()) return c;
+            evicted = victim->second;
+            c->workers.erase(victim);
+            evicted->mu.unlock();
+        }
+    }
+    if (evicted) destroy_worker(evicted);
     gs_ctx *w = nullptr;
     if (gs_ctx_create(&w, c->device, nullptr) != GS_OK) return c;
+    unregister_parent(w);                                          // a worker is not a parent
     w->parent = c;
     w->last_sketch[0] = 0;
-    c->workers[me] = w;
+    w->profile = c->profile;
+    {
+        std::lock_guard<std::mutex> lk(c->workers_mu);
+        w->last_use = ++c->use_tick;
+        c->workers[me] = w;
+    }
+    bool known = false;
+    for (gs_ctx *x : t_workers.parents) known |= (x == c);
+    if (!known) t_workers.parents.push_back(c);
     return w;
+}
+// after a call on worker w of parent c: what gs_ctx_last_sketch_info(parent) reports is the last sketch call of ANY thread
+void worker_done(gs_ctx *c, gs_ctx *w)
+{
+    if (!c || !w || w == c) return;
+    std::lock_guard<std::mutex> lk(c->workers_mu);
+    for (int i = 0; i < 4; i++) c->last_sketch[i] = w->last_sketch[i];
+}
+// a call on a worker failed on the device (typically: its scratch did not fit beside the other workers' pools): give every idle worker's pool back
+void on_worker_failed(gs_ctx *c)
+{
+    (void)hipGetLastError();
+    std::vector<gs_ctx *> ws;
+    { std::lock_guard<std::mutex> lk(c->workers_mu); for (auto &w : c->workers) ws.push_back(w.second); }
+    for (gs_ctx *w : ws) {
+        if (!w->mu.try_lock()) continue;
+        (void)hipSetDevice(w->device);
+        (void)hipStreamSynchronize(w->stream);
+        delete (ScratchPool *)w->scratch_pool; w->scratch_pool = nullptr;
+        w->mu.unlock();
+    }
+    (void)hipGetLastError();
 }
 }  // namespace gs
 
@@ -64,12 +148,14 @@ int gs_ctx_create(gs_ctx **out, int device_id, void *stream)
     else { GS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     GS_HIP_CHECK(hipEventCreate(&c->t0));
     GS_HIP_CHECK(hipEventCreate(&c->t1));
+    gs::register_parent(c);
     *out = c;
     return GS_OK;
 }
 void gs_ctx_destroy(gs_ctx *c)
 {
     if (!c) return;
+    if (!c->parent) gs::unregister_parent(c);          // from here on no exiting thread touches this context's worker table
     if (c->child) { gs_ctx_destroy(c->child); c->child = nullptr; }
     for (auto &w : c->workers) gs_ctx_destroy(w.second);
     c->workers.clear();
@@ -121,6 +207,7 @@ int gs_ctx_last_sketch_info(gs_ctx *c, uint32_t out[4])
 {
     GS_REQUIRE(c && out, GS_ERR_INVALID, "gs_ctx_last_sketch_info: null argument");
     GS_CTX_LOCK(c);
+    std::lock_guard<std::mutex> lk(c->workers_mu);                 // worker threads publish their last call here (gs::worker_done)
     for (int i = 0; i < 4; i++) out[i] = c->last_sketch[i];
     return GS_OK;
 }
@@ -143,6 +230,8 @@ int gs_ctx_profile(gs_ctx *c, int enable)
 {
     GS_REQUIRE(c, GS_ERR_INVALID, "null context");
     c->profile = enable != 0;
+    std::lock_guard<std::mutex> lk(c->workers_mu);
+    for (auto &w : c->workers) w.second->profile = c->profile;      // kernels of worker threads are counted too (gs_ctx_profile_read merges them)
     return GS_OK;
 }
 int gs_ctx_profile_read(gs_ctx *c, int family, double *total_ms, uint64_t *launches, int reset)
@@ -159,9 +248,20 @@ int gs_ctx_profile_read(gs_ctx *c, int family, double *total_ms, uint64_t *launc
         (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
     }
     s.pending.clear();
-    if (total_ms) *total_ms = s.total_ms;
-    if (launches) *launches = s.launches;
+    double tot = s.total_ms; uint64_t nl = s.launches;
     if (reset) { s.total_ms = 0; s.launches = 0; }
+    if (!c->parent) {                                               // the launches of this context's worker threads belong to the same totals
+        std::vector<gs_ctx *> ws;
+        { std::lock_guard<std::mutex> lk(c->workers_mu); for (auto &w : c->workers) ws.push_back(w.second); }
+        for (gs_ctx *w : ws) {
+            double t = 0; uint64_t n = 0;
+            const int rc = gs_ctx_profile_read(w, family, &t, &n, reset);
+            if (rc) return rc;
+            tot += t; nl += n;
+        }
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = nl;
     return GS_OK;
 }
 

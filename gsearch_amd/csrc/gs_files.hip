@@ -935,8 +935,8 @@ static int sketch_files_impl(gs_ctx *c, const gs_sketch_params *p, const char *c
     return GS_OK;
 }
 
-int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
-                    void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out)
+static int sketch_files_all(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
+                            void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out /* 6 doubles or NULL */)
 {
     GS_REQUIRE(c && (n_files == 0 || paths), GS_ERR_INVALID, "null argument");
     GS_CTX_LOCK(c);
@@ -1001,6 +1001,21 @@ int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *pat
         stats_out[5] = (double)redo.size();                // members it handed back to the host decoders (multi-member, trailer / CRC mismatch, no room)
     }
     return GS_OK;
+}
+// the round-1 contract: FOUR doubles (the array grew to six under the same symbol - a caller that passes double[4] was written out of bounds)
+int gs_sketch_files(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
+                    void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out)
+{
+    return gs_sketch_files_ex(c, p, paths, n_files, block_mode, pio, n_threads, sig_out, n_records_out, n_symbols_out, stats_out, stats_out ? 4 : 0);
+}
+int gs_sketch_files_ex(gs_ctx *c, const gs_sketch_params *p, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio, uint32_t n_threads,
+                       void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out, uint32_t stats_cap)
+{
+    GS_REQUIRE(stats_out || stats_cap == 0, GS_ERR_INVALID, "gs_sketch_files_ex: stats_cap without stats_out");
+    double st[GS_SKETCH_FILES_STATS] = {0, 0, 0, 0, 0, 0};
+    const int rc = sketch_files_all(c, p, paths, n_files, block_mode, pio, n_threads, sig_out, n_records_out, n_symbols_out, st);
+    for (uint32_t i = 0; i < stats_cap && i < (uint32_t)GS_SKETCH_FILES_STATS; i++) stats_out[i] = st[i];
+    return rc;
 }
 
 }  // extern "C"

@@ -330,7 +330,7 @@ int gs_hamming_qxc(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, 
     GS_REQUIRE(c && m > 0, GS_ERR_INVALID, "bad argument");
     if (nq == 0 || nc == 0) return GS_OK;
     GS_REQUIRE(Q && C && out, GS_ERR_INVALID, "null argument");
-    c = gs::worker_ctx(c);
+    return gs::on_worker(c, [&](gs_ctx *c) -> int {
     GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const size_t row = gs::kind_bytes(kind) * (size_t)m;
@@ -345,6 +345,7 @@ int gs_hamming_qxc(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t nq, 
     GS_HIP_CHECK(hipMemcpyAsync(out, dout.p, 4 * nq * nc, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GS_OK;
+    });
 }
 
 int gs_hamming_pairs(gs_ctx *c, int kind, uint32_t m, const void *A, uint64_t na, const void *B, uint64_t nb, const uint64_t *ia,
@@ -355,7 +356,7 @@ int gs_hamming_pairs(gs_ctx *c, int kind, uint32_t m, const void *A, uint64_t na
     if (npairs == 0) return GS_OK;
     GS_REQUIRE(A && B && ia && ib && out, GS_ERR_INVALID, "null argument");
     for (uint64_t p = 0; p < npairs; p++) GS_REQUIRE(ia[p] < na && ib[p] < nb, GS_ERR_INVALID, "pair %llu out of range", (unsigned long long)p);
-    c = gs::worker_ctx(c);
+    return gs::on_worker(c, [&, kind](gs_ctx *c) mutable -> int {
     GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     const size_t row = gs::kind_bytes(kind) * (size_t)m;
@@ -391,6 +392,7 @@ int gs_hamming_pairs(gs_ctx *c, int kind, uint32_t m, const void *A, uint64_t na
     GS_HIP_CHECK(hipMemcpyAsync(out, dout.p, 4 * npairs, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GS_OK;
+    });
 }
 
 }  // extern "C"

@@ -2270,6 +2270,13 @@ namespace gs {
 static void ids_append(gs_index *ix, const uint64_t *ids, const uint8_t *lv, uint64_t n)
 {
     const uint64_t first = ix->pid_rank.size();
+    //  ids that continue nb_point.. in order - gsearch's own case, dnasketch.rs:429-433, also when a host always goes through the `_ids`
+    // entry point - ARE the node numbers: `origin` stays empty, so searches launch no k_map_ids and gs_index_save keeps the GSAMDIX1 form
+    if (ids && ix->origin.empty()) {
+        bool identity = true;
+        for (uint64_t i = 0; i < n && identity; i++) identity = ids[i] == first + i;
+        if (identity) ids = nullptr;
+    }
     if (ids && ix->origin.empty()) { ix->origin.resize(first); for (uint64_t i = 0; i < first; i++) ix->origin[i] = i; }
     for (uint64_t i = 0; i < n; i++) {
         ix->pid_rank.push_back((int32_t)ix->level_count[lv[i] <= 16 ? lv[i] : 16]++);
@@ -2446,7 +2453,17 @@ int gs_index_sketch_and_search_dev(gs_index *ix, const gs_sketch_params *p, cons
     std::vector<hipEvent_t> ev(parts, nullptr);
     std::vector<uint8_t> waited(parts, 0);
     hipEvent_t ev_in = nullptr;
-    auto cleanup = [&]() { for (auto e : ev) if (e) (void)hipEventDestroy(e); if (ev_in) (void)hipEventDestroy(ev_in); };
+    // every exit goes through here: events destroyed, the worker's pending profile events handed to this context's accounts, its profile flag cleared
+    auto cleanup = [&]() {
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        for (int f = 0; f < gs::FAM_COUNT; f++) {
+            auto &src = w->prof[f].pending;
+            c->prof[f].pending.insert(c->prof[f].pending.end(), src.begin(), src.end());
+            src.clear();
+        }
+        w->profile = false;
+    };
 #define GS_FUSED_FAIL(code) do { const int rc_ = (code); (void)hipStreamSynchronize(w->stream); (void)hipStreamSynchronize(c->stream); ix->feed = nullptr; cleanup(); return rc_; } while (0)
     // the sketches read what the caller produced on this context's stream
     if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev_in, c->stream) != hipSuccess || hipStreamWaitEvent(w->stream, ev_in, 0) != hipSuccess) {
@@ -2469,15 +2486,7 @@ int gs_index_sketch_and_search_dev(gs_index *ix, const gs_sketch_params *p, cons
     ix->feed = nullptr;
     if (rc) GS_FUSED_FAIL(rc);
     if ((rc = gs::finish_ids(ix, ids, nq * knbn, nullptr, nullptr))) GS_FUSED_FAIL(rc);
-    GS_HIP_CHECK(hipStreamSynchronize(w->stream));
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    // the worker stream's kernel timings belong to this context's accounts
-    for (int f = 0; f < gs::FAM_COUNT; f++) {
-        auto &src = w->prof[f].pending;
-        c->prof[f].pending.insert(c->prof[f].pending.end(), src.begin(), src.end());
-        src.clear();
-    }
-    w->profile = false;
+    if (hipStreamSynchronize(w->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { gs::set_error("stream synchronisation failed after the fused request"); GS_FUSED_FAIL(GS_ERR_HIP); }
     cleanup();
 #undef GS_FUSED_FAIL
     return GS_OK;
@@ -2487,7 +2496,9 @@ int gs_index_set_ids(gs_index *ix, const uint64_t *ids, uint64_t n)
     GS_REQUIRE(ix && ids, GS_ERR_INVALID, "null argument");
     GS_REQUIRE(n == ix->n, GS_ERR_INVALID, "gs_index_set_ids: %llu ids for %llu points", (unsigned long long)n, (unsigned long long)ix->n);
     GS_CTX_LOCK(ix->ctx);
-    ix->origin.assign(ids, ids + n);
+    bool identity = true;
+    for (uint64_t i = 0; i < n && identity; i++) identity = ids[i] == i;
+    if (identity) ix->origin.clear(); else ix->origin.assign(ids, ids + n);
     ix->origin_d_n = 0;
     return GS_OK;
 }

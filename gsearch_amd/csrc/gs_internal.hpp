@@ -62,6 +62,7 @@ struct gs_ctx {
     std::thread::id owner_thread{};
     std::map<std::thread::id, gs_ctx *> workers; std::mutex workers_mu;
     gs_ctx *parent = nullptr;
+    uint64_t last_use = 0, use_tick = 0;   // LRU stamps of the worker table (under workers_mu)
     uint32_t last_sketch[4] = {0, 0, 0, 0};   // gs_ctx_last_sketch_info: {filtered emitter, slot table in LDS, workgroups per genome, launches} of the last slot-min sketch call
     // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
     // and parallel_search through &self from many threads (dnasketch.rs:252,305,322): every entry point that touches the stream or the
@@ -78,6 +79,20 @@ namespace gs {
 // the context a host-pointer call of the current thread runs on: `c` itself for the thread that used it first, a per-thread worker context otherwise
 // (GS_THREAD_CONTEXTS=0: always `c` - every call of every thread queues on the one context, as before round 4)
 gs_ctx *worker_ctx(gs_ctx *c);
+void worker_done(gs_ctx *parent, gs_ctx *worker);
+void on_worker_failed(gs_ctx *parent);
+// run a synchronous host-pointer call on the calling thread's worker context; a device failure there (a worker's scratch pool beside 63 others)
+// releases the idle workers' pools and repeats the call on the parent, where it queues as every call did before worker contexts existed
+template <class F> inline int on_worker(gs_ctx *c, F &&body)
+{
+    gs_ctx *w = worker_ctx(c);
+    int rc = body(w);
+    if (w != c) {
+        worker_done(c, w);
+        if (rc == GS_ERR_HIP) { on_worker_failed(c); rc = body(c); }
+    }
+    return rc;
+}
 
 // Wait for the context's stream WITHOUT spinning: hipStreamSynchronize busy-waits on a core, and the two pipelines of gs_sketch_files wait
 // for hundreds of milliseconds at a time (a k_inflate launch) while the host decoders want every core of the cgroup's quota.

@@ -1953,7 +1953,7 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
 }
 
 static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len,
-                   const uint64_t *rec_upre, const uint64_t *genome_rec_off, const uint64_t *gen_units, uint64_t n_genomes, uint16_t *sig_out)
+                   const uint64_t *rec_upre, const uint64_t *genome_rec_off, const uint64_t *gen_units, uint64_t n_genomes, uint64_t total_units, uint16_t *sig_out)
 {
     const uint32_t m = p->sketch_size;
     const bool aa = p->data_t == GS_DATA_AA;
@@ -1988,9 +1988,12 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     if (gtab && (rc = gt.alloc((size_t)4 * m * std::max<uint32_t>(wgs, (uint32_t)c->n_cu)))) return rc;
     // survivor lists of pass A: 2^20 hashes (8 MB) per workgroup - ~8 % of the k-mers of a 5 Mbp genome survive the running cut; a longer genome
     // overflows its list and takes the second walk as before (GS_HLL_SURVIVORS=n: lists of n hashes, 0 = always the second walk)
-    const uint32_t surv_cap = getenv("GS_HLL_SURVIVORS") ? (uint32_t)std::max(0, std::min(1 << 24, atoi(getenv("GS_HLL_SURVIVORS")))) : (1u << 20);
-    if (surv_cap && (rc = sv.alloc((size_t)8 * surv_cap * wgs))) return rc;
+    uint32_t surv_cap = getenv("GS_HLL_SURVIVORS") ? (uint32_t)std::max(0, std::min(1 << 24, atoi(getenv("GS_HLL_SURVIVORS")))) : (1u << 20);
     const uint32_t surv_minch = getenv("GS_HLL_SURVIVORS_MINCHUNKS") ? (uint32_t)std::max(4, atoi(getenv("GS_HLL_SURVIVORS_MINCHUNKS"))) : 64u;
+    //  the lists are only allocated when some genome of the batch can reach `surv_minch` chunks - no genome holds more units than the whole
+    // batch does -, and a batch whose lists do not fit takes the plain second walk instead of failing the call
+    if (total_units / ((uint64_t)HL_T * 8) < surv_minch) surv_cap = 0;
+    if (surv_cap && sv.alloc((size_t)8 * surv_cap * wgs) != GS_OK) { (void)hipGetLastError(); surv_cap = 0; }
     {
         ProfScope ps(c, FAM_SKETCH);
 #define GS_LAUNCH_HLL(AAV, GV)                                                                                                 \
@@ -2100,7 +2103,7 @@ int sketch_dev_impl(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint6
         hipLaunchKernelGGL(k_unit_prefix, dim3((uint32_t)((n_genomes + 3) / 4)), dim3(256), 0, c->stream, rec_start, rec_len,
                            genome_rec_off, n_genomes, p->k, upre.as<uint64_t>(), gunits.as<uint64_t>());
         GS_HIP_CHECK(hipGetLastError());
-        rc = run_hll(c, p, (const uint8_t *)seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), n_genomes, (uint16_t *)sig_out);
+        rc = run_hll(c, p, (const uint8_t *)seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), n_genomes, (p->data_t == GS_DATA_AA ? seq_bytes / 32 : seq_bytes / 8) + n_rec + 1, (uint16_t *)sig_out);
         if (rc) return rc;
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));
         return GS_OK;
@@ -2138,7 +2141,9 @@ int gs_sketch_batch(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint6
     for (uint64_t r = 0; r < n_rec; r++)
         GS_REQUIRE(rec_start[r] + rec_len[r] <= sym_cap, GS_ERR_INVALID, "record %llu exceeds the sequence buffer", (unsigned long long)r);
     GS_REQUIRE(genome_rec_off[n_genomes] <= n_rec, GS_ERR_INVALID, "genome_rec_off exceeds n_rec");
-    c = gs::worker_ctx(c);                 // (a worker thread of the host: its own stream and scratch, see gs_internal.hpp)
+    // (a worker thread of the host runs on its own stream and scratch, see gs_internal.hpp; a device failure there is repeated on the main context)
+    return gs::on_worker(c, [&](gs_ctx *c) -> int {
+    int rc;
     GS_CTX_LOCK(c);
     GS_HIP_CHECK(hipSetDevice(c->device));
     // staging from the context's grow-only pool: a hipMalloc / hipFree pair per call costs more than a small sketch and, worse, hipFree waits for
@@ -2163,6 +2168,7 @@ int gs_sketch_batch(gs_ctx *c, const gs_sketch_params *p, const void *seq, uint6
     GS_HIP_CHECK(hipMemcpyAsync(sig_out, dsig.p, sigbytes, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return GS_OK;
+    });
 }
 
 }  // extern "C"

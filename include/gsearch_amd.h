@@ -138,11 +138,16 @@ int  gs_list_fasta_files(const char *dir, int data_t, char *paths_buf, uint64_t 
  * n_threads host threads (0 -> the CPUs the process may use: affinity mask and cgroup quota) while the previous group crosses PCIe from pinned memory on a copy stream and the one before is
  * filtered / 2-bit packed / sketched on the context's stream. block_mode 0: k-mers never span records (process_file_by_sequence,
  * dnafiles.rs:43-107); 1: --block, records concatenated (process_file_in_one_block, dnafiles.rs:200-262); `capsid` records skipped.
- * sig_out: HOST n_files x sketch_size. Optional per-file n_records_out / n_symbols_out (HOST) and stats_out[6] = {host read+decode+scan
- * seconds summed over threads, seconds waited for PCIe, seconds in device pack + sketch, wall seconds, .gz members inflated by the device
- * kernel, members the device path handed back to the host decoders (multi-member files, a trailer / CRC-32 that does not check, no room)}. */
+ * sig_out: HOST n_files x sketch_size. Optional per-file n_records_out / n_symbols_out (HOST) and stats_out[4] = {host read+decode+scan
+ * seconds summed over threads, seconds waited for PCIe, seconds in device pack + sketch, wall seconds}. */
 int  gs_sketch_files(gs_ctx *, const gs_sketch_params *, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio,
                      uint32_t n_threads, void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out);
+/* the same call with a SIZED statistics array: the first min(stats_cap, GS_SKETCH_FILES_STATS) entries of {the four above, .gz members inflated by
+ * the device kernel, members the device path handed back to the host decoders (multi-member files, a trailer / CRC-32 that does not check, no room)}
+ * are written - a later library may know more entries, a caller never receives more than it made room for. */
+enum { GS_SKETCH_FILES_STATS = 6 };
+int  gs_sketch_files_ex(gs_ctx *, const gs_sketch_params *, const char *const *paths, uint64_t n_files, int block_mode, uint32_t pio,
+                        uint32_t n_threads, void *sig_out, uint64_t *n_records_out, uint64_t *n_symbols_out, double *stats_out, uint32_t stats_cap);
 /* gzip members inflated ON the device (gs_inflate.hip; the .gz path of gs_sketch_files, exposed for parity tests against zlib - the
  * reference reads .gz through needletail's flate2 reader, files.rs:258-341). in[i]/in_len[i]: HOST bytes of one single-member gzip file;
  * out[i]/out_cap[i]: HOST buffers for the text; out_len[i]: bytes produced; status[i]: 0 = ok (deflate data, ISIZE and CRC-32 all
@@ -200,8 +205,10 @@ int      gs_index_parallel_insert_ids(gs_index *, const void *sigs, const uint64
 int      gs_index_parallel_insert_ids_dev(gs_index *, const void *sigs_dev, const uint64_t *ids, uint64_t n);
 int      gs_index_set_ids(gs_index *, const uint64_t *ids, uint64_t n /* == nb_point */);
 int      gs_index_get_ids(gs_index *, uint64_t first, uint64_t n, uint64_t *ids_out);
-/* parallel_search(&[Vec<Sig>], knbn, ef) -> per query min(knbn, found) Neighbour{d_id, distance},
- * ascending by (distance, d_id). Unused tail slots: id = UINT64_MAX, distance = +inf.
+/* parallel_search(&[Vec<Sig>], knbn, ef) -> per query min(knbn, found) Neighbour{d_id, distance}, ascending by (distance, node number): the
+ * node number is the insertion order, which IS d_id unless the caller gave its own ids (gs_index_parallel_insert_ids / gs_index_set_ids) - ties
+ * are then still broken by insertion order, not by the caller's id - or the index came from gs_index_load_hnswrs of a dump with ids other than
+ * 0..n-1, whose nodes are renumbered in data-file order (layer-major). Unused tail slots: id = UINT64_MAX, distance = +inf.
  * evals_out (optional): number of DistHamming evaluations spent per query. */
 int      gs_index_parallel_search(gs_index *, const void *queries, uint64_t nq, uint32_t knbn, uint32_t ef,
                                   uint64_t *ids_out, float *dist_out, uint32_t *count_out, uint64_t *evals_out);
