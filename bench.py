@@ -380,7 +380,24 @@ def run_request(args, D):
     q_first = 1_000_000_000 + D.rank * nq_rank
     chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, q_first, nq_rank, L, n_roots, mu_lo, mu_hi, d_qseq))
     d_qsig = ctx.alloc(qps * m * 4)
-    ex = S.TopkExchange(qps, knbn, D.world if D.on else 1, D.device)       # ids + distances in one send buffer -> ONE all-gather per step
+    # the exchange: ONE all-gather of the per-rank top-k blocks per step, through the LIBRARY's communicator (gs_comm_*: its own RCCL communicator, pack kernel ->
+    # ncclAllGather -> unpack kernel on the context's stream; torch only ships the 128-byte unique id at set-up) - the path a Rust host would call. Should that
+    # communicator not come up on this node, the torch collective takes over and the line says so (`multi_gpu_check.collective`).
+    ex, ex_kind = None, "none (single rank)"
+    if D.on and D.backend == "nccl" and not os.environ.get("GS_BENCH_TORCH_EXCHANGE"):
+        try:
+            ex = S.LibExchange(ctx, qps, qps, knbn, D.world, D.rank, D.device)
+            ex_kind = "gs_comm_allgatherv_topk_dev: one ncclAllGather of the packed top-k blocks per step (the library's RCCL communicator)"
+        except Exception as e:                                 # noqa: BLE001 - any failure here must not cost the scaling run
+            print("# rank %d: gs_comm set-up failed (%s): torch.distributed all_gather instead" % (D.rank, e), file=sys.stderr, flush=True)
+            ex = None
+    lib_ok = D.sum_i64(1 if isinstance(ex, S.LibExchange) else 0) if D.on else 0
+    if D.on and lib_ok != D.world:                             # all ranks or none
+        ex = None
+    if ex is None:
+        ex = S.TopkExchange(qps, knbn, D.world if D.on else 1, D.device)       # ids + distances in one send buffer -> ONE all-gather per step
+        if D.on and D.world > 1:
+            ex_kind = "one all_gather_into_tensor of the packed top-k blocks per step (torch.distributed / RCCL)"
     ids_t, dist_t = ex.ids, ex.dist
     cnt_t = torch.empty((qps,), dtype=torch.int32, device=D.device)
     ev_t = torch.zeros((qps,), dtype=torch.int64, device=D.device)
@@ -430,6 +447,7 @@ def run_request(args, D):
     sum_of_own = D.sum_i64(own_sum) & M63
     n_ok = D.sum_i64(1 if (exchange_ok and all_sum == sum_of_own) else 0)
     rank_mask = D.sum_i64(1 << D.rank)
+    ranks_seen = ex.ranks_seen() if isinstance(ex, S.LibExchange) else bin(rank_mask).count("1")     # gs_comm_size of the library's communicator
     value = D.world * qps * args.steps / dt
     out = {
         "metric": "query genomes/sec", "value": value, "unit": "genomes/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
@@ -444,8 +462,7 @@ def run_request(args, D):
                    "distinct_query_sets": max(nq_rank // qps, 1), "queries_per_db_family_per_step": qps / n_roots},
         "step_ms": [round(x, 2) for x in step_ms], "build_seconds": build_s, "build_genomes_per_sec": N / build_s, "dist_evals_per_query": evals_total / (qps * args.steps),
         "sketch_kmers_per_sec": (L - k + 1) * qps * sk_n / (sk_ms * 1e-3) if sk_ms > 0 else None,
-        "multi_gpu_check": {"rccl_ranks_seen": bin(rank_mask).count("1"), "ranks_whose_block_and_checksum_verified": n_ok, "world": D.world,
-                            "collective": "one all_gather_into_tensor of the packed top-k blocks per step (RCCL)" if (D.on and D.world > 1) else "none (single rank)"},
+        "multi_gpu_check": {"rccl_ranks_seen": ranks_seen, "ranks_whose_block_and_checksum_verified": n_ok, "world": D.world, "collective": ex_kind},
     }
     if D.rank == 0:
         out.update(request_accounting(args, ctx, hn, lib, chk, torch, D, dict(

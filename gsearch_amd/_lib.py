@@ -109,6 +109,11 @@ SYMBOLS = {
     "gs_comm_rank": (_i, [_vp]),
     "gs_comm_size": (_i, [_vp]),
     "gs_comm_allgather_topk_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
+    "gs_comm_allgatherv_topk_dev": (_i, [_vp, _vp, _vp, _u64, _u64, _u32, _vp, _vp, _vp]),
+    "gs_topk_block_bytes": (_u64, [_u64, _u32]),
+    "gs_topk_pack": (_i, [_vp, _vp, _u64, _u64, _u32, _vp]),
+    "gs_topk_unpack": (_i, [_vp, _i, _u64, _u32, _vp, _vp, _vp]),
+    "gs_topk_merge_dev": (_i, [_vp, _vp, _vp, _u32, _u64, _u32, _vp, _u32, _vp, _vp]),
     "gs_synth_dna_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _vp]),
     "gs_synth_aa_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _vp]),
     "gs_synth_dna_family_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _u64, C.c_double, C.c_double, _vp]),

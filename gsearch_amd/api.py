@@ -134,6 +134,15 @@ class Comm:
     def allgather_topk_dev(self, ids_dev, dist_dev, nq_local, knbn, all_ids_dev, all_dist_dev):
         check(self.L.gs_comm_allgather_topk_dev(self.h, ids_dev, dist_dev, nq_local, knbn, all_ids_dev, all_dist_dev))
 
+    def allgatherv_topk_dev(self, ids_dev, dist_dev, nq_local, nq_max, knbn, all_ids_dev, all_dist_dev):
+        """unequal shards: this rank's nq_local (<= nq_max, may be 0) rows -> compact concatenation in rank order; returns every rank's count"""
+        counts = np.zeros(self.n_ranks, dtype=np.uint64)
+        check(self.L.gs_comm_allgatherv_topk_dev(self.h, ids_dev, dist_dev, int(nq_local), int(nq_max), int(knbn), all_ids_dev, all_dist_dev, _p(counts)))
+        return counts
+
+    def size(self):
+        return int(self.L.gs_comm_size(self.h))
+
     def close(self):
         if getattr(self, "h", None):
             self.L.gs_comm_destroy(self.h)
@@ -145,6 +154,36 @@ class Comm:
                 self.close()
         except Exception:
             pass
+
+
+def topk_block_bytes(nq_max, knbn):
+    return int(_lib.load().gs_topk_block_bytes(int(nq_max), int(knbn)))
+
+
+def topk_pack(ids, dist, nq_max):
+    """host form of the exchange's block layout (gs_topk_pack): (nq_local, knbn) ids / distances -> one fixed-size block (uint8 array)"""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64); dist = np.ascontiguousarray(dist, dtype=np.float32)
+    nq, knbn = ids.shape
+    out = np.zeros(topk_block_bytes(nq_max, knbn), dtype=np.uint8)
+    check(_lib.load().gs_topk_pack(_p(ids) if nq else None, _p(dist) if nq else None, nq, int(nq_max), knbn, _p(out)))
+    return out
+
+
+def topk_unpack(blocks, n_ranks, nq_max, knbn):
+    """n_ranks blocks back to back -> (compact ids, compact distances, counts per rank), rank order (gs_topk_unpack)"""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    counts = np.zeros(n_ranks, dtype=np.uint64)
+    check(_lib.load().gs_topk_unpack(_p(blocks), int(n_ranks), int(nq_max), int(knbn), None, None, _p(counts)))
+    tot = int(counts.sum())
+    ids, dist = np.zeros((tot, knbn), np.uint64), np.zeros((tot, knbn), np.float32)
+    check(_lib.load().gs_topk_unpack(_p(blocks), int(n_ranks), int(nq_max), int(knbn), _p(ids), _p(dist), _p(counts)))
+    return ids, dist, counts
+
+
+def topk_merge_dev(ctx, ids_dev, dist_dev, n_shards, nq, knbn_in, knbn_out, out_ids_dev, out_dist_dev, id_offset=None):
+    """DB-sharded alternative: merge the answers of n_shards shards for the same nq queries on the device (gs_topk_merge_dev)"""
+    off = None if id_offset is None else np.ascontiguousarray(id_offset, dtype=np.uint64)
+    check(ctx.L.gs_topk_merge_dev(ctx.h, ids_dev, dist_dev, int(n_shards), int(nq), int(knbn_in), _p(off), int(knbn_out), out_ids_dev, out_dist_dev))
 
 
 _default_ctx = None

@@ -40,6 +40,13 @@ struct IndexDev {
     const uint8_t *levels; const uint32_t *deg0; const uint32_t *nbr0;
     const int32_t *upidx; const uint32_t *degU; const uint32_t *nbrU;
     const uint64_t *rowptr;      // pair cache: rowptr[a] -> uint16 counts of node a against every node b < a (0 = not cached)
+    // sparse pair rows (round 5; what replaces the n^2-byte cache beyond ~400 k nodes): node a keeps the (b, c(a,b)) of ITS CLOSEST older nodes -
+    // every b < a with c(a,b) <= cut(a), at most sp_L of them, ascending by b. sp_meta[a] = valid << 63 | len << 16 | cut(a); a pair that is not in
+    // the list of its younger node has a count ABOVE that node's cut - all the selection heuristic needs to know while its threshold is <= the cut.
+    // sp_bm[a] (optional, 0 = none): bitmap over b < a of "m - c(a,b) >= J0(a) - 1", the level just below the list's cut - kept for the nodes whose list
+    // is shorter than ~ef_construction, where a selection walk reaches candidates of that level (a pair that is not listed has fewer than J0 matches,
+    // so the bit says "exactly J0 - 1": all a threshold of cut + 1 asks)
+    const uint32_t *sp_ids; const uint16_t *sp_cnt; const uint64_t *sp_meta; const uint64_t *sp_bm; uint32_t sp_L;
     uint64_t n; int64_t entry; int top;
 };
 
@@ -565,9 +572,16 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__built
 // (kept as a function for readability; making it a real call - noinline - was tried: the whole kernel then pays for a stack, 124 -> 490 ms)
 
 struct Phase2IO { uint32_t nT, evals, pops; bool tm; long long c_build, c_drain; uint64_t *wl; uint32_t cap_log, nlog; };
-template <bool ONEG, bool WLOG>
+// SPLIT (round 5, indexes beyond what one workgroup's LDS can map): the visited bitmap covers node ids [0, vis_w) in LDS and [vis_w, n) in this
+// workgroup's global scratch `visg`. Here, where nothing depends on the order of the pops, a HIGH id (>= vis_w) goes to the Bloom filter FIRST: the
+// ~98 % that cannot lie below tau are dropped without touching memory at all, only the rest pays a memory-side test-and-set + the count look-up. What
+// that skips is the evaluation COUNT of the dropped ids - so after the drain the popped nodes' adjacency rows are walked once more per LDS-sized
+// range of high ids, with the range's global bits (phase 1's marks and the Bloom positives, both counted when they were set) copied into the LDS
+// bitmap: every high id that is still clear there is a distinct evaluation. ids, distances and evaluation counts stay the oracle's.
+template <bool ONEG, bool WLOG, bool SPLIT>
 __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds &S, uint32_t *vis, const uint16_t *__restrict__ matrow, uint32_t tau, uint32_t knbn,
-                                                       uint64_t *Gold, uint64_t *Gnew, uint32_t headG, uint32_t nG, uint32_t headN, uint32_t nN, uint64_t Tmax, Phase2IO &io)
+                                                       uint64_t *Gold, uint64_t *Gnew, uint32_t headG, uint32_t nG, uint32_t headN, uint32_t nN, uint64_t Tmax, Phase2IO &io,
+                                                       uint32_t vis_w, uint32_t *__restrict__ visg)
 {
     const uint32_t maxdeg = 2 * ix.M;
     constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;
@@ -624,11 +638,18 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
             if (idx >= deg) continue;
             const uint32_t id = rid[j];
             const uint32_t bit = 1u << (id & 31);
-            const uint32_t old = atomicOr(&vis[id >> 5], bit);
-            if (old & bit) continue;
-            nev++;
             const uint32_t ha = (id * 0x9E3779B1u) >> (32 - lgA), hb = (id * 0x85EBCA77u) >> (32 - lgB);
-            if (!((bfA[ha >> 5] >> (ha & 31)) & (bfB[hb >> 5] >> (hb & 31)) & 1u)) continue;      // certainly not below tau
+            if (SPLIT && id >= vis_w) {
+                if (!((bfA[ha >> 5] >> (ha & 31)) & (bfB[hb >> 5] >> (hb & 31)) & 1u)) continue;  // certainly not below tau: counted by the walk after the drain
+                const uint32_t oldg = __hip_atomic_fetch_or(&visg[(id - vis_w) >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (oldg & bit) continue;
+                nev++;
+            } else {
+                const uint32_t old = atomicOr(&vis[id >> 5], bit);
+                if (old & bit) continue;
+                nev++;
+                if (!((bfA[ha >> 5] >> (ha & 31)) & (bfB[hb >> 5] >> (hb & 31)) & 1u)) continue;      // certainly not below tau
+            }
             const uint32_t cc = matrow[id];
             if (cc >= tau) continue;
             WL[atomicAdd(&s_cnt[0], 1u)] = id;               // accepted: expanded in the next generation
@@ -665,6 +686,39 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
         head = tail;
     }
     if (io.tm) { io.c_build = pt0; io.c_drain = clock64(); }
+    if (SPLIT && vis_w < ix.n) {
+        // the evaluation count of the high ids the Bloom filter dropped: one more walk over the popped nodes' rows per range of vis_w high ids
+        const uint32_t npop = head, lw = vis_w >> 5;
+        for (uint64_t base64 = vis_w; base64 < ix.n; base64 += vis_w) {
+            const uint32_t base = (uint32_t)base64;
+            const uint32_t span = (uint32_t)(ix.n - base64 < (uint64_t)vis_w ? ix.n - base64 : (uint64_t)vis_w), sw = (span + 31) >> 5;
+            __syncthreads();
+            for (uint32_t w = threadIdx.x; w < lw; w += DT)
+                vis[w] = w < sw ? __hip_atomic_load(&visg[((base - vis_w) >> 5) + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            __syncthreads();
+            uint32_t itx = wv;
+            uint32_t rowB[NR], degB = 0, nodeA = 0;
+            if (itx < npop) fetch_row(uni32(WL[itx]), rowB, degB);
+            if (itx + WS < npop) nodeA = WL[itx + WS];
+            for (; itx < npop; itx += WS) {
+                uint32_t rowC[NR], degC = degB;
+#pragma unroll
+                for (int j = 0; j < NR; j++) rowC[j] = rowB[j];
+                const uint32_t nn = uni32(nodeA);
+                if (itx + WS < npop) fetch_row(nn, rowB, degB);
+                if (itx + 2 * WS < npop) nodeA = WL[itx + 2 * WS];
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const uint32_t idx = lane + 64 * j;
+                    if (idx >= degC) continue;
+                    const uint32_t r = rowC[j] - base;               // (ids below base wrap around: out of the span)
+                    if (r >= span) continue;
+                    const uint32_t bit = 1u << (r & 31);
+                    if (!(atomicOr(&vis[r >> 5], bit) & bit)) nev++;
+                }
+            }
+        }
+    }
     if (nev) atomicAdd(&s_cnt[2], nev);
     __syncthreads();
     // T <- knbn smallest of T u TA, in chunks the existing merge takes (sorted A of at most maxdeg keys; A's region is free again)
@@ -694,24 +748,28 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
 // WLOG (insert-time pre-pass): every accepted key is also appended to a per-workgroup log; R is always "the ef smallest
 // accepted keys", so at the end of the query the log, cut at dmax and sorted, IS the sorted result set W of search_layer - which the
 // histogram form of R never materialises. Queries flagged in `skip` are left to the caller.
-template <bool VLDS, bool PROF, int OCC, bool ONEG, bool WLOG>
+template <bool VLDS, bool PROF, int OCC, bool ONEG, bool WLOG, bool SPLIT = false>
 __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *__restrict__ mat, uint64_t mat_ld,
                                                            uint32_t *__restrict__ scratch, uint32_t scratch_words, uint64_t *__restrict__ cbuf, uint32_t capC,
                                                            unsigned long long *__restrict__ counter, uint64_t *__restrict__ ids_out, float *__restrict__ dist_out,
                                                            uint32_t *__restrict__ count_out, uint64_t *__restrict__ evals_out, unsigned long long *__restrict__ prof,
                                                            unsigned long long *__restrict__ stats, uint64_t *__restrict__ wlog, uint32_t cap_log, uint32_t sort_cap,
-                                                           uint64_t *__restrict__ w_out, uint32_t *__restrict__ w_n, const uint32_t *__restrict__ ep_in)
+                                                           uint64_t *__restrict__ w_out, uint32_t *__restrict__ w_n, const uint32_t *__restrict__ ep_in, uint32_t vis_w_arg)
 {
+    static_assert(!SPLIT || VLDS, "the split bitmap is a form of the LDS placement");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t maxdeg = 2 * ix.M;
     const uint32_t efs = ef > knbn ? ef : knbn;
-    const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = (uint32_t)((ix.n + 31) / 32);
+    // SPLIT: node ids [0, vis_w) are mapped by the LDS bitmap, [vis_w, n) by `visg`, behind this workgroup's fine histogram bins in the global scratch
+    const uint32_t vis_w = SPLIT ? vis_w_arg : 0u;
+    const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = SPLIT ? (vis_w >> 5) : (uint32_t)((ix.n + 31) / 32);
+    const uint32_t visg_words = SPLIT && ix.n > vis_w ? (uint32_t)((ix.n - vis_w + 31) / 32) : 0u;
     uint32_t st_pops = 0, st_acc = 0, st_p1 = 0, st_p2 = 0;                 // work counters (workgroup-uniform): pops / accepting pops / pops before dmax reached tau, of this workgroup (< 2^32)
     constexpr bool PHASE2 = true;       // (round 4: also with the visited bitmap in global memory - indexes beyond ~600 k nodes: test-and-set through L2 atomics)
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;         // capacity of N: >= 2M (an empty N takes a whole expansion), one key per lane in its merge
-    DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, ix.n, VLDS, CN);
+    DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, SPLIT ? (uint64_t)vis_w : ix.n, VLDS, CN);
     // adjacency row of a (wave-uniform) candidate: the node id is pinned to an SGPR so that the row base is scalar and the load takes a
     // 32-bit lane offset instead of a 64-bit per-lane pointer
 #define GS_DROWX(K, PD, PI)                                                                                                \
@@ -726,6 +784,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     // per-workgroup global scratch: the visited bitmap (VLDS = false) or the fine histogram bins (VLDS = true)
     uint32_t *vis = VLDS ? S.vis : scratch + (uint64_t)blockIdx.x * scratch_words;
     Hist3 hs; hs.Hf = VLDS ? scratch + (uint64_t)blockIdx.x * scratch_words : S.Hf; hs.H2 = S.H2; hs.H1 = S.H1;
+    uint32_t *visg = SPLIT ? scratch + (uint64_t)blockIdx.x * scratch_words + hwords : nullptr;
     uint64_t *Cb[2] = {cbuf + (uint64_t)blockIdx.x * 2 * capC, cbuf + (uint64_t)blockIdx.x * 2 * capC + capC};
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t half = ONEG ? 0u : threadIdx.x >> 8, hl = ONEG ? threadIdx.x : threadIdx.x & 255, hl4 = hl * 4;
@@ -743,6 +802,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         const uint32_t tau = PHASE2 ? dense_row_tau(matrow, ix.n, ix.m, efs, S.H1, S.hist, S.wsum) : 0u;
         const long long tm1 = tm ? clock64() : 0;
         for (uint32_t w = threadIdx.x; w < vis_words; w += DT) vis[w] = 0;
+        if (SPLIT) for (uint32_t w = threadIdx.x; w < visg_words; w += DT) visg[w] = 0;
         for (uint32_t w = threadIdx.x; w < hwords; w += DT) hs.Hf[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb * (HB / HG / 2); w += DT) S.H2[w] = 0;
         for (uint32_t w = threadIdx.x; w < nb; w += DT) S.H1[w] = 0;
@@ -781,7 +841,8 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             S.T[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
             if (WLOG) wl[0] = KEY(ep_cnt, ep);
             hist_add<VLDS>(hs, ep_cnt, 1);
-            if (VLDS) vis[ep >> 5] = 1u << (ep & 31);
+            if (SPLIT && ep >= vis_w) __hip_atomic_fetch_or(&visg[(ep - vis_w) >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (VLDS) vis[ep >> 5] = 1u << (ep & 31);
             else __hip_atomic_fetch_or(&vis[ep >> 5], 1u << (ep & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (efs == 1) { dmax = ep_cnt; tieT = 1; }
@@ -833,7 +894,8 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 if (hl < pdeg) {
                     const uint32_t bit = 1u << (id & 31);
                     uint32_t old;
-                    if (VLDS) old = atomicOr(&vis[id >> 5], bit);
+                    if (SPLIT && id >= vis_w) old = __hip_atomic_fetch_or(&visg[(id - vis_w) >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else if (VLDS) old = atomicOr(&vis[id >> 5], bit);
                     else old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     unv = !(old & bit);
                     if (unv) cntv = (pst == 2 && pclr) ? pcnt : (uint32_t)matrow[id];   // every 2-byte lookup costs a full HBM sector: only for the unvisited
@@ -846,7 +908,8 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 if (VLDS) {
                     pclr = false;
                     if (hl < pdeg) {
-                        pclr = !((vis[pid >> 5] >> (pid & 31)) & 1u);
+                        if (SPLIT && pid >= vis_w) pclr = !((__hip_atomic_load(&visg[(pid - vis_w) >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (pid & 31)) & 1u);
+                        else pclr = !((vis[pid >> 5] >> (pid & 31)) & 1u);
                         if (pclr) pcnt = matrow[pid];
                     }
                     pst = 2;
@@ -873,7 +936,11 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                     if (nk == c1) {
                         pid = nid; pdeg = ndeg; pclr = false;
                         if (VLDS) {
-                            if (hl < pdeg) { pclr = !((vis[pid >> 5] >> (pid & 31)) & 1u); if (pclr) pcnt = matrow[pid]; }
+                            if (hl < pdeg) {
+                                if (SPLIT && pid >= vis_w) pclr = !((__hip_atomic_load(&visg[(pid - vis_w) >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (pid & 31)) & 1u);
+                                else pclr = !((vis[pid >> 5] >> (pid & 31)) & 1u);
+                                if (pclr) pcnt = matrow[pid];
+                            }
                             pst = 2;
                         } else pst = 1;
                     } else { GS_DROW(c1); pst = 1; }                 // not predicted: the row only (its lookups go direct at the expansion)
@@ -1105,7 +1172,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         const long long tm2 = tm ? clock64() : 0;
         if (PHASE2 && phase2) {
             Phase2IO io{nT, evals, 0u, tm, 0, 0, wl, cap_log, nlog};
-            dense_phase2<ONEG, WLOG>(ix, S, vis, matrow, tau, knbn, Cb[cur], Cb[cur ^ 1], headG, nG, headN, nN, Tmax, io);
+            dense_phase2<ONEG, WLOG, SPLIT>(ix, S, vis, matrow, tau, knbn, Cb[cur], Cb[cur ^ 1], headG, nG, headN, nN, Tmax, io, vis_w, visg);
             nT = io.nT; evals = io.evals; st_pops += io.pops; st_p2 += io.pops; nlog = io.nlog;
             if (tm) { atomicAdd(&stats[13], (unsigned long long)(io.c_build - tm2)); atomicAdd(&stats[14], (unsigned long long)(io.c_drain - io.c_build)); }
         }
@@ -1257,9 +1324,53 @@ __device__ __forceinline__ bool select_check_rows(const IndexDev &ix, const Sear
 // cache the walk takes the candidates SEL_CH at a time: every lane that owns a kept key looks the chunk's candidates up at once (one
 // memory round trip and two barriers per chunk instead of per candidate); the chunk ends at its first accepted candidate - the ones
 // behind it have to see the new member - so the result is the sequential one.
+// ---- sparse pair rows: "is c(hi, lo) <= T ?" for up to NJ pairs per lane at once --------------------------------------------------------
+// hi / lo / T come from callables of j (their inputs live in LDS: the lane keeps only the search state in registers). The NJ binary searches
+// advance in lockstep - one dependent round trip per step for all of them (13 steps at sp_L = 4096) - with the branch-free "largest p with
+// ids[p-1] <= lo" descent: ids are distinct and ascending, so a probe that reads lo itself fixes the answer and no later probe moves past it.
+// yes: bit j = count <= T (exact count found); unk: bit j = not decidable from the list (no row, or not stored while T lies above the row's cut).
+#define SP_VALID(mt) ((uint32_t)((mt) >> 63))
+#define SP_LEN(mt) ((uint32_t)((mt) >> 16) & 0xFFFFu)
+#define SP_CUT(mt) ((uint32_t)(mt) & 0xFFFFu)
+template <int NJ, class FH, class FL, class FT>
+__device__ __forceinline__ void sparse_pairs(const IndexDev &ix, uint32_t want, const FH &fhi, const FL &flo, const FT &fT, uint32_t &yes, uint32_t &unk)
+{
+    uint32_t base[NJ], len[NJ], eq = 0, cutok = 0;
+    uint32_t top = 1; while (top < ix.sp_L) top <<= 1;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        base[j] = 0; len[j] = 0;
+        if ((want >> j) & 1u) {
+            const uint64_t mt = ix.sp_meta[fhi(j)];
+            if (!SP_VALID(mt)) { unk |= 1u << j; want &= ~(1u << j); }
+            else { len[j] = SP_LEN(mt); if (fT(j) <= SP_CUT(mt)) cutok |= 1u << j; }
+        }
+    }
+    for (uint32_t step = top; step; step >>= 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t pp = base[j] + step;
+            if (((want >> j) & 1u) && pp <= len[j]) {
+                const uint32_t v = ix.sp_ids[(uint64_t)fhi(j) * ix.sp_L + pp - 1], l = flo(j);
+                if (v <= l) { base[j] = pp; if (v == l) eq |= 1u << j; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        if (!((want >> j) & 1u)) continue;
+        if ((eq >> j) & 1u) { if ((uint32_t)ix.sp_cnt[(uint64_t)fhi(j) * ix.sp_L + base[j] - 1] <= fT(j)) yes |= 1u << j; }
+        else if (!((cutok >> j) & 1u)) {                        // not stored: its count is above the cut - decides only thresholds <= cut ...
+            const uint32_t h = fhi(j);
+            const uint32_t *bm = (fT(j) == SP_CUT(ix.sp_meta[h]) + 1 && ix.sp_bm) ? (const uint32_t *)ix.sp_bm[h] : nullptr;
+            if (!bm) unk |= 1u << j;                            // ... and, through the level bitmap, the threshold cut + 1
+            else { const uint32_t l = flo(j); if ((bm[l >> 5] >> (l & 31)) & 1u) yes |= 1u << j; }
+        }
+    }
+}
 constexpr int SEL_CH = 16;     // (8 -> 16: the walk is bound by its memory round trips per chunk, not by the sectors it fetches)
 template <int KIND>
-__device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const SearchLds &S, uint32_t nW, uint32_t deg, bool heuristic, uint64_t &evals, uint32_t na0 = 0)
+__device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const SearchLds &S, uint32_t nW, uint32_t deg, bool heuristic, uint64_t &evals, uint32_t na0 = 0, unsigned long long *st = nullptr)
 {
     if (!heuristic) {
         for (uint32_t t = threadIdx.x; t < nW; t += ST) S.A[t] = S.R[t];
@@ -1270,7 +1381,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
     uint32_t *orw = (uint32_t *)&S.scal[4];
     while (i < nW && na < deg) {
         if (na == 0) { if (threadIdx.x == 0) S.A[0] = S.R[i]; na = 1; i++; __syncthreads(); continue; }
-        if (!(ix.rowptr && na <= ST)) {                                   // no pair cache: one candidate at a time, rows streamed
+        if (!((ix.rowptr || ix.sp_meta) && na <= ST)) {                   // no pair cache: one candidate at a time, rows streamed
             const uint64_t e = S.R[i];
             const bool accept = KCNT(e) < ix.m && select_check_rows<KIND>(ix, S, e, na, evals);
             if (accept) { if (threadIdx.x == 0) S.A[na] = e; na++; __syncthreads(); }
@@ -1285,6 +1396,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
         if (threadIdx.x < na) {
             const uint32_t sid = KID(S.A[threadIdx.x]);
             const uint16_t *row[SEL_CH]; uint32_t lo[SEL_CH];
+            uint32_t miss = 0;                                            // pairs the dense rows do not hold: the sparse rows' turn
 #pragma unroll
             for (int j = 0; j < SEL_CH; j++) {
                 row[j] = nullptr; lo[j] = 0;
@@ -1292,12 +1404,22 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
                     const uint32_t eid = KID(S.R[i + j]);
                     const uint32_t hi = sid > eid ? sid : eid;
                     lo[j] = sid > eid ? eid : sid;
-                    row[j] = (const uint16_t *)ix.rowptr[hi];
-                    if (!row[j]) cm |= 1u << (16 + j);
+                    row[j] = ix.rowptr ? (const uint16_t *)ix.rowptr[hi] : nullptr;
+                    if (!row[j]) miss |= 1u << j;
                 }
             }
 #pragma unroll
             for (int j = 0; j < SEL_CH; j++) if (row[j] && (uint32_t)row[j][lo[j]] <= KCNT(S.R[i + j])) cm |= 1u << j;
+            if (miss) {
+                if (!ix.sp_meta) cm |= miss << 16;
+                else {
+                    if (st && threadIdx.x == 0) atomicAdd(&st[2], 1ull);          // chunks whose first kept key went to the sparse rows
+                    uint32_t yes = 0, unk = 0;
+                    sparse_pairs<SEL_CH>(ix, miss, [&](int j) { const uint32_t e = KID(S.R[i + j]); return sid > e ? sid : e; },
+                                         [&](int j) { const uint32_t e = KID(S.R[i + j]); return sid > e ? e : sid; }, [&](int j) { return KCNT(S.R[i + j]); }, yes, unk);
+                    cm |= yes | (unk << 16);
+                }
+            }
         } else if (threadIdx.x - na < (uint32_t)(SEL_CH * (SEL_CH - 1) / 2)) {
             static_assert(SEL_CH <= 16, "cm: 16 conflict bits + 16 not-cached bits; pair bits in orw[1..4]");
             // the pairs INSIDE the chunk (j > k): candidate j must also clear the candidates of the chunk that are kept before it.
@@ -1308,9 +1430,15 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
             if (j < nc && !((fr >> j) & 1u) && !((fr >> k) & 1u)) {
                 const uint32_t ej = KID(S.R[i + j]), ek = KID(S.R[i + k]);
                 const uint32_t hi = ej > ek ? ej : ek, lo2 = ej > ek ? ek : ej;
-                const uint16_t *row = (const uint16_t *)ix.rowptr[hi];
-                if (!row) cm |= 1u << (16 + j);
-                else if ((uint32_t)row[lo2] <= KCNT(S.R[i + j])) { pbit = j * (j - 1) / 2 + k; pm = 1; }
+                const uint16_t *row = ix.rowptr ? (const uint16_t *)ix.rowptr[hi] : nullptr;
+                if (row) { if ((uint32_t)row[lo2] <= KCNT(S.R[i + j])) { pbit = j * (j - 1) / 2 + k; pm = 1; } }
+                else if (!ix.sp_meta) cm |= 1u << (16 + j);
+                else {
+                    uint32_t yes = 0, unk = 0;
+                    sparse_pairs<1>(ix, 1u, [&](int) { return hi; }, [&](int) { return lo2; }, [&](int) { return KCNT(S.R[i + j]); }, yes, unk);
+                    if (unk) cm |= 1u << (16 + j);
+                    else if (yes) { pbit = j * (j - 1) / 2 + k; pm = 1; }
+                }
             }
         }
         if (threadIdx.x < 6) orw[threadIdx.x] = 0;
@@ -1341,6 +1469,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
         na += nacc;
         if (slow) {
             __syncthreads();
+            if (st && threadIdx.x == 0) atomicAdd(&st[1], 1ull);                  // candidates checked by streaming rows (a pair no cache decides)
             const uint64_t e = S.R[i + j];
             if (select_check_rows<KIND>(ix, S, e, na, evals)) { if (threadIdx.x == 0) S.A[na] = e; na++; }
             i += j + 1;
@@ -1359,7 +1488,7 @@ __device__ __forceinline__ uint32_t select_block(const IndexDev &ix, const Searc
 // distance 1.0 after the first kept neighbour ends the walk: every later candidate is pruned by c(e,s) <= m.
 template <int KIND>
 __device__ __forceinline__ uint32_t select_extended(const IndexDev &ix, const uint4 *__restrict__ q, const SearchLds &S, uint32_t *vis, uint32_t vis_words, uint32_t nW,
-                                                    uint32_t deg, uint32_t win, uint64_t *__restrict__ E, uint32_t capE, const uint16_t *__restrict__ matrow, uint64_t &evals)
+                                                    uint32_t deg, uint32_t win, uint64_t *__restrict__ E, uint32_t capE, const uint16_t *__restrict__ matrow, uint64_t &evals, unsigned long long *st = nullptr)
 {
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t w = threadIdx.x; w < vis_words; w += ST) vis[w] = 0;
@@ -1420,7 +1549,7 @@ __device__ __forceinline__ uint32_t select_extended(const IndexDev &ix, const ui
         for (uint32_t t = threadIdx.x; t < wn; t += ST) S.R[t] = E[pos + t];
         __syncthreads();
         if (na >= 1 && KCNT(S.R[0]) >= ix.m) break;
-        na = select_block<KIND>(ix, S, wn, deg, true, evals, na);
+        na = select_block<KIND>(ix, S, wn, deg, true, evals, na, st);
     }
     __syncthreads();
     return na;
@@ -1503,8 +1632,8 @@ __global__ __launch_bounds__(ST) void k_hnsw_plan(IndexDev ix, uint64_t b0, uint
         if (nW && ext && nW <= deg && ext_keys) {
             // R and C are one contiguous LDS region (carve_lds) and C is dead by now: the selection windows may run over both
             const uint32_t room = 3 * ef_lds + maxdeg, win = room < 512u ? room : 512u;
-            na = select_extended<KIND>(ix, q, S, vis, vis_words, nW, deg, win, ext_keys + (uint64_t)i * ext_cap, ext_cap, matrow, evals);
-        } else if (nW) na = select_block<KIND>(ix, S, nW, deg, !(nW <= deg && !ext), evals);
+            na = select_extended<KIND>(ix, q, S, vis, vis_words, nW, deg, win, ext_keys + (uint64_t)i * ext_cap, ext_cap, matrow, evals, evals_total);
+        } else if (nW) na = select_block<KIND>(ix, S, nW, deg, !(nW <= deg && !ext), evals, 0, evals_total);
         uint64_t *pk = plan_keys + ((uint64_t)i * ix.max_layer + (uint32_t)L) * maxdeg;
         for (uint32_t t = threadIdx.x; t < na; t += ST) pk[t] = S.A[t];
         if (threadIdx.x == 0) plan_n[(uint64_t)i * ix.max_layer + (uint32_t)L] = na;
@@ -1526,7 +1655,89 @@ __global__ void k_cache_rows(uint16_t *__restrict__ rowbase, uint64_t ld, uint64
     const uint32_t i = blockIdx.x;
     uint16_t *row = rowbase + (uint64_t)i * ld;
     for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) row[b0 + j] = (uint16_t)cntmat[(uint64_t)i * nb + j];
-    if (threadIdx.x == 0) rowptr[b0 + i] = (uint64_t)row;
+    if (threadIdx.x == 0 && rowptr) rowptr[b0 + i] = (uint64_t)row;          // (rowptr == nullptr: the rows are not kept - group buffer -, only the mates' columns are patched in)
+}
+
+// sparse pair row of node a = a0 + blockIdx.x from its count row (counts against every b < a; rows `ld` apart): the cut is the largest count
+// level whose nodes all fit - J0 = the smallest number of matches j with #{b < a : m - c(a,b) >= j} <= L, cut = m - J0 (cut = m: the whole row) -
+// and the list is written in ascending b (chunks in order, lanes in order, a lane's 8 counts in order: ordered compaction by prefix sums).
+// A row whose closest L nodes cannot be separated by level (more than L nodes with >= 63 matches) gets no list (meta 0: the selection streams rows).
+constexpr int SPF_T = 256;
+struct SpArena { unsigned long long base, off, size, stored, noroom; };      // bump allocator of the level bitmaps (device side: the kernel knows who needs one)
+__global__ __launch_bounds__(SPF_T) void k_sparse_fill(const uint16_t *__restrict__ rowbase, uint64_t ld, uint64_t a0, uint32_t m, uint32_t L,
+                                                       uint32_t *__restrict__ sp_ids, uint16_t *__restrict__ sp_cnt, uint64_t *__restrict__ sp_meta,
+                                                       uint64_t *__restrict__ sp_bm, SpArena *__restrict__ arena, uint32_t bm_below_len)
+{
+    __shared__ uint32_t hist[64], wsum[SPF_T / 64], s_cut, s_base;
+    __shared__ unsigned long long s_bm;
+    const uint64_t a = a0 + blockIdx.x;
+    const uint16_t *row = rowbase + (uint64_t)blockIdx.x * ld;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;                      // matches 0..3: ~99 % of an unrelated database - tallied in registers
+    for (uint64_t b = threadIdx.x; b < a; b += SPF_T) {
+        const uint32_t c = row[b], d = c <= m ? m - c : 0;
+        if (d == 0) t0++; else if (d == 1) t1++; else if (d == 2) t2++; else if (d == 3) t3++; else atomicAdd(&hist[d < 63 ? d : 63], 1u);
+    }
+    if (t0) atomicAdd(&hist[0], t0);
+    if (t1) atomicAdd(&hist[1], t1);
+    if (t2) atomicAdd(&hist[2], t2);
+    if (t3) atomicAdd(&hist[3], t3);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, j0 = 64;                                // j0 = smallest j with #{d >= j} <= L
+        for (int j = 63; j >= 0; j--) { if (run + hist[j] > L) break; run += hist[j]; j0 = (uint32_t)j; }
+        s_cut = j0 == 64 ? 0xFFFFFFFFu : m - j0;
+        if (j0 != 64 && j0 > m) s_cut = 0xFFFFFFFFu;              // (only when m < 63 and even the pairs with m matches outnumber L: no list)
+        s_base = 0;
+    }
+    __syncthreads();
+    const uint32_t cut = s_cut;
+    if (cut == 0xFFFFFFFFu) { if (threadIdx.x == 0) { sp_meta[a] = 0; if (sp_bm) sp_bm[a] = 0; } return; }
+    uint32_t *ids = sp_ids + a * L; uint16_t *cnt = sp_cnt + a * L;
+    for (uint64_t c0 = 0; c0 < a; c0 += (uint64_t)SPF_T * 8) {
+        const uint64_t b0 = c0 + (uint64_t)threadIdx.x * 8;
+        uint32_t cc[8], nk = 0;
+#pragma unroll
+        for (int h = 0; h < 8; h++) { cc[h] = b0 + h < a ? row[b0 + h] : 0xFFFFFFFFu; nk += cc[h] <= cut; }
+        uint32_t inc = nk;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t off = s_base + inc - nk, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SPF_T / 64; w++) { if (w < (int)wv) off += wsum[w]; tot += wsum[w]; }
+#pragma unroll
+        for (int h = 0; h < 8; h++) if (cc[h] <= cut) { if (off < L) { ids[off] = (uint32_t)(b0 + h); cnt[off] = (uint16_t)cc[h]; } off++; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sp_meta[a] = ((uint64_t)1 << 63) | ((uint64_t)(s_base < L ? s_base : L) << 16) | (uint64_t)(cut & 0xFFFFu);
+        unsigned long long ptr = 0;
+        if (sp_bm && arena && cut < m && s_base < bm_below_len && a > 0) {        // (cut == m: the whole row is listed, nothing lies below)
+            const unsigned long long bytes = ((a + 31) / 32 * 4 + 15) & ~15ull;
+            const unsigned long long off = atomicAdd(&arena->off, bytes);
+            if (arena->base && off + bytes <= arena->size) { ptr = arena->base + off; atomicAdd(&arena->stored, 1ull); }
+            else atomicAdd(&arena->noroom, 1ull);
+        }
+        s_bm = ptr;
+        if (sp_bm) sp_bm[a] = ptr;
+    }
+    __syncthreads();
+    if (s_bm) {
+        uint32_t *bm = (uint32_t *)s_bm;
+        const uint32_t lvl = cut + 1;                                 // counts <= cut + 1 <=> matches >= J0 - 1
+        for (uint64_t w = threadIdx.x; w < (a + 31) / 32; w += SPF_T) {
+            uint32_t bits = 0;
+#pragma unroll 8
+            for (int h = 0; h < 32; h++) { const uint64_t b = w * 32 + h; if (b < a && (uint32_t)row[b] <= lvl) bits |= 1u << h; }
+            bm[w] = bits;
+        }
+    }
 }
 
 // ---- phase 2: links -------------------------------------------------------------------------------
@@ -1682,6 +1893,9 @@ struct gs_index {
     gs::DevBuf stats;                 // device work counters: [0] join atomics, [1] dense-traversal pops, [2] accepting pops (gs_index_search_stats)
     uint64_t stat_wg_in_flight = 0, stat_adj_row_bytes = 0;
     gs::DevBuf rowptr;
+    // sparse pair rows (IndexDev::sp_*): allocated at the first dense insert batch, grown with the index; sp_L = 0: off (GS_SPARSE_ROWS=0, m > 65535, no memory)
+    gs::DevBuf sp_ids, sp_cnt, sp_meta, sp_bm, sp_arena; uint32_t sp_L = 0; bool sp_tried = false;
+    std::vector<gs::DevBuf *> bm_chunks; uint64_t bm_bytes = 0, bm_budget = 0, bm_reserved = 0, bm_chunk_size = 0; uint32_t bm_idle_groups = 0; bool bm_on = true;
     std::vector<gs::DevBuf *> slabs;
     uint64_t pair_cache_bytes = 0, pair_cache_budget = 0;
     bool early_cached = false;        // the nodes older than the first cached batch have all-pairs rows (insert_common)
@@ -1701,6 +1915,7 @@ struct gs_index {
         if (jev) (void)hipEventDestroy(jev);
         if (jev_up) (void)hipEventDestroy(jev_up);
         for (auto *b : slabs) delete b;
+        for (auto *b : bm_chunks) delete b;
     }
 };
 
@@ -1738,8 +1953,10 @@ static int index_reserve(gs_index *ix, uint64_t need, uint64_t need_upper)
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
     if (need > ix->cap) {
         uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap + ix->cap / 2, 1024));
-        struct { DevBuf *b; size_t per; } arr[] = {
+        struct Arr { DevBuf *b; size_t per; };
+        std::vector<Arr> arr = {
             {&ix->data, (size_t)ix->stride}, {&ix->levels, 1}, {&ix->deg0, 4}, {&ix->nbr0, (size_t)8 * M}, {&ix->cnt0, (size_t)8 * M}, {&ix->upidx, 4}, {&ix->rowptr, 8}};
+        if (ix->sp_L && ix->sp_meta.p) { arr.push_back({&ix->sp_ids, (size_t)4 * ix->sp_L}); arr.push_back({&ix->sp_cnt, (size_t)2 * ix->sp_L}); arr.push_back({&ix->sp_meta, 8}); arr.push_back({&ix->sp_bm, 8}); }
         for (auto &a : arr) {
             DevBuf nb;
             int rc = alloc_or_evict(ix, nb, a.per * ncap); if (rc) return rc;
@@ -1774,6 +1991,9 @@ static IndexDev index_dev(const gs_index *ix)
     d.levels = ix->levels.as<uint8_t>(); d.deg0 = ix->deg0.as<uint32_t>(); d.nbr0 = ix->nbr0.as<uint32_t>();
     d.upidx = ix->upidx.as<int32_t>(); d.degU = ix->degU.as<uint32_t>(); d.nbrU = ix->nbrU.as<uint32_t>();
     d.rowptr = ix->rowptr.as<uint64_t>();
+    const bool sp = ix->sp_L && ix->sp_meta.p;
+    d.sp_ids = sp ? ix->sp_ids.as<uint32_t>() : nullptr; d.sp_cnt = sp ? ix->sp_cnt.as<uint16_t>() : nullptr; d.sp_meta = sp ? ix->sp_meta.as<uint64_t>() : nullptr; d.sp_L = sp ? ix->sp_L : 0;
+    d.sp_bm = sp ? ix->sp_bm.as<uint64_t>() : nullptr;
     d.n = ix->n; d.entry = ix->entry; d.top = ix->top;
     return d;
 }
@@ -1932,16 +2152,38 @@ static bool dense_vis_in_lds(const gs_index *ix, uint32_t knbn, uint32_t maxdeg)
     // the LDS placement is kept up to ~1.08 M nodes
     return l <= cap;
 }
+// SPLIT placement (round 5): the LDS bitmap maps node ids [0, W), this workgroup's global scratch the rest. W = what lets `per_cu` workgroups share a
+// CU (GS_SPLIT_PER_CU, default 2; GS_SPLIT_W overrides W itself - tests), a multiple of 1024; 0 = not possible / not wanted. Taken whenever the
+// whole bitmap does not fit the LDS (GS_DENSE_VIS=global keeps the round-4 all-global form, GS_DENSE_VIS=split forces the split at any size).
+static uint32_t dense_split_w(const gs_index *ix, uint32_t knbn, uint32_t maxdeg, uint32_t dcn, size_t min_bytes = 0)
+{
+    const char *e = getenv("GS_DENSE_VIS");
+    const bool forced = e && !strcmp(e, "split");
+    if (e && !forced) { if (!strcmp(e, "global") || !strcmp(e, "lds")) return 0; }
+    if (!forced && dense_vis_in_lds(ix, knbn, maxdeg)) return 0;
+    const size_t base = std::max(dense_lds_bytes(ix->prm.m, knbn, maxdeg, 0, true, dcn), min_bytes);
+    int per = getenv("GS_SPLIT_PER_CU") ? std::max(1, std::min(3, atoi(getenv("GS_SPLIT_PER_CU")))) : 2;
+    uint64_t w = 0;
+    for (; per >= 1 && w < 1024; per--) {
+        const size_t budget = (size_t)(160 * 1024 / per) / 1280 * 1280 - 64;
+        w = budget > base ? ((uint64_t)(budget - base) * 8) & ~(uint64_t)1023 : 0;
+    }
+    if (getenv("GS_SPLIT_W")) w = std::min<uint64_t>(w, (uint64_t)std::max(1024, atoi(getenv("GS_SPLIT_W"))) & ~(uint64_t)1023);
+    if (w < 1024) return 0;
+    return (uint32_t)std::min<uint64_t>(w, round_up(ix->n, 1024));
+}
 static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_t ef, const uint16_t *mat, uint64_t mat_ld, uint64_t *ids, float *dist,
                                uint32_t *count, uint64_t *evals)
 {
     gs_ctx *c = ix->ctx;
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
-    const bool vlds = dense_vis_in_lds(ix, knbn, maxdeg);
     const bool oneg = maxdeg > (uint32_t)DT / 2;                       // rows of more than 256 ids: one 512-lane group instead of two halves
     const uint32_t dcn = oneg ? 512u : (uint32_t)DCN;
-    const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, vlds, dcn);
+    const uint32_t vis_w = dense_split_w(ix, knbn, maxdeg, dcn);
+    const bool split = vis_w != 0;
+    const bool vlds = split || dense_vis_in_lds(ix, knbn, maxdeg);
+    const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, split ? (uint64_t)vis_w : ix->n, vlds, dcn);
     // three 8-wave workgroups per CU while the LDS allows it (n <= ~300 k with the bitmap in LDS): that build is capped at 80 VGPRs
     // (18 dwords spill, none on the per-pop path); the two-per-CU build (<= 128 VGPRs) takes over for larger n
     const size_t granted = round_up(lds, 1280);                       // LDS is granted in 1280-byte granules
@@ -1949,7 +2191,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     if (oneg) per_cu = std::min<uint32_t>(per_cu, 2);                    // that build is not capped at 80 VGPRs
     if (getenv("GS_DENSE_PER_CU")) per_cu = std::max(1, std::min((int)per_cu, atoi(getenv("GS_DENSE_PER_CU"))));
     // per-workgroup global scratch: visited bitmap (vlds = false) or the fine histogram bins (vlds = true)
-    const uint32_t scratch_words = vlds ? dense_nblocks(ix->prm.m) * (HB / 2) : (uint32_t)((ix->n + 31) / 32);
+    const uint32_t scratch_words = (vlds ? dense_nblocks(ix->prm.m) * (HB / 2) : (uint32_t)((ix->n + 31) / 32)) + (split && ix->n > vis_w ? (uint32_t)((ix->n - vis_w + 31) / 32) : 0u);
     const uint32_t capC = 2 * efs + 2 * dcn + maxdeg + 64;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)c->n_cu * per_cu);
     int rc;
@@ -1966,19 +2208,22 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     if (getenv("GS_TRAV_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); prof = profbuf.as<unsigned long long>(); }
     {
     ProfScope ps(c, FAM_SEARCH);
-#define GS_LAUNCH_DSEARCH(V, P, O, G)                                                                                        \
+#define GS_LAUNCH_DSEARCH(V, P, O, G) GS_LAUNCH_DSEARCH_S(V, P, O, G, false)
+#define GS_LAUNCH_DSEARCH_S(V, P, O, G, SP)                                                                                  \
     do {                                                                                                                  \
-        auto kern = k_hnsw_search_dense<V, P, O, G, false>;                                                                \
+        auto kern = k_hnsw_search_dense<V, P, O, G, false, SP>;                                                            \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, nq, knbn, ef, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
                            ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), ids, dist, count, evals, prof, ix->stats.as<unsigned long long>(),  \
-                           (uint64_t *)nullptr, p2_off, 0u, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);  \
+                           (uint64_t *)nullptr, p2_off, 0u, (uint64_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, vis_w);  \
     } while (0)
-    if (oneg) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4, true); else GS_LAUNCH_DSEARCH(false, false, 4, true); }
+    if (split) { if (oneg) GS_LAUNCH_DSEARCH_S(true, false, 4, true, true); else GS_LAUNCH_DSEARCH_S(true, false, 4, false, true); }
+    else if (oneg) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4, true); else GS_LAUNCH_DSEARCH(false, false, 4, true); }
     else if (prof) { if (vlds) GS_LAUNCH_DSEARCH(true, true, 4, false); else GS_LAUNCH_DSEARCH(false, true, 4, false); }
     else if (per_cu >= 3) { if (vlds) GS_LAUNCH_DSEARCH(true, false, 6, false); else GS_LAUNCH_DSEARCH(false, false, 6, false); }
     else { if (vlds) GS_LAUNCH_DSEARCH(true, false, 4, false); else GS_LAUNCH_DSEARCH(false, false, 4, false); }
 #undef GS_LAUNCH_DSEARCH
+#undef GS_LAUNCH_DSEARCH_S
     }
     GS_HIP_CHECK(hipGetLastError());
     if (prof) {
@@ -2528,13 +2773,47 @@ static int gen_level_host(const gs_index *ix, uint64_t id)
 // entry point comes out of an ef-search on layer 1, not of the greedy descent) are skipped and keep the sorted-array search inside
 // k_hnsw_plan. Leaves the device pointers of W (efc keys per point, sorted), |W| (0xFFFFFFFF = not done) and the evaluation counts.
 namespace gs {
+// sparse pair rows of `nrows` nodes a0.. from their count rows (k_sparse_fill), with room for their level bitmaps: the bitmaps come from chunks of a
+// bump arena the KERNEL allocates from (only it knows which rows need one). The host reserves the worst case - every row takes one - and looks at the
+// real fill level (one 40-byte read back) only when that reservation runs out; chunks stop being added at GS_SPARSE_BITMAP_GB (default 24).
+static int sparse_fill(gs_index *ix, const uint16_t *rows, uint64_t ld, uint64_t a0, uint32_t nrows)
+{
+    gs_ctx *c = ix->ctx;
+    if (!ix->sp_L || nrows == 0) return GS_OK;
+    if (ix->bm_on && ix->sp_arena.p) {
+        const uint64_t need = (uint64_t)nrows * (((a0 + nrows + 31) / 32) * 4 + 16);
+        if (ix->bm_chunks.empty() || ix->bm_reserved + need > ix->bm_chunk_size) {
+            SpArena h{};
+            GS_HIP_CHECK(hipMemcpyAsync(&h, ix->sp_arena.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            const uint64_t used = std::min<uint64_t>(h.off, h.size);
+            if (!ix->bm_chunks.empty() && used + need <= ix->bm_chunk_size) ix->bm_reserved = used + need;       // the worst case did not happen: room left
+            else {
+                const uint64_t want = std::max<uint64_t>(4 * need, (uint64_t)512 << 20);
+                if (ix->bm_budget == 0) ix->bm_budget = (uint64_t)((getenv("GS_SPARSE_BITMAP_GB") ? atof(getenv("GS_SPARSE_BITMAP_GB")) : 24.0) * 1e9);
+                gs::DevBuf *ch = (ix->bm_bytes + want <= ix->bm_budget) ? new gs::DevBuf() : nullptr;
+                if (ch && ch->alloc(want) != GS_OK) { (void)hipGetLastError(); delete ch; ch = nullptr; }
+                if (!ch) { ix->bm_on = false; h.base = 0; h.off = 0; h.size = 0; }                              // no more bitmaps: the rows that want one count `noroom`
+                else { ix->bm_chunks.push_back(ch); ix->bm_bytes += want; ix->bm_chunk_size = want; ix->bm_reserved = need; h.base = (unsigned long long)ch->p; h.off = 0; h.size = want; }
+                GS_HIP_CHECK(hipMemcpyAsync(ix->sp_arena.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+                GS_HIP_CHECK(hipStreamSynchronize(c->stream));                                                    // (h is a local)
+            }
+        } else ix->bm_reserved += need;
+    }
+    const uint32_t below = (uint32_t)std::min<uint64_t>(ix->sp_L, (uint64_t)ix->prm.ef_construction + ix->prm.ef_construction / 4);
+    hipLaunchKernelGGL(k_sparse_fill, dim3(nrows), dim3(SPF_T), 0, c->stream, rows, ld, a0, ix->prm.m, ix->sp_L, ix->sp_ids.as<uint32_t>(), ix->sp_cnt.as<uint16_t>(),
+                       ix->sp_meta.as<uint64_t>(), ix->sp_bm.as<uint64_t>(), ix->sp_arena.as<SpArena>(), below);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
 static bool prepass_ok(const gs_index *ix, uint32_t efc)
 {
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn, knbn = 1;
     if (getenv("GS_PLAN_PREPASS") && !atoi(getenv("GS_PLAN_PREPASS"))) return false;
     if (ix->n < 4096 || ix->entry < 0 || maxdeg > (uint32_t)DT / 2 || efc > 65535u || efc < 2 || ix->prm.m > 65535u) return false;
-    if (!dense_vis_in_lds(ix, knbn, maxdeg)) return false;                       // WLOG is only instantiated for the LDS bitmap
     uint32_t sort_cap = 2; while (sort_cap < 4 * efc) sort_cap <<= 1;
+    if (dense_split_w(ix, knbn, maxdeg, (uint32_t)DCN, (size_t)8 * sort_cap + 64)) return true;     // (round 5) beyond the LDS: the split bitmap
+    if (!dense_vis_in_lds(ix, knbn, maxdeg)) return false;                       // WLOG is instantiated for the LDS bitmap and its split form
     return std::max<size_t>(dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true), (size_t)8 * sort_cap + 64) <= 160 * 1024 - 1024;
 }
 static int plan_prepass(gs_index *ix, uint32_t nb, uint32_t efc, const uint16_t *mat, uint64_t mat_ld, const uint64_t **w0k, const uint32_t **w0n, const uint64_t **w0e)
@@ -2543,11 +2822,12 @@ static int plan_prepass(gs_index *ix, uint32_t nb, uint32_t efc, const uint16_t 
     *w0k = nullptr; *w0n = nullptr; *w0e = nullptr;
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn, knbn = 1;
     uint32_t sort_cap = 2; while (sort_cap < 4 * efc) sort_cap <<= 1;             // keys the epilogue can sort: ties at dmax ride along
-    size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true);
+    const uint32_t vis_w = dense_split_w(ix, knbn, maxdeg, (uint32_t)DCN, (size_t)8 * sort_cap + 64);
+    size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, vis_w ? (uint64_t)vis_w : ix->n, true);
     lds = std::max<size_t>(lds, (size_t)8 * sort_cap + 64);
     const size_t granted = round_up(lds, 1280);
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / granted));
-    const uint32_t scratch_words = dense_nblocks(ix->prm.m) * (HB / 2);
+    const uint32_t scratch_words = dense_nblocks(ix->prm.m) * (HB / 2) + (vis_w && ix->n > vis_w ? (uint32_t)((ix->n - vis_w + 31) / 32) : 0u);
     const uint32_t capC = 2 * efc + 2 * (uint32_t)DCN + maxdeg + 64,
                    cap_log = 16 * efc + ((getenv("GS_DENSE_PHASE2") && !atoi(getenv("GS_DENSE_PHASE2"))) ? 1u : 0u);      // (odd = order-free phase 2 off, A/B)
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nb, (uint64_t)c->n_cu * per_cu);
@@ -2563,17 +2843,19 @@ static int plan_prepass(gs_index *ix, uint32_t nb, uint32_t efc, const uint16_t 
     GS_HIP_CHECK(hipMemsetAsync(ix->counter.p, 0, 8, c->stream));
     IndexDev d = index_dev(ix);
     {   // (inside the caller's FAM_INSERT profiling scope)
-#define GS_LAUNCH_WL(O)                                                                                                   \
+#define GS_LAUNCH_WL(O) GS_LAUNCH_WL_S(O, false)
+#define GS_LAUNCH_WL_S(O, SP)                                                                                             \
     do {                                                                                                                  \
-        auto kern = k_hnsw_search_dense<true, false, O, false, true>;                                                     \
+        auto kern = k_hnsw_search_dense<true, false, O, false, true, SP>;                                                 \
         GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DT), lds, c->stream, d, (uint64_t)nb, knbn, efc, mat, mat_ld, ix->visited.as<uint32_t>(), scratch_words, \
                            ix->cbuf.as<uint64_t>(), capC, ix->counter.as<unsigned long long>(), (uint64_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr, \
                            ix->w0_evals.as<uint64_t>(), (unsigned long long *)nullptr, (unsigned long long *)nullptr, ix->wlog.as<uint64_t>(), cap_log, sort_cap, \
-                           ix->w0_keys.as<uint64_t>(), ix->w0_n.as<uint32_t>(), ix->ep0.as<uint32_t>());                      \
+                           ix->w0_keys.as<uint64_t>(), ix->w0_n.as<uint32_t>(), ix->ep0.as<uint32_t>(), vis_w);               \
     } while (0)
-        if (per_cu >= 3) GS_LAUNCH_WL(6); else GS_LAUNCH_WL(4);
+        if (vis_w) GS_LAUNCH_WL_S(4, true); else if (per_cu >= 3) GS_LAUNCH_WL(6); else GS_LAUNCH_WL(4);
 #undef GS_LAUNCH_WL
+#undef GS_LAUNCH_WL_S
     }
     GS_HIP_CHECK(hipGetLastError());
     *w0k = ix->w0_keys.as<uint64_t>(); *w0n = ix->w0_n.as<uint32_t>(); *w0e = ix->w0_evals.as<uint64_t>();
@@ -2747,15 +3029,65 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
                     } else delete early;
                 }
             }
-            uint16_t *out16;
-            if (slab) { out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld; mat_ld = slab_ld; }
-            else { if (ix->mat.bytes < (size_t)2 * B * slab_ld && (rc = alloc_or_evict(ix, ix->mat, (size_t)2 * B * slab_ld))) return rc; out16 = ix->mat.as<uint16_t>(); mat_ld = slab_ld; }
-            if (!slab) grp_b0 = grp_end = 0;
-            if (slab && grp_n > 1 && b0 >= grp_b0 && b0 < grp_end) {
-                // inside a group: this batch's counts against the nodes of the group's start are in the slab already; the nodes the earlier
+            // sparse pair rows (round 5): allocated here, at the first dense batch of the index (they cost sp_L x 6 bytes per node of capacity)
+            if (!ix->sp_tried) {
+                ix->sp_tried = true;
+                const char *eo = getenv("GS_SPARSE_ROWS"), *el = getenv("GS_SPARSE_L");
+                // list length: what the device can afford next to the signatures and their column copy AT THE DECLARED CAPACITY (hnsw_params.capacity: 1.5 M in
+                // gsearch) - 6 bytes per entry and node -, between 2048 and 8192; a level of chance matches must fit whole
+                uint32_t autoL = 4096;
+                {
+                    const uint64_t capd = std::max<uint64_t>(ix->prm.capacity, ix->cap);
+                    const uint64_t fixed = 2 * (uint64_t)ix->stride * capd + ((uint64_t)32 << 30);
+                    const uint64_t room = c->hbm_bytes > fixed ? c->hbm_bytes - fixed : 0;
+                    autoL = (uint32_t)std::max<uint64_t>(2048, std::min<uint64_t>(8192, room / (6 * capd) / 512 * 512));
+                }
+                ix->sp_L = (eo && !atoi(eo)) ? 0u : (uint32_t)std::max(64, std::min(32768, el ? atoi(el) : (int)autoL));
+                if (ix->sp_L) {
+                    if (ix->sp_ids.alloc((size_t)4 * ix->sp_L * ix->cap) != GS_OK || ix->sp_cnt.alloc((size_t)2 * ix->sp_L * ix->cap) != GS_OK || ix->sp_meta.alloc((size_t)8 * ix->cap) != GS_OK ||
+                        ix->sp_bm.alloc((size_t)8 * ix->cap) != GS_OK || ix->sp_arena.alloc(64) != GS_OK) {
+                        (void)hipGetLastError(); ix->sp_ids.release(); ix->sp_cnt.release(); ix->sp_meta.release(); ix->sp_bm.release(); ix->sp_arena.release(); ix->sp_L = 0;
+                    } else {
+                        GS_HIP_CHECK(hipMemsetAsync(ix->sp_meta.p, 0, (size_t)8 * ix->cap, c->stream));
+                        GS_HIP_CHECK(hipMemsetAsync(ix->sp_bm.p, 0, (size_t)8 * ix->cap, c->stream));
+                        GS_HIP_CHECK(hipMemsetAsync(ix->sp_arena.p, 0, 64, c->stream));
+                        ix->bm_on = !(getenv("GS_SPARSE_BITMAP_GB") && atof(getenv("GS_SPARSE_BITMAP_GB")) <= 0);
+                    }
+                }
+                // the nodes inserted before this batch have no count rows to take their lists from: one all-pairs tile pass over them (like the dense
+                // cache's early rows, which it reuses when they exist), lists written, matrix given back
+                if (ix->sp_L && b0 > 0 && b0 <= 32768) {
+                    const uint64_t eld = gs::round_up(b0, 8);
+                    gs::DevBuf tmp; const uint16_t *em = nullptr;
+                    if (ix->early_cached && !ix->slabs.empty()) em = ix->slabs.back()->as<uint16_t>();      // (pushed just above, this call)
+                    else if (tmp.alloc(b0 * eld * 2) == GS_OK) {
+                        if ((rc = gs::hamming_qxc_strided(c, ix->ikind, ix->prm.m, ix->data.p, b0, ix->stride, ix->data.p, b0, ix->stride, nullptr, nullptr, tmp.as<uint16_t>(), eld))) return rc;
+                        em = tmp.as<uint16_t>();
+                    } else (void)hipGetLastError();
+                    if (em) {
+                        if ((rc = gs::sparse_fill(ix, em, eld, 0, (uint32_t)b0))) return rc;
+                        GS_HIP_CHECK(hipStreamSynchronize(c->stream));          // tmp goes out of scope
+                    }
+                }
+                d = gs::index_dev(ix); d.n = b0; d.entry = ix->entry; d.top = ix->top;
+            }
+            // where this batch's count rows live: the call's slab of the dense pair cache (kept), or a rolling buffer of one GROUP of batches (ix->mat;
+            // round 5: without a slab the batches were joined one by one - the columns streamed once per batch instead of once per group)
+            const bool can_group = grp_n > 1 && gs::use_join(ix);
+            uint16_t *out16; mat_ld = slab_ld;
+            if (slab) out16 = slab->as<uint16_t>() + (b0 - slab_first) * slab_ld;
+            else {
+                const size_t rows_wanted = can_group ? (size_t)grp_n * B : (size_t)B;
+                if (!(b0 >= grp_b0 && b0 < grp_end)) {                                    // a new group (or single batch) starts: the buffer may grow now
+                    if (ix->mat.bytes < 2 * rows_wanted * slab_ld && (rc = alloc_or_evict(ix, ix->mat, 2 * rows_wanted * slab_ld))) return rc;
+                }
+                out16 = (b0 >= grp_b0 && b0 < grp_end) ? ix->mat.as<uint16_t>() + (b0 - grp_b0) * slab_ld : ix->mat.as<uint16_t>();
+            }
+            if (can_group && b0 >= grp_b0 && b0 < grp_end) {
+                // inside a group: this batch's counts against the nodes of the group's start are in its rows already; the nodes the earlier
                 // batches of the group added since (at most (grp_n - 1) * B of them) take a small join of their own (their columns only)
                 if (b0 > grp_b0 && (rc = gs::dense_counts_range(ix, rows, nb, grp_b0, b0 - grp_b0, out16, mat_ld))) return rc;
-            } else if (slab && grp_n > 1 && gs::use_join(ix)) {
+            } else if (can_group) {
                 // a group of batches: ONE join of all their points against the nodes present now - the columns (21.6 GB at 300 k nodes) are
                 // streamed once per group instead of once per batch
                 grp_b0 = b0; grp_end = std::min<uint64_t>(first + n, b0 + (uint64_t)grp_n * B);
@@ -2765,21 +3097,22 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
                 pf_have = false;
             } else {
                 if (pf_have) { GS_HIP_CHECK(hipStreamSynchronize(ix->jstream)); pf_have = false; }
+                grp_b0 = grp_end = 0;
                 if ((rc = gs::dense_counts(ix, rows, nb, b0, out16, mat_ld))) return rc;
                 // a join produced on the main stream shares the query-column scratch and the column store with the next one on the second
                 // stream: that one must not start before this one is done
                 if (overlap) { GS_HIP_CHECK(hipEventRecord(ix->jev_up, c->stream)); GS_HIP_CHECK(hipStreamWaitEvent(ix->jstream, ix->jev_up, 0)); }
             }
             if (slab && ix->slabs.empty()) {                         // evicted under our feet after all: this batch's counts again, into ix->mat
-                slab = nullptr;
+                slab = nullptr; grp_b0 = grp_end = 0;
                 if (ix->mat.bytes < (size_t)2 * B * slab_ld && (rc = ix->mat.alloc((size_t)2 * B * slab_ld))) return rc;
                 out16 = ix->mat.as<uint16_t>();
                 if ((rc = gs::dense_counts(ix, rows, nb, b0, out16, mat_ld))) return rc;
             }
-            if (slab) {
-                hipLaunchKernelGGL(gs::k_cache_rows, dim3(nb), dim3(256), 0, c->stream, out16, mat_ld, b0, nb, ix->cntmat.as<uint32_t>(), ix->rowptr.as<uint64_t>());
-                GS_HIP_CHECK(hipGetLastError());
-            }
+            // the mates' columns from the tile matrix; with a slab the rows stay where they are as the dense pair cache (rowptr)
+            hipLaunchKernelGGL(gs::k_cache_rows, dim3(nb), dim3(256), 0, c->stream, out16, mat_ld, b0, nb, ix->cntmat.as<uint32_t>(), slab ? ix->rowptr.as<uint64_t>() : (uint64_t *)nullptr);
+            GS_HIP_CHECK(hipGetLastError());
+            if ((rc = gs::sparse_fill(ix, out16, mat_ld, b0, nb))) return rc;
             matp = out16;
         }
         if (b0 >= 4096) { seg_den += (double)nb * (double)b0; seg_batches++; }
@@ -2843,10 +3176,22 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         ix->n = b0 + nb;
         // the level / batch buffers are reused by the next batch: the stream orders the copies after the kernels
     }
-    unsigned long long ev = 0;
-    GS_HIP_CHECK(hipMemcpyAsync(&ev, ix->evals_dev.p, 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long ev[3] = {0, 0, 0};
+    GS_HIP_CHECK(hipMemcpyAsync(ev, ix->evals_dev.p, 24, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    ix->insert_evals = ev;
+    ix->insert_evals = ev[0];
+    if (getenv("GS_SPARSE_VERBOSE")) {
+        uint64_t with = 0, full = 0;
+        if (ix->sp_L && ix->sp_meta.p) {
+            std::vector<uint64_t> mt(ix->n);
+            GS_HIP_CHECK(hipMemcpy(mt.data(), ix->sp_meta.p, 8 * ix->n, hipMemcpyDeviceToHost));
+            for (uint64_t v : mt) { with += v >> 63; full += (v >> 63) && ((v >> 16) & 0xFFFFu) == ix->sp_L; }
+        }
+        gs::SpArena ar{};
+        if (ix->sp_arena.p) GS_HIP_CHECK(hipMemcpy(&ar, ix->sp_arena.p, sizeof(ar), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[GS_SPARSE] n %llu L %u: nodes with a list %llu (at capacity %llu), dense-cache bytes %llu; selection chunks through the lists %llu, candidates checked by streaming rows %llu (both since the index was made); level bitmaps %llu in %llu bytes of chunks, turned away %llu\n",
+                (unsigned long long)ix->n, ix->sp_L, (unsigned long long)with, (unsigned long long)full, (unsigned long long)ix->pair_cache_bytes, ev[2], ev[1], ar.stored, (unsigned long long)ix->bm_bytes, ar.noroom);
+    }
     return GS_OK;
 }
 

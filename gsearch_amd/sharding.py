@@ -73,6 +73,54 @@ class TopkExchange:
         return ids, dist
 
 
+class LibExchange:
+    """The same one-collective exchange through the LIBRARY's communicator (gs_comm_*: RCCL loaded by the C-ABI library, pack kernel -> one
+    ncclAllGather of fixed-size blocks -> unpack kernel) - what a host that is not Python calls, and what `bench.py --gpus N` times. Shards may be
+    unequal (`nq_max` = the largest). torch only carries the 128-byte unique id from rank 0 to the others once, at set-up."""
+
+    def __init__(self, ctx, nq_local, nq_max, knbn, world, rank, device):
+        import torch
+        import torch.distributed as td
+        import gsearch_amd as G
+        self.ctx, self.nq, self.nq_max, self.knbn, self.world, self.rank = ctx, nq_local, nq_max, knbn, world, rank
+        uid = torch.zeros(128, dtype=torch.uint8, device=device)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(G.Comm.unique_id()), dtype=torch.uint8))
+        if world > 1:
+            td.broadcast(uid, src=0)
+        self.comm = G.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+        self.ids = torch.zeros((max(nq_local, 1), knbn), dtype=torch.int64, device=device)[:nq_local]
+        self.dist = torch.zeros((max(nq_local, 1), knbn), dtype=torch.float32, device=device)[:nq_local]
+        self.all_ids = torch.zeros((world * nq_max, knbn), dtype=torch.int64, device=device)
+        self.all_dist = torch.zeros((world * nq_max, knbn), dtype=torch.float32, device=device)
+        self.counts = None
+
+    def exchange(self):
+        self.counts = self.comm.allgatherv_topk_dev(self.ids.data_ptr(), self.dist.data_ptr(), self.nq, self.nq_max, self.knbn,
+                                                    self.all_ids.data_ptr(), self.all_dist.data_ptr())
+
+    def gathered(self):
+        tot = int(self.counts.sum())
+        return self.all_ids[:tot], self.all_dist[:tot]
+
+    def ranks_seen(self):
+        return self.comm.size()
+
+
+def allgather_topk_blocks(ids, dist, nq_max):
+    """unequal shards over ANY torch.distributed backend (the gloo tests; a host with its own transport does the same with gs_topk_pack / gs_topk_unpack):
+    this rank's (nq_local, k) answers -> (compact ids, compact distances, counts per rank), rank order, through ONE all_gather of fixed-size blocks"""
+    import torch
+    import torch.distributed as td
+    import gsearch_amd as G
+    world = td.get_world_size()
+    knbn = ids.shape[1]
+    block = torch.from_numpy(G.topk_pack(ids, dist, nq_max))
+    recv = torch.empty(world * block.numel(), dtype=torch.uint8)
+    td.all_gather_into_tensor(recv, block)
+    return G.topk_unpack(recv.numpy(), world, nq_max, knbn)
+
+
 def shard_bounds(n, rank, world):
     """contiguous block [lo, hi) of rank; sizes differ by at most one"""
     base, rem = divmod(n, world)

@@ -280,6 +280,21 @@ int  gs_comm_size(const gs_comm *);
  * One ncclAllGather of the packed block (12 bytes per neighbour). Same nq_local and knbn on every rank. */
 int  gs_comm_allgather_topk_dev(gs_comm *, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint32_t knbn,
                                 uint64_t *all_ids_dev, float *all_dist_dev);
+/* the same exchange for UNEQUAL shards (a contiguous sharding of a batch hands out blocks that differ by one query; a rank may hold none): every rank
+ * passes its own nq_local and the same nq_max >= all of them; all_*_dev (room for n_ranks x nq_max rows) receive the COMPACT concatenation in rank order,
+ * counts_out (HOST, n_ranks, optional) every rank's count. Still ONE ncclAllGather - of fixed-size blocks, gs_topk_block_bytes() each. */
+int  gs_comm_allgatherv_topk_dev(gs_comm *, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint64_t nq_max, uint32_t knbn,
+                                 uint64_t *all_ids_dev, float *all_dist_dev, uint64_t *counts_out);
+/* the block layout itself, on the HOST (no device needed), for hosts that move the blocks by their own means (MPI, sockets): header {u64 nq_local, u32 knbn,
+ * u32 magic}, nq_max x knbn ids, nq_max x knbn distances. unpack: n_ranks blocks back to back -> compact rows in rank order + counts. */
+uint64_t gs_topk_block_bytes(uint64_t nq_max, uint32_t knbn);
+int  gs_topk_pack(const uint64_t *ids, const float *dist, uint64_t nq_local, uint64_t nq_max, uint32_t knbn, void *block_out);
+int  gs_topk_unpack(const void *blocks, int n_ranks, uint64_t nq_max, uint32_t knbn, uint64_t *all_ids, float *all_dist, uint64_t *counts_out);
+/* DB-sharded alternative (the per-shard loop + merge of scripts/multiple_search.sh:71-107: the database split over the GPUs, every rank answers ALL queries
+ * on its shard, the gathered answers are merged): ids_dev / dist_dev = n_shards x nq x knbn_in (shard-major, as gathered), id_offset (HOST, optional) is
+ * added to the ids of each shard; out_*_dev: nq x knbn_out, the best under (distance, id). */
+int  gs_topk_merge_dev(gs_ctx *, const uint64_t *ids_dev, const float *dist_dev, uint32_t n_shards, uint64_t nq, uint32_t knbn_in, const uint64_t *id_offset,
+                       uint32_t knbn_out, uint64_t *out_ids_dev, float *out_dist_dev);
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Synthetic inputs generated in HBM (bench / tests): counter-based, reproducible on the host.      */

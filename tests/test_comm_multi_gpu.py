@@ -43,6 +43,16 @@ RANK_SCRIPT = textwrap.dedent("""
     all_ids = ctx.download(d_aids, (world * nq, knbn), np.uint64); all_dist = ctx.download(d_adist, (world * nq, knbn), np.float32)
     want_ids, want_dist, _, _ = hn.search_arrays(q, knbn, 60)            # the single-rank answer for the whole batch
     ok = bool(np.array_equal(all_ids, want_ids) and np.array_equal(all_dist, want_dist))
+    # unequal shards (round 5): the same batch minus its last three queries, contiguous blocks that differ by one, through gs_comm_allgatherv_topk_dev
+    from gsearch_amd import sharding as S
+    nqt = nq * world - 3
+    lo, hi = S.shard_bounds(nqt, rank, world)
+    nq_max = max(S.shard_bounds(nqt, r, world)[1] - S.shard_bounds(nqt, r, world)[0] for r in range(world))
+    ids2, dist2, _, _ = hn.search_arrays(q[lo:hi], knbn, 60)
+    ctx.upload(d_ids, ids2); ctx.upload(d_dist, dist2)
+    counts = comm.allgatherv_topk_dev(d_ids, d_dist, hi - lo, nq_max, knbn, d_aids, d_adist)
+    g_ids = ctx.download(d_aids, (nqt, knbn), np.uint64); g_dist = ctx.download(d_adist, (nqt, knbn), np.float32)
+    ok = ok and bool(np.array_equal(g_ids, want_ids[:nqt]) and np.array_equal(g_dist, want_dist[:nqt]) and int(counts.sum()) == nqt and comm.size() == world)
     open(outfile, "w").write("ok" if ok else "MISMATCH")
     comm.close()
 """)

@@ -120,7 +120,7 @@ def test_config2_request_300k(gpu_ctx, monkeypatch):
     assert np.array_equal(od, bd[:4])
 
 
-@pytest.mark.parametrize("n,placement", [(700_000, "lds bitmap, one workgroup per CU"), (1_250_000, "global bitmap")])
+@pytest.mark.parametrize("n,placement", [(700_000, "lds bitmap, one workgroup per CU"), (1_250_000, "split bitmap"), (1_250_000, "global bitmap")])
 def test_dense_search_on_very_large_graphs(gpu_ctx, monkeypatch, n, placement):
     """the dense traversal's visited-bitmap placements beyond the sizes the other tests reach: up to ~1.08 M nodes the bitmap stays in LDS (one
     workgroup per CU), beyond it lives in global memory; both run the order-free second phase. A random regular graph over short signatures
@@ -128,6 +128,8 @@ def test_dense_search_on_very_large_graphs(gpu_ctx, monkeypatch, n, placement):
     (gsearch constructs Hnsw with capacity 1 500 000, /root/reference/src/bin/gsearch.rs:268-269)."""
     import gsearch_amd as G
     monkeypatch.setenv("GS_DIST_MODE", "dense")
+    if placement == "global bitmap":
+        monkeypatch.setenv("GS_DENSE_VIS", "global")                        # (round 5: beyond the LDS the default is the split bitmap)
     m, M, nq, knbn, ef = 32, 8, 96, 10, 300
     rng = np.random.default_rng(n % 1000)
     db = rng.integers(0, 6, (n, m)).astype(np.float32)                       # narrow value band: plenty of ties and chance agreements

@@ -669,14 +669,16 @@ def test_dense_strategies_for_every_signature_kind(gpu_ctx, monkeypatch, dtype, 
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
 
 
-@pytest.mark.parametrize("vis", ["lds", "global"])
+@pytest.mark.parametrize("vis", ["lds", "global", "split"])
 @pytest.mark.parametrize("regime", ["spread", "ties", "tiny_ef"])
 def test_dense_traversal_placements_and_regimes(gpu_ctx, monkeypatch, vis, regime):
-    """dense traversal (histogram result set): visited bitmap in LDS / in global memory, on data with spread-out distances (the rank
-    path), with almost everything tied at distance 1 (the flood regime of the request workload) and with ef = knbn = small"""
+    """dense traversal (histogram result set): visited bitmap in LDS / in global memory / split (round 5: ids below GS_SPLIT_W in LDS, the rest in global
+    memory with the Bloom filter in front of it in the order-free phase and the evaluation count of what it dropped taken by a walk after the drain), on
+    data with spread-out distances (the rank path), with almost everything tied at distance 1 (the flood regime of the request workload) and with ef = knbn = small"""
     import gsearch_amd as G
     monkeypatch.setenv("GS_DIST_MODE", "dense")
     monkeypatch.setenv("GS_DENSE_VIS", vis)
+    monkeypatch.setenv("GS_SPLIT_W", "1024")                    # 1200 nodes: ids 1024.. live in the global part (two walks' worth would need > 2048)
     m = 200
     if regime == "ties":
         db = H.synth_sig_db(150, 8, m, 77, jlo=0.0, jhi=0.6)      # many small unrelated families: most pairs share no slot
@@ -700,7 +702,7 @@ def test_dense_traversal_placements_and_regimes(gpu_ctx, monkeypatch, vis, regim
         assert (want[1] == 1.0).mean() > 0.3                      # the data really is tie-heavy
 
 
-@pytest.mark.parametrize("vis", ["lds", "global"])
+@pytest.mark.parametrize("vis", ["lds", "global", "split"])
 @pytest.mark.parametrize("M,regime", [(160, "spread"), (140, "ties"), (200, "tiny_ef")])
 def test_dense_traversal_wide_adjacency(gpu_ctx, monkeypatch, vis, M, regime):
     """max_nb_conn above 128 (gsearch allows -n up to 255, gsearch.rs:268): layer-0 rows of up to 510 ids are expanded by one 512-lane group
@@ -709,6 +711,7 @@ def test_dense_traversal_wide_adjacency(gpu_ctx, monkeypatch, vis, M, regime):
     import gsearch_amd as G
     monkeypatch.setenv("GS_DIST_MODE", "dense")
     monkeypatch.setenv("GS_DENSE_VIS", vis)
+    monkeypatch.setenv("GS_SPLIT_W", "1024")                    # "ties": 6000 nodes = the LDS part + five walks over the global part
     m = 160
     if regime == "ties":
         m = 64
@@ -767,6 +770,75 @@ def test_insert_prepass_builds_the_oracle_graph(gpu_ctx, monkeypatch, dtype, M, 
             d = int(og["deg0"][i])
             assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d])
     assert (og["levels"][4096:] > 0).sum() >= 3
+
+
+@pytest.mark.parametrize("L,grp,data", [("4096", None, "families"), ("192", None, "families"), ("192", "1", "families"), ("64", "3", "families"),
+                                        ("4096", None, "noise"), ("512", None, "noise"), ("512", "0", "noise")])
+def test_insert_with_sparse_pair_rows_builds_the_oracle_graph(gpu_ctx, monkeypatch, capfd, L, grp, data):
+    """round 5: with the dense pair cache switched off (GS_PAIR_CACHE_GB=0 - what a build beyond ~400 k genomes runs into) the selection heuristic
+    takes c(e,s) from the SPARSE pair rows: every node keeps the counts of its <= L closest older nodes and a cut; a pair that is not listed lies above
+    the cut, which decides every candidate whose own count is <= the cut, and the rest is checked by streaming rows. 21 000 nodes in 210 families, so a
+    list of 4096 holds a family and the best of the chance level, lists of 192 / 64 are cut inside the family (candidates above the cut: the level bitmap
+    one level below the cut, then the streaming path, must agree too). "noise": 21 000 unrelated rows over a narrow value band - every pair agrees in
+    ~16 +- 4 of 96 slots, so the lists are cut in the middle of the bulk and the selection walks are long. grp "0": without the level bitmaps
+    (GS_SPARSE_BITMAP_GB=0). Graph (levels, degrees, neighbour ids AND their counts) == oracle; batches joined in groups without a slab (group buffer)."""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_PAIR_CACHE_GB", "0")
+    monkeypatch.setenv("GS_SPARSE_L", L)
+    monkeypatch.setenv("GS_SPARSE_VERBOSE", "1")
+    if grp == "0":
+        monkeypatch.setenv("GS_SPARSE_BITMAP_GB", "0")
+    elif grp is not None:
+        monkeypatch.setenv("GS_INSERT_GROUP", grp)
+    m, M, efc = 96, 10, 48
+    if data == "families":
+        db = H.synth_sig_db(210, 100, m, 77, jlo=0.05, jhi=0.9)
+    else:
+        db = np.random.default_rng(5).integers(0, 6, (21000, m)).astype(np.float32)
+    oix = O.Index(np.float32, m, M, efc, scale_modify=0.5, seed=6)
+    oix.parallel_insert(db, batch=256)
+    og = oix.export()
+    hn = G.Hnsw.new(M, 100000, 16, efc, G.DistHamming(), seed=6, insert_batch=256)
+    hn.modify_level_scale(0.5); hn.set_extend_candidates(True)
+    for lo in range(0, len(db), 6000):                                   # several insert calls: the lists of earlier calls serve the later ones
+        hn.parallel_insert(db[lo:lo + 6000])
+    err = capfd.readouterr().err
+    last = [l for l in err.splitlines() if l.startswith("[GS_SPARSE]")][-1]
+    f = last.replace(",", " ").replace(":", " ").replace("(", " ").replace(")", " ").replace(";", " ").split()
+    with_list = int(f[f.index("list") + 1]); chunks = int(f[f.index("lists") + 1]); dense_bytes = int(f[f.index("bytes") + 1])
+    assert dense_bytes == 0 and with_list == len(db) and chunks > (10 * len(db) if data == "noise" else 1000), last
+    g = hn.export_graph()
+    assert np.array_equal(g["levels"], og["levels"]) and np.array_equal(g["deg0"], og["deg0"])
+    for i in range(len(db)):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d]) and np.array_equal(g["cnt0"][i, :d], og["cnt0"][i, :d]), i
+
+
+def test_insert_prepass_with_split_bitmap(gpu_ctx, monkeypatch):
+    """the insert pre-pass (k_hnsw_search_dense<.., WLOG>) with the split visited bitmap - what a build beyond ~1.08 M nodes runs (before round 5 the
+    pre-pass was given up there and every point searched by the sorted-array kernel): same graph as the oracle, levels > 0 included"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_DENSE_VIS", "split")
+    monkeypatch.setenv("GS_SPLIT_W", "2048")
+    m, M, efc = 64, 12, 60
+    db = H.synth_sig_db(130, 50, m, 321, jlo=0.05, jhi=0.9)
+    oix = O.Index(np.float32, m, M, efc, scale_modify=1.0, seed=4)
+    oix.parallel_insert(db, batch=256)
+    og = oix.export()
+    hn = G.Hnsw.new(M, 100000, 16, efc, G.DistHamming(), seed=4, insert_batch=256)
+    hn.modify_level_scale(1.0); hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    g = hn.export_graph()
+    assert np.array_equal(g["levels"], og["levels"]) and np.array_equal(g["deg0"], og["deg0"])
+    for i in range(len(db)):
+        d = int(og["deg0"][i])
+        assert np.array_equal(g["nbr0"][i, :d], og["nbr0"][i, :d])
+    q = np.concatenate([H.queries_from(db, 200, 5, frac=0.25), db[:30]])
+    got, want = hn.search_arrays(q, 10, 200), oix.parallel_search(q, 10, 200)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
 
 
 def test_insert_with_join_on_second_stream(gpu_ctx, monkeypatch):
@@ -1120,11 +1192,54 @@ def test_comm_allgather_single_rank(gpu_ctx):
         comm.allgather_topk_dev(d_i, d_d, nq, knbn, d_ai, d_ad)
         assert np.array_equal(ctx.download(d_ai, ids.shape, np.uint64), ids)
         assert np.array_equal(ctx.download(d_ad, dist.shape, np.float32), dist)
-        assert comm.n_ranks == 1 and comm.rank == 0
+        assert comm.n_ranks == 1 and comm.rank == 0 and comm.size() == 1
+        # the unequal-shard form: 37 rows in a block sized for 50, and an empty rank
+        d_bi, d_bd = ctx.alloc(50 * knbn * 8), ctx.alloc(50 * knbn * 4)
+        try:
+            counts = comm.allgatherv_topk_dev(d_i, d_d, nq, 50, knbn, d_bi, d_bd)
+            assert list(counts) == [nq]
+            assert np.array_equal(ctx.download(d_bi, ids.shape, np.uint64), ids) and np.array_equal(ctx.download(d_bd, dist.shape, np.float32), dist)
+            assert list(comm.allgatherv_topk_dev(None, None, 0, 50, knbn, d_bi, d_bd)) == [0]
+        finally:
+            ctx.free(d_bi); ctx.free(d_bd)
     finally:
         for p_ in (d_i, d_d, d_ai, d_ad):
             ctx.free(p_)
         comm.close()
+
+
+@pytest.mark.parametrize("S,nq,kin,kout", [(8, 300, 50, 50), (3, 41, 7, 10), (2, 5, 128, 20), (1, 9, 6, 6)])
+def test_topk_merge_of_db_shards_on_the_device(gpu_ctx, S, nq, kin, kout):
+    """the DB-sharded alternative (scripts/multiple_search.sh:71-107): every shard answers all queries, gs_topk_merge_dev keeps the best under
+    (distance, id) - against the numpy k-way merge of gsearch_amd.sharding, with ties across shards, unused slots (UINT64_MAX / +inf) and local ->
+    global id offsets"""
+    import gsearch_amd as G
+    from gsearch_amd import sharding as Sh
+    ctx = gpu_ctx
+    rng = np.random.default_rng(S * 1000 + nq)
+    per = 100000
+    ids = np.stack([np.sort(rng.choice(per, (nq, kin)), axis=1) for _ in range(S)]).astype(np.uint64)          # local ids
+    dist = np.sort((rng.integers(0, 40, (S, nq, kin)) / np.float32(64)).astype(np.float32), axis=2)               # plenty of ties
+    short = rng.random((S, nq)) < 0.2                                                                              # some lists hold fewer than kin answers
+    for s_ in range(S):
+        for q_ in np.nonzero(short[s_])[0]:
+            cut = int(rng.integers(0, kin))
+            ids[s_, q_, cut:] = np.uint64(0xFFFFFFFFFFFFFFFF); dist[s_, q_, cut:] = np.inf
+    off = (np.arange(S, dtype=np.uint64) * np.uint64(per))
+    glob = np.where(ids == np.uint64(0xFFFFFFFFFFFFFFFF), ids, ids + off[:, None, None])
+    want_i, want_d = Sh.merge_topk_shards([glob[s_] for s_ in range(S)], [dist[s_] for s_ in range(S)], kout)
+    d_i, d_d, d_oi, d_od = ctx.alloc(ids.nbytes), ctx.alloc(dist.nbytes), ctx.alloc(nq * kout * 8), ctx.alloc(nq * kout * 4)
+    try:
+        ctx.upload(d_i, ids); ctx.upload(d_d, dist)
+        G.topk_merge_dev(ctx, d_i, d_d, S, nq, kin, kout, d_oi, d_od, id_offset=off)
+        got_i, got_d = ctx.download(d_oi, (nq, kout), np.uint64), ctx.download(d_od, (nq, kout), np.float32)
+    finally:
+        for p_ in (d_i, d_d, d_oi, d_od):
+            ctx.free(p_)
+    if S * kin < kout:
+        want_i = np.concatenate([want_i, np.full((nq, kout - S * kin), 0xFFFFFFFFFFFFFFFF, np.uint64)], axis=1)
+        want_d = np.concatenate([want_d, np.full((nq, kout - S * kin), np.inf, np.float32)], axis=1)
+    assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)) and np.array_equal(got_i, want_i)
 
 
 @pytest.mark.parametrize("block", [False, True])
