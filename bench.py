@@ -664,6 +664,57 @@ def c5_distance_leg(args, ctx, lib, chk, O):
                "note": "frac = HBM bytes of the memory-side counters / launch time / 8 TB/s (null without a PMC sidecar); the algorithmic rate counts 192 kB per evaluation and, with every "
                        "traversal touching >= 10 % of a 50 000-row index, includes rows re-served by L2 / Infinity Cache - it is NOT an HBM fraction",
                "ids_distances_evals_equal_oracle_16_queries": bool(np.array_equal(oids, ids[:16]) and np.array_equal(odist, dist[:16]) and np.array_equal(oev, ev[:16]))}
+        # ---- configs[4] AT SIZE: 10 000 u64 queries (fresh mutants of the index's families) through the DEFAULT strategy - for a batch
+        # this size the cost model takes the dense one: match-join with 8-byte keys, then the look-up traversal - next to the same request forced through
+        # the row-gather kernel on its first 512 queries; answers of a 16-query sample == oracle, and the two strategies agree on the 512
+        nqs = int(os.environ.get("GS_C5_QUERIES", "10000"))
+        if nqs > 0:
+            for p_ in (d_qx, d_ids, d_dist, d_cnt, d_ev):
+                ctx.free(p_)
+            d_qx = ctx.alloc(nqs * maa * 8)
+            chk(lib.gs_synth_sigs_dev(ctx.h, 2, maa, seed, 6_000_000, nqs, n_roots, 0.3, 0.95, d_qx))
+            d_ids, d_dist, d_cnt, d_ev = ctx.alloc(8 * nqs * 50), ctx.alloc(4 * nqs * 50), ctx.alloc(4 * nqs), ctx.alloc(8 * nqs)
+            if prev_mode is None:
+                os.environ.pop("GS_DIST_MODE", None)
+            else:
+                os.environ["GS_DIST_MODE"] = prev_mode
+            best = None
+            for rep in range(3):
+                ctx.profile(True)
+                for fam in (1, 2):
+                    ctx.profile_read(fam, reset=True)
+                hx.search_stats(reset=True)
+                ctx.sync(); t0 = time.perf_counter()
+                chk(lib.gs_index_parallel_search_dev(hx.h, d_qx, nqs, 50, 5000, d_ids, d_dist, d_cnt, d_ev)); ctx.sync()
+                dt = time.perf_counter() - t0
+                t_ms, t_n = ctx.profile_read(2, reset=True); j_ms, j_n = ctx.profile_read(1, reset=True); ctx.profile(False)
+                st = hx.search_stats(reset=True)
+                if rep and (best is None or dt < best[0]):
+                    best = (dt, t_ms, t_n, j_ms, j_n, st)
+            dt, t_ms, t_n, j_ms, j_n, st = best
+            ids_d = ctx.download(d_ids, (nqs, 50), np.uint64); dist_d = ctx.download(d_dist, (nqs, 50), np.float32); ev_d = ctx.download(d_ev, (nqs,), np.uint64)
+            qh = ctx.download(d_qx, (16, maa), np.uint64)
+            oids, odist, _, oev = oix.parallel_search(qh, 50, 5000, nthreads=host_cpu_budget()[1])
+            os.environ["GS_DIST_MODE"] = "gather"
+            ng = min(512, nqs)
+            d_i2, d_d2, d_c2, d_e2 = ctx.alloc(8 * ng * 50), ctx.alloc(4 * ng * 50), ctx.alloc(4 * ng), ctx.alloc(8 * ng)
+            ctx.profile(True); ctx.profile_read(2, reset=True)
+            ctx.sync(); t0 = time.perf_counter()
+            chk(lib.gs_index_parallel_search_dev(hx.h, d_qx, ng, 50, 5000, d_i2, d_d2, d_c2, d_e2)); ctx.sync()
+            g_dt = time.perf_counter() - t0
+            gg_ms, _ = ctx.profile_read(2, reset=True); ctx.profile(False)
+            same = bool(np.array_equal(ctx.download(d_i2, (ng, 50), np.uint64), ids_d[:ng]) and np.array_equal(ctx.download(d_d2, (ng, 50), np.float32), dist_d[:ng]) and
+                        np.array_equal(ctx.download(d_e2, (ng,), np.uint64), ev_d[:ng]))
+            for p_ in (d_i2, d_d2, d_c2, d_e2):
+                ctx.free(p_)
+            out["request_at_size"] = {
+                "queries": nqs, "strategy_chosen_by_the_cost_model": "dense: match-join (8-byte keys) + look-up traversal" if st["pops"] > 0 else "row gather",
+                "call_ms": dt * 1e3, "queries_per_sec": nqs / dt, "traversal_kernel_ms": t_ms, "traversal_launches": t_n, "count_matrix_kernels_ms": j_ms, "count_matrix_launches": j_n,
+                "join_atomics": int(st["join_atomics"]), "pops_per_query": st["pops"] / nqs, "evals_per_query": float(ev_d.mean()),
+                "row_gather_same_request_first_%d_queries" % ng: {"call_ms": g_dt * 1e3, "kernel_ms": gg_ms, "queries_per_sec": ng / g_dt,
+                                                                   "algorithmic_GBps": float(ev_d[:ng].sum()) * maa * 8 / (gg_ms * 1e-3) / 1e9, "same_ids_distances_evals_as_default": same},
+                "speedup_over_row_gather_per_query": (g_dt / ng) / (dt / nqs),
+                "ids_distances_evals_equal_oracle_16_queries": bool(np.array_equal(oids, ids_d[:16]) and np.array_equal(odist, dist_d[:16]) and np.array_equal(oev, ev_d[:16]))}
         del oix
         hx.close()
         for p_ in (d_qx, d_ids, d_dist, d_cnt, d_ev):

@@ -1909,8 +1909,14 @@ struct gs_index {
     // gs_index_sketch_and_search_dev: the padded query rows are produced batch by batch while the search is under way; dense_counts asks for
     // rows [q0, q0 + nb) of the buffer at feed_base just before it joins them
     std::function<int(uint64_t, uint64_t)> *feed = nullptr; const uint8_t *feed_base = nullptr;
+    // three-stage request pipeline (round 5, GS_REQUEST_PIPELINE=3): the traversal of join batch b runs on this stream beside the count matrix of batch b + 1
+    // and the sketch of batch b + 2 (search_dev, dense strategy)
+    hipStream_t tstream = nullptr; hipEvent_t tev = nullptr, tev_done = nullptr; bool pipe3 = false;
     ~gs_index()
     {
+        if (tstream) { (void)hipStreamSynchronize(tstream); (void)hipStreamDestroy(tstream); }
+        if (tev) (void)hipEventDestroy(tev);
+        if (tev_done) (void)hipEventDestroy(tev_done);
         if (jstream) { (void)hipStreamSynchronize(jstream); (void)hipStreamDestroy(jstream); }
         if (jev) (void)hipEventDestroy(jev);
         if (jev_up) (void)hipEventDestroy(jev_up);
@@ -2351,6 +2357,27 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     QB = std::min<uint64_t>(QB, rest);
     if (ix->mat.bytes < (size_t)2 * QB * ld && (rc = alloc_or_evict(ix, ix->mat, (size_t)2 * QB * ld))) return rc;
     if (join && (rc = ensure_cols(ix, ix->n))) return rc;
+    if (ix->pipe3 && join && done == 0 && QB == nq) {
+        // three stages, batch by batch (the fused request): count matrix of batch b on this stream, its traversal on `tstream` - beside the count matrix of
+        // batch b + 1 here and the sketches the caller queued on its own stream. The traversal scratch (visited / candidate arrays / query counter) is per
+        // index: launches on tstream follow one another.
+        const uint64_t maxq = match_join_max_queries(), parts = (nq + maxq - 1) / maxq, jq = (nq + parts - 1) / parts;
+        struct SGuard { gs_ctx *c; hipStream_t main; ~SGuard() { c->stream = main; } } sg{c, c->stream};
+        for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
+            const uint64_t nb = std::min(jq, nq - q0);
+            if ((rc = dense_counts(ix, q + q0 * ix->stride, nb, ix->n, ix->mat.as<uint16_t>() + q0 * ld, ld))) return rc;
+            GS_HIP_CHECK(hipEventRecord(ix->tev, c->stream));
+            GS_HIP_CHECK(hipStreamWaitEvent(ix->tstream, ix->tev, 0));
+            c->stream = ix->tstream;
+            rc = search_launch(ix, q + q0 * ix->stride, nb, knbn, ef, ix->mat.as<uint16_t>() + q0 * ld, ld, ids + q0 * knbn, dist + q0 * knbn, count ? count + q0 : nullptr,
+                               evals ? evals + q0 : nullptr);
+            c->stream = sg.main;
+            if (rc) return rc;
+        }
+        GS_HIP_CHECK(hipEventRecord(ix->tev_done, ix->tstream));
+        GS_HIP_CHECK(hipStreamWaitEvent(c->stream, ix->tev_done, 0));
+        return GS_OK;
+    }
     for (uint64_t q0 = done; q0 < nq; q0 += QB) {
         const uint64_t nb = std::min(QB, nq - q0);
         if ((rc = dense_counts(ix, q + q0 * ix->stride, nb, ix->n, ix->mat.as<uint16_t>(), ld))) return rc;
@@ -2685,6 +2712,7 @@ int gs_index_sketch_and_search_dev(gs_index *ix, const gs_sketch_params *p, cons
     const char *pe = getenv("GS_REQUEST_PIPELINE");
     const bool pipe = !(pe && !atoi(pe)) && parts >= 2 && (p->algo == GS_ALGO_OPTDENS || p->algo == GS_ALGO_REVOPTDENS) && gs::use_join(ix) &&
                       gs::search_goes_dense(ix, nq, knbn, ef);
+    const bool pipe3 = pipe && pe && atoi(pe) == 3;
     if (!pipe) {
         if ((rc = gs::sketch_dev_impl(c, p, seq_dev, seq_bytes, rec_start_dev, rec_len_dev, n_rec, genome_rec_off_dev, nq, sig, true))) return rc;
         if ((rc = gs::upload_user_rows(ix, dq.p, sig, nq, hipMemcpyDeviceToDevice))) return rc;
@@ -2715,6 +2743,21 @@ int gs_index_sketch_and_search_dev(gs_index *ix, const gs_sketch_params *p, cons
         gs::set_error("event setup failed"); GS_FUSED_FAIL(GS_ERR_HIP);
     }
     w->profile = c->profile;
+    if (pipe3) {
+        // launches shaped to SHARE a compute unit: a sketch workgroup that asks for more than half of the LDS stays alone of its kind on its CU and leaves
+        // room for a traversal workgroup (53.7 kB at 300 k nodes) beside it; the traversal stream gets the highest priority - its workgroups are the
+        // latency-bound ones -, the sketch stream the lowest
+        if (!ix->tstream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&ix->tstream, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&ix->tev, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ix->tev_done, hipEventDisableTiming) != hipSuccess) { gs::set_error("stream setup failed"); GS_FUSED_FAIL(GS_ERR_HIP); }
+        }
+        const char *sl = getenv("GS_PIPE_SKETCH_LDS");
+        w->sketch_min_lds = sl ? (uint32_t)atoi(sl) : 100u * 1024u;
+        ix->pipe3 = true;
+    }
+    struct P3Guard { gs_index *ix; gs_ctx *w; ~P3Guard() { ix->pipe3 = false; w->sketch_min_lds = 0; } } p3guard{ix, w};
     for (uint64_t b = 0; b < parts; b++) {
         const uint64_t g0 = b * jq, nb = std::min<uint64_t>(jq, nq - g0);
         // (seq_bytes only feeds the launch heuristics: this batch's share of it)

@@ -63,6 +63,7 @@ struct gs_ctx {
     std::map<std::thread::id, gs_ctx *> workers; std::mutex workers_mu;
     gs_ctx *parent = nullptr;
     uint64_t last_use = 0, use_tick = 0;   // LRU stamps of the worker table (under workers_mu)
+    uint32_t sketch_min_lds = 0;             // the slot-min sketch kernel asks for at least this much LDS per workgroup (co-residency shaping of the request pipeline; 0 = what it needs)
     uint32_t last_sketch[4] = {0, 0, 0, 0};   // gs_ctx_last_sketch_info: {filtered emitter, slot table in LDS, workgroups per genome, launches} of the last slot-min sketch call
     // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
     // and parallel_search through &self from many threads (dnasketch.rs:252,305,322): every entry point that touches the stream or the

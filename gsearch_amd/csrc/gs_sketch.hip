@@ -597,7 +597,8 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
 #define GS_LAUNCH_MIN(AAV, LDSV, FV)                                                                                    \
     do {                                                                                                                \
         auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T, FV>;                                                        \
-        const size_t l = LDSV ? (FV ? lds_f : lds) : ((size_t)2 * m + 15) & ~(size_t)15;      /* slot table (+ survivor queues), or its 2-byte filter */  \
+        const size_t l0_ = LDSV ? (FV ? lds_f : lds) : ((size_t)2 * m + 15) & ~(size_t)15;    /* slot table (+ survivor queues), or its 2-byte filter */  \
+        const size_t l = std::min<size_t>(std::max<size_t>(l0_, c->sketch_min_lds), 160 * 1024 - 256);                                       \
         if (l > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
         hipLaunchKernelGGL(kern, grid, block, l, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, kq_of(p), m, zone, tab); \
     } while (0)

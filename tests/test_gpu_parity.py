@@ -801,13 +801,13 @@ def test_insert_with_sparse_pair_rows_builds_the_oracle_graph(gpu_ctx, monkeypat
     og = oix.export()
     hn = G.Hnsw.new(M, 100000, 16, efc, G.DistHamming(), seed=6, insert_batch=256)
     hn.modify_level_scale(0.5); hn.set_extend_candidates(True)
-    for lo in range(0, len(db), 6000):                                   # several insert calls: the lists of earlier calls serve the later ones
-        hn.parallel_insert(db[lo:lo + 6000])
+    for lo in range(0, len(db), 6144):                                   # several insert calls (whole batches each: the graph depends on the batch boundaries): the lists of earlier calls serve the later ones
+        hn.parallel_insert(db[lo:lo + 6144])
     err = capfd.readouterr().err
     last = [l for l in err.splitlines() if l.startswith("[GS_SPARSE]")][-1]
     f = last.replace(",", " ").replace(":", " ").replace("(", " ").replace(")", " ").replace(";", " ").split()
     with_list = int(f[f.index("list") + 1]); chunks = int(f[f.index("lists") + 1]); dense_bytes = int(f[f.index("bytes") + 1])
-    assert dense_bytes == 0 and with_list == len(db) and chunks > (10 * len(db) if data == "noise" else 1000), last
+    assert dense_bytes == 0 and with_list == len(db) and chunks > (len(db) if data == "noise" else 1000), last
     g = hn.export_graph()
     assert np.array_equal(g["levels"], og["levels"]) and np.array_equal(g["deg0"], og["deg0"])
     for i in range(len(db)):

@@ -35,11 +35,29 @@ def separate():
     chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, nq, knbn, ef, *outs[0]))
 def fused():
     hn.sketch_and_search_dev(prm, d_seq, nq * gb + 64, d_rs, d_rl, nq, d_go, nq, knbn, ef, *outs[1], d_sig=d_qsig)
-for name, fn in (("two calls", separate), ("one call ", fused), ("two calls", separate), ("one call ", fused)):
+# further arguments: environment variants of the one-call form ("GS_REQUEST_PIPELINE=3,GS_PIPE_SKETCH_LDS=102400" ...), each timed and compared with the two calls
+variants = sys.argv[4:] or [""]
+shapes = ((nq, knbn), (nq, knbn), (nq,), (nq,)); dts = (np.uint64, np.uint32, np.uint32, np.uint64)
+def timeit(fn):
     best = None
     for r in range(reps):
         ctx.sync(); t0 = time.perf_counter(); fn(); ctx.sync(); dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
-    print("%s: %.1f ms per %d-query request (%.0f genomes/s)" % (name, best * 1e3, nq, nq / best), flush=True)
-same = all(np.array_equal(ctx.download(a, s, d), ctx.download(b, s, d)) for a, b, s, d in zip(outs[0], outs[1], ((nq, knbn), (nq, knbn), (nq,), (nq,)), (np.uint64, np.uint32, np.uint32, np.uint64)))
-print("same answers:", same)
+    return best
+b = timeit(separate)
+print("two calls: %.1f ms per %d-query request (%.0f genomes/s)" % (b * 1e3, nq, nq / b), flush=True)
+ref = [ctx.download(a, s_, d) for a, s_, d in zip(outs[0], shapes, dts)]
+for v in variants:
+    saved = {}
+    for kv in [x for x in v.split(",") if x]:
+        k_, val = kv.split("="); saved[k_] = os.environ.get(k_); os.environ[k_] = val
+    for a in outs[1]:
+        lib.gs_dev_memset(ctx.h, a, 0, 4 * nq)
+    b = timeit(fused)
+    same = all(np.array_equal(ctx.download(a, s_, d), r_) for a, s_, d, r_ in zip(outs[1], shapes, dts, ref))
+    print("one call [%s]: %.1f ms per %d-query request (%.0f genomes/s)  same answers: %s" % (v or "defaults", b * 1e3, nq, nq / b, same), flush=True)
+    for k_, old in saved.items():
+        if old is None: os.environ.pop(k_, None)
+        else: os.environ[k_] = old
+b = timeit(separate)
+print("two calls: %.1f ms per %d-query request (%.0f genomes/s)" % (b * 1e3, nq, nq / b), flush=True)
