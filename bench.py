@@ -187,20 +187,25 @@ def sketch_valu_model(kmers_per_sec):
     tools/ubench_valu -> profiles/r02_sketch_isa_mix.json); the instruction COUNT per k-mer is the one rocprofv3 measured for this very
     workload (SQ_INSTS_VALU, tools/pmc_sketch.sh -> profiles/r02_sketch_pmc.json), because the filtered emitter drops most k-mers after
     two of the three SplitMix64 mixes and its work per k-mer depends on the data."""
-    path = os.path.join(ROOT, "profiles", "r02_sketch_isa_mix.json")
-    if not os.path.exists(path):
+    import glob
+    def newest(pattern):                                   # the latest round's file (r05_... sorts after r02_...)
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return f[-1] if f else None
+    path = newest("r0*_sketch_isa_mix.json")
+    if not path:
         return None
     mix = json.load(open(path))
     cyc_per_instr = mix["issue_cycles_per_kmer"] / mix["valu_per_kmer"]       # mean issue cycles of a VALU instruction of this mix (wave64)
     valu, src = mix["valu_per_kmer"], "static ISA count of the unfiltered loop"
-    pmc = os.path.join(ROOT, "profiles", "r02_sketch_pmc.json")
-    if os.path.exists(pmc):
-        valu, src = json.load(open(pmc))["valu_wave_instr_per_64_kmers"], "SQ_INSTS_VALU of profiles/r02_sketch_pmc.json"
+    pmc = newest("r0*_sketch_pmc.json")
+    if pmc:
+        pj = json.load(open(pmc))
+        valu, src = pj["valu_wave_instr_per_64_kmers"], "SQ_INSTS_VALU of profiles/%s (taken at %s)" % (os.path.basename(pmc), pj.get("head") or "an earlier commit")
     cyc = valu * cyc_per_instr
     peak = SIMDS * CLOCK_HZ / cyc * 64                     # k-mers/s if every SIMD issued nothing but this stream
     return {"bound": "valu", "valu_wave_instr_per_64_kmers": valu, "valu_wave_instr_per_64_kmers_full_hash": mix["valu_per_kmer"],
             "mean_issue_cycles_per_valu_instr": cyc_per_instr, "kmers_per_sec_at_issue_ceiling": peak, "frac": kmers_per_sec / peak,
-            "source": "instruction count: %s; issue costs: profiles/r02_sketch_isa_mix.json + profiles/r02_ubench_valu.txt" % src}
+            "source": "instruction count: %s; issue costs: profiles/%s + profiles/r02_ubench_valu.txt" % (src, os.path.basename(path))}
 
 
 def run_sketch(args, D):

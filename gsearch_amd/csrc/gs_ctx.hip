@@ -474,6 +474,7 @@ __global__ void k_synth_sigs(uint32_t m, uint64_t seed, uint64_t r0, uint64_t nr
         uint64_t v = keep ? rootv : ownv;
         if (KIND == GS_KIND_F32) ((float *)out)[i] = (float)(uint32_t)(v >> 41) * 0x1.0p-23f;
         else if (KIND == GS_KIND_U32) ((uint32_t *)out)[i] = (uint32_t)(v >> 32);
+        else if (KIND == GS_KIND_U16) ((uint16_t *)out)[i] = (uint16_t)(v >> 48);       // (SetSketch-like registers: unrelated rows agree in 1 of 65 536 slots)
         else ((uint64_t *)out)[i] = v;
     }
 }
@@ -521,6 +522,7 @@ int gs_synth_sigs_dev(gs_ctx *c, int kind, uint32_t m, uint64_t seed, uint64_t r
     if (kind == GS_KIND_F32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_F32>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
     else if (kind == GS_KIND_U32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U32>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
     else if (kind == GS_KIND_U64) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U64>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
+    else if (kind == GS_KIND_U16) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U16>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
     else GS_REQUIRE(false, GS_ERR_INVALID, "unsupported kind %d", kind);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;

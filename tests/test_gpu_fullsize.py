@@ -212,3 +212,53 @@ def test_sketch_and_search_in_one_call(gpu_ctx, monkeypatch, pipeline):
             hn.close()
         for p_ in [d_seq, d_rs, d_rl, d_go, d_sig, d_qsig, d_qsig2] + outs[0] + outs[1]:
             ctx.free(p_)
+
+
+@pytest.mark.parametrize("kind,m,n,n_roots,nq,M,efc,ef", [("f32", 2000, 20_000, 200, 2048, 32, 200, 500), ("u16", 4096, 100_000, 1000, 2048, 48, 400, 1000),
+                                                             ("f32", 18000, 300_000, 3000, 1024, 128, 1600, 5000)])
+def test_cost_model_picks_a_strategy_close_to_the_better_one(gpu_ctx, monkeypatch, kind, m, n, n_roots, nq, M, efc, ef):
+    """`auto` (dense_pays(): match-join + look-up traversal against row streaming) at three operating points - a small index of short
+    f32 sketches, a u16 (SetSketch) index, and the headline shape. Each strategy is timed on the same batch (second call); `auto` must give the same
+    answers and may cost at most 1.3x the better of the two forced strategies (+ 2 ms: at the small point a whole search is a few milliseconds)."""
+    import time
+    import gsearch_amd as G
+    ctx, lib, chk = gpu_ctx, gpu_ctx.L, G._lib.check
+    kid, dt, esz = (G._lib.KIND_F32, np.float32, 4) if kind == "f32" else (G._lib.KIND_U16, np.uint16, 2)
+    d_db, d_q = ctx.alloc(n * m * esz), ctx.alloc(nq * m * esz)
+    hn = None
+    try:
+        chk(lib.gs_synth_sigs_dev(ctx.h, kid, m, 99, 0, n, n_roots, 0.3, 0.99, d_db))
+        chk(lib.gs_synth_sigs_dev(ctx.h, kid, m, 99, 7_000_000, nq, n_roots, 0.3, 0.99, d_q))
+        hn = G.Hnsw.new(M, n, 16, efc, G.DistHamming(ctx), dtype=dt, seed=5, insert_batch=256, ctx=ctx)
+        hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+        hn._ensure(m)
+        for g0 in range(0, n, 8192):
+            chk(lib.gs_index_parallel_insert_dev(hn.h, d_db + g0 * m * esz, min(8192, n - g0)))
+        ctx.free(d_db); d_db = None
+        outs = [ctx.alloc(8 * nq * 50), ctx.alloc(4 * nq * 50), ctx.alloc(4 * nq), ctx.alloc(8 * nq)]
+        times, answers = {}, {}
+        try:
+            for mode in ("gather", "dense", "auto", "gather", "dense", "auto"):         # second round = the timings (first: allocations, the model's probe)
+                if mode == "auto":
+                    monkeypatch.delenv("GS_DIST_MODE", raising=False)
+                else:
+                    monkeypatch.setenv("GS_DIST_MODE", mode)
+                ctx.sync(); t0 = time.perf_counter()
+                chk(lib.gs_index_parallel_search_dev(hn.h, d_q, nq, 50, ef, *outs)); ctx.sync()
+                times[mode] = time.perf_counter() - t0
+                answers[mode] = (ctx.download(outs[0], (nq, 50), np.uint64), ctx.download(outs[1], (nq, 50), np.float32), ctx.download(outs[3], (nq,), np.uint64))
+        finally:
+            for p_ in outs:
+                ctx.free(p_)
+        print("cost model at %s m=%d n=%d nq=%d: gather %.1f ms, dense %.1f ms, auto %.1f ms" % (kind, m, n, nq, times["gather"] * 1e3, times["dense"] * 1e3, times["auto"] * 1e3))
+        for mode in ("dense", "auto"):
+            for a, b in zip(answers[mode], answers["gather"]):
+                assert np.array_equal(a, b), mode
+        assert times["auto"] <= 1.3 * min(times["gather"], times["dense"]) + 2e-3, times
+    finally:
+        if hn is not None:
+            hn.close()
+        for p in (d_db, d_q):
+            if p:
+                ctx.free(p)
+        ctx.release_scratch()

@@ -21,6 +21,7 @@ ap.add_argument("--per-root", type=int, default=100)
 ap.add_argument("--genome-len", type=int, default=5_000_000)
 ap.add_argument("--report", type=int, default=131072)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--variants", nargs="*", default=[""], help='environment variants of the final request ("GS_DENSE_VIS=global" "GS_SPLIT_PER_CU=1" ...)')
 a = ap.parse_args()
 
 ctx = G.Context(0)
@@ -66,7 +67,13 @@ ctx.free(d_rows)
 for p_ in (d_seq, d_rs, d_rl, d_go):
     ctx.free(p_)
 q = ctx.download(d_q, (a.nq, a.m), np.float32)
-for rep in range(a.reps):
+base = None
+for v in a.variants:
+  saved = {}
+  for kv in [x for x in v.split(",") if x]:
+      k_, val = kv.split("="); saved[k_] = os.environ.get(k_); os.environ[k_] = val
+  print("request variant [%s]" % (v or "defaults"), flush=True)
+  for rep in range(a.reps):
     ctx.profile(True)
     for f in range(4):
         ctx.profile_read(f, reset=True)
@@ -77,5 +84,11 @@ for rep in range(a.reps):
     srch = ctx.profile_read(2, reset=True)
     ctx.profile(False)
     st = hn.search_stats(reset=True)
-    print("request of %d queries at %d nodes: call %.1f ms, traversal kernel %.2f ms; pops/q %.0f (phase 1 %.0f) evals/q %.0f wg %d" %
-          (a.nq, a.n, dt * 1e3, srch[0], st["pops"] / a.nq, st["pops_phase1"] / a.nq, res[3].mean(), st["wg_in_flight"]), flush=True)
+    same = "-" if base is None else str(all(np.array_equal(x, y) for x, y in zip(res, base)))
+    print("request of %d queries at %d nodes: call %.1f ms, traversal kernel %.2f ms; pops/q %.0f (phase 1 %.0f) evals/q %.0f wg %d  same answers as the first variant: %s" %
+          (a.nq, a.n, dt * 1e3, srch[0], st["pops"] / a.nq, st["pops_phase1"] / a.nq, res[3].mean(), st["wg_in_flight"], same), flush=True)
+  if base is None:
+      base = res
+  for k_, old in saved.items():
+      if old is None: os.environ.pop(k_, None)
+      else: os.environ[k_] = old

@@ -4,7 +4,7 @@ interior-word fast loop of k_sketch_min<DNA, LDS table, optdens, 64-bit values, 
 the unrolled-by-2 loop that carries the fewest 64-bit compares, i.e. no bounds test) and counts instructions per class. Issue cycles per
 wave64 instruction: simple VALU 2 (MI355X_MICROARCH.md:52-54); 32-bit integer multiplies / v_mad_u64_u32 weighted by the ratio measured by
 tools/ubench_valu (profiles/r02_ubench_valu.txt) when that file is given, else the quarter-rate assumption (x4).
-usage: isa_mix.py [ubench_valu.txt] > profiles/r02_sketch_isa_mix.json"""
+usage: isa_mix.py [ubench_valu.txt] > profiles/r05_sketch_isa_mix.json"""
 import collections, json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,7 @@ asm = os.path.join(tempfile.gettempdir(), "gs_sketch_isa.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", asm, src],
                       stderr=subprocess.DEVNULL)
 text = open(asm).read()
-a = text.index("_ZN2gs12k_sketch_minILb0ELb1ELi4ELi64EjEE")
+a = text.index("_ZN2gs12k_sketch_minILb0ELb1ELi4ELi64EjLb0EEE")      # <DNA, LDS table, optdens, 64-bit values, u32 keys, unfiltered emitter>
 body = text[a:text.index("s_endpgm", a)].splitlines()
 ins = [l.split()[0] for l in body if l.startswith("\t") and l.strip() and not l.strip().startswith((";", "."))]
 mins = [i for i, op in enumerate(ins) if op == "ds_min_u32"]
