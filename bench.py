@@ -208,6 +208,35 @@ def sketch_valu_model(kmers_per_sec):
             "source": "instruction count: %s; issue costs: profiles/%s + profiles/r02_ubench_valu.txt" % (src, os.path.basename(path))}
 
 
+def join_valu_model(elements_per_launch, batch_ms):
+    """the instruction budget of k_match_join per (slot, node) element, from the SQ counters of the request-time launches (tools/pmc_any.sh over
+    `bench.py --steps 1`, condensed in profiles/r0*_step_sq_counters.txt): measured lane-instructions per element against a hand count of what one element needs,
+    and how busy VALU issue is - the kernel is priced against the memory-side atomics (frac_of_atomics_ceiling), not against VALU."""
+    import glob
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_step_sq_counters.txt")))
+    if not f:
+        return None
+    vals = {}
+    for line in open(f[-1], errors="replace"):
+        if "k_match_join<3, unsigned int, 1, false>" in line and "grid=4194304" in line:
+            p = line.split()
+            name = [x for x in p if x.startswith(("SQ_", "GRBM", "FETCH", "WRITE"))]
+            if name:
+                vals[name[0]] = float(line.rsplit("mean=", 1)[1])
+    if "SQ_INSTS_VALU" not in vals:
+        return None
+    el = 18000.0 * 300000.0 * (18000 - 48) / 18000                 # the launch the counters were taken on: slots 48.. of 300 000 nodes
+    valu, salu, lds = vals["SQ_INSTS_VALU"] * 64 / el, vals.get("SQ_INSTS_SALU", 0) * 64 / el, vals.get("SQ_INSTS_LDS", 0) * 64 / el
+    issue_ms = vals["SQ_INSTS_VALU"] * 4.2 / (SIMDS * CLOCK_HZ) * 1e3                    # ~4.2 cycles per wave64 VALU instruction of this mix (profiles/r02_ubench_valu.txt)
+    return {"source": os.path.basename(f[-1]), "valu_lane_instr_per_element": valu, "salu_wave_instr_x64_per_element": salu, "lds_lane_instr_per_element": lds,
+            "necessary_valu_per_element_hand_count": 32,
+            "hand_count": "bitmap filter 10 (hash multiply, word index, LDS read, two bit tests, mask) + next value's load / validity 2 + table build amortised over the 8 values a lane "
+                          "owns per slot: clear 3, 2.4 inserts x ~40 / 8 = 12 + ~7 % survivors x ~60 (queue entry, probe chain, accumulator rule) = 4 + loop 1 = 32; the other half "
+                          "is the survivor queue's push / pop (eight ballot + mbcnt sequences each, executed by every lane of a wavefront that has ONE survivor)",
+            "valu_issue_ms_per_launch_at_4.2_cycles": issue_ms, "valu_issue_frac_of_batch_time": issue_ms / batch_ms if batch_ms else None,
+            "note": "VALU issue is about half busy: the binding resource is the memory-side atomic unit (frac_of_atomics_ceiling); halving the queue's instructions would not shorten the launch"}
+
+
 def run_sketch(args, D):
     import ctypes as C
     import gsearch_amd as G
@@ -521,6 +550,7 @@ def request_accounting(args, ctx, hn, lib, chk, torch, D, r):
                        "atomics_uniform_random_slab_per_sec": ATOMICS_SLAB,
                        "traffic": pmc_traffic("k_match_join")})
             kd["achieved_GBps"] = kd["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            kd["valu_model"] = join_valu_model(float(N) * (m - 48) , avg_ms)
         else:
             valu_peak = SIMDS * 64 / (2 * 2.0) * CLOCK_HZ                      # 2 VALU instr per pair-element, 2 cycles per wave64 instr
             kd.update({"class": "valu", "pair_elements_per_sec": pairs_total * m / (tile_ms * 1e-3), "valu_peak_pair_elements_per_sec": valu_peak,

@@ -894,7 +894,12 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 if (hl < pdeg) {
                     const uint32_t bit = 1u << (id & 31);
                     uint32_t old;
-                    if (SPLIT && id >= vis_w) old = __hip_atomic_fetch_or(&visg[(id - vis_w) >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (SPLIT && id >= vis_w) {
+                        // a hint that saw the bit SET is never stale (bits only get set): more than half of the neighbours of a flood-regime pop are
+                        // visited already, and each of them would otherwise be a memory-side atomic - phase 1 of a large index is bound by those
+                        if (pst == 2 && !pclr) old = bit;
+                        else old = __hip_atomic_fetch_or(&visg[(id - vis_w) >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     else if (VLDS) old = atomicOr(&vis[id >> 5], bit);
                     else old = __hip_atomic_fetch_or(&vis[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     unv = !(old & bit);
@@ -2161,12 +2166,16 @@ static bool dense_vis_in_lds(const gs_index *ix, uint32_t knbn, uint32_t maxdeg)
 // SPLIT placement (round 5): the LDS bitmap maps node ids [0, W), this workgroup's global scratch the rest. W = what lets `per_cu` workgroups share a
 // CU (GS_SPLIT_PER_CU, default 2; GS_SPLIT_W overrides W itself - tests), a multiple of 1024; 0 = not possible / not wanted. Taken whenever the
 // whole bitmap does not fit the LDS (GS_DENSE_VIS=global keeps the round-4 all-global form, GS_DENSE_VIS=split forces the split at any size).
-static uint32_t dense_split_w(const gs_index *ix, uint32_t knbn, uint32_t maxdeg, uint32_t dcn, size_t min_bytes = 0)
+static uint32_t dense_split_w(const gs_index *ix, uint32_t knbn, uint32_t maxdeg, uint32_t dcn, size_t min_bytes = 0, bool many_queries = false)
 {
     const char *e = getenv("GS_DENSE_VIS");
     const bool forced = e && !strcmp(e, "split");
     if (e && !forced) { if (!strcmp(e, "global") || !strcmp(e, "lds")) return 0; }
-    if (!forced && dense_vis_in_lds(ix, knbn, maxdeg)) return 0;
+    // a request of many queries also takes the split form where the whole bitmap WOULD fit the LDS but only with one workgroup per CU (~600 k - 1.2 M nodes):
+    // two workgroups per CU with the upper ids behind the Bloom filter beat one with everything in LDS (1 M nodes, 10 000 queries: 101.6 against 121.4 ms,
+    // profiles/r05_request_1M_placements.log). The insert pre-pass (256 points per batch: one workgroup per CU anyway) keeps the plain form.
+    const bool one_per_cu = many_queries && round_up(dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, true, dcn), 1280) > (size_t)(160 * 1024 / 2);
+    if (!forced && !one_per_cu && dense_vis_in_lds(ix, knbn, maxdeg)) return 0;
     const size_t base = std::max(dense_lds_bytes(ix->prm.m, knbn, maxdeg, 0, true, dcn), min_bytes);
     int per = getenv("GS_SPLIT_PER_CU") ? std::max(1, std::min(3, atoi(getenv("GS_SPLIT_PER_CU")))) : 2;
     uint64_t w = 0;
@@ -2186,7 +2195,7 @@ static int search_launch_dense(gs_index *ix, uint64_t nq, uint32_t knbn, uint32_
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
     const bool oneg = maxdeg > (uint32_t)DT / 2;                       // rows of more than 256 ids: one 512-lane group instead of two halves
     const uint32_t dcn = oneg ? 512u : (uint32_t)DCN;
-    const uint32_t vis_w = dense_split_w(ix, knbn, maxdeg, dcn);
+    const uint32_t vis_w = dense_split_w(ix, knbn, maxdeg, dcn, 0, nq >= (uint64_t)2 * c->n_cu);
     const bool split = vis_w != 0;
     const bool vlds = split || dense_vis_in_lds(ix, knbn, maxdeg);
     const size_t lds = dense_lds_bytes(ix->prm.m, knbn, maxdeg, split ? (uint64_t)vis_w : ix->n, vlds, dcn);

@@ -81,12 +81,12 @@ for v in a.variants:
     t = time.perf_counter()
     res = hn.search_arrays(q, a.knbn, a.ef)
     dt = time.perf_counter() - t
-    srch = ctx.profile_read(2, reset=True)
+    srch = ctx.profile_read(2, reset=True); joink = ctx.profile_read(1, reset=True)
     ctx.profile(False)
     st = hn.search_stats(reset=True)
     same = "-" if base is None else str(all(np.array_equal(x, y) for x, y in zip(res, base)))
-    print("request of %d queries at %d nodes: call %.1f ms, traversal kernel %.2f ms; pops/q %.0f (phase 1 %.0f) evals/q %.0f wg %d  same answers as the first variant: %s" %
-          (a.nq, a.n, dt * 1e3, srch[0], st["pops"] / a.nq, st["pops_phase1"] / a.nq, res[3].mean(), st["wg_in_flight"], same), flush=True)
+    print("request of %d queries at %d nodes: call %.1f ms, count-matrix kernels %.1f ms in %d launches, traversal kernel %.2f ms; pops/q %.0f (phase 1 %.0f) evals/q %.0f wg %d  same answers as the first variant: %s" %
+          (a.nq, a.n, dt * 1e3, joink[0], joink[1], srch[0], st["pops"] / a.nq, st["pops_phase1"] / a.nq, res[3].mean(), st["wg_in_flight"], same), flush=True)
   if base is None:
       base = res
   for k_, old in saved.items():
