@@ -16,6 +16,7 @@
 // search_layer in closed form and merge the accepted keys into R and C with one in-LDS parallel merge.
 #include <algorithm>
 #include <functional>
+#include <chrono>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1964,6 +1965,12 @@ static int index_reserve(gs_index *ix, uint64_t need, uint64_t need_upper)
     const uint32_t M = ix->prm.max_nb_conn, ML = ix->prm.max_layer;
     if (need > ix->cap) {
         uint64_t ncap = std::max<uint64_t>(need, std::max<uint64_t>(ix->cap + ix->cap / 2, 1024));
+        // never past the capacity the caller declared (hnsw_params.capacity, 1.5 M in gsearch) while the points still fit it: the last growth step of a large index
+        // is the one that decides whether it fits the device at all
+        if (ix->prm.capacity >= need && ncap > ix->prm.capacity) ncap = ix->prm.capacity;
+        // the column copy is rebuilt from the rows at the new capacity anyway (ensure_cols): give it back BEFORE the rows are copied - at 1 M+ genomes the old and
+        // the new signature block next to it would not fit otherwise
+        if (ix->cols.p && (uint64_t)ix->stride * ncap > ((uint64_t)8 << 30)) { ix->cols.release(); ix->cols_cap = 0; ix->cols_n = 0; }
         struct Arr { DevBuf *b; size_t per; };
         std::vector<Arr> arr = {
             {&ix->data, (size_t)ix->stride}, {&ix->levels, 1}, {&ix->deg0, 4}, {&ix->nbr0, (size_t)8 * M}, {&ix->cnt0, (size_t)8 * M}, {&ix->upidx, 4}, {&ix->rowptr, 8}};
@@ -2358,13 +2365,19 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     uint64_t budget = (uint64_t)4 << 30;
     {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::max<uint64_t>(budget, std::min<uint64_t>((uint64_t)32 << 30, (uint64_t)fr / 4 + ix->mat.bytes));
+        // (round 5: 0.7 of what is free or already held by the matrix, not a quarter of the free memory plus what is held - at 1 M nodes that grew the buffer
+        // from call to call, 10.8 -> 15.6 -> 19.2 -> 20 GB, and every growth is a hipFree + hipMalloc of ~0.45 s: profiles/r05_request_1M_matrix_realloc.log)
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::max<uint64_t>(budget, std::min<uint64_t>((uint64_t)32 << 30, (uint64_t)(0.7 * (double)((uint64_t)fr + ix->mat.bytes))));
     }
     uint64_t QB = budget / (2 * ld);
     QB = std::max<uint64_t>(128, QB / 128 * 128);
     if (getenv("GS_SEARCH_QB")) QB = std::min<uint64_t>(QB, (uint64_t)std::max(1, atoi(getenv("GS_SEARCH_QB"))));
     QB = std::min<uint64_t>(QB, rest);
+    const bool sv = getenv("GS_SEARCH_VERBOSE") != nullptr;
+    const auto sv_t0 = std::chrono::steady_clock::now();
+    if (sv) { size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot); fprintf(stderr, "[GS_SEARCH] nq %llu n %llu: QB %llu, count matrix %.2f GB wanted, %.2f GB held, device free %.2f GB\n", (unsigned long long)nq, (unsigned long long)ix->n, (unsigned long long)QB, 2.0 * QB * ld / 1e9, ix->mat.bytes / 1e9, fr / 1e9); }
     if (ix->mat.bytes < (size_t)2 * QB * ld && (rc = alloc_or_evict(ix, ix->mat, (size_t)2 * QB * ld))) return rc;
+    if (sv) fprintf(stderr, "[GS_SEARCH] count matrix ready after %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sv_t0).count());
     if (join && (rc = ensure_cols(ix, ix->n))) return rc;
     if (ix->pipe3 && join && done == 0 && QB == nq) {
         // three stages, batch by batch (the fused request): count matrix of batch b on this stream, its traversal on `tstream` - beside the count matrix of
@@ -2390,8 +2403,10 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     for (uint64_t q0 = done; q0 < nq; q0 += QB) {
         const uint64_t nb = std::min(QB, nq - q0);
         if ((rc = dense_counts(ix, q + q0 * ix->stride, nb, ix->n, ix->mat.as<uint16_t>(), ld))) return rc;
+        if (sv) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[GS_SEARCH] count matrix of %llu queries done at %.1f ms\n", (unsigned long long)nb, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sv_t0).count()); }
         if ((rc = search_launch(ix, q + q0 * ix->stride, nb, knbn, ef, ix->mat.as<uint16_t>(), ld, ids + q0 * knbn, dist + q0 * knbn,
                                 count ? count + q0 : nullptr, evals ? evals + q0 : nullptr))) return rc;
+        if (sv) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[GS_SEARCH] traversal done at %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sv_t0).count()); }
     }
     return GS_OK;
 }
