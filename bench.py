@@ -315,7 +315,7 @@ def run_sketch(args, D):
 
 
 _PMC = None
-PMC_DEFAULTS = ("profiles/r04_pmc_sidecar.json", "profiles/r03_pmc_sidecar.json", "profiles/r02_pmc_sidecar.json")
+PMC_DEFAULTS = ("profiles/r05_pmc_sidecar.json", "profiles/r04_pmc_sidecar.json", "profiles/r03_pmc_sidecar.json", "profiles/r02_pmc_sidecar.json")
 
 
 def _pmc_load():

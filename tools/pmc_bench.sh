@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON the GPU box (through gpurun, from the repo root): kernel stats + HBM traffic counters of the bench command, then the bench itself with the
 # sidecar so that roofline.traffic is measured by THIS session. Counters are collected in their own passes (--kernel-trace only, never with other
-# trace domains). usage: tools/pmc_bench.sh [round tag, default r04]
+# trace domains). usage: tools/pmc_bench.sh [round tag, default r05]
 # Outputs under gpurun_out/: <tag>_kernel_stats.csv, <tag>_pmc_sidecar.json, <tag>_pmc_raw.csv, <tag>_bench_request.log, <tag>_bench_sketch.log
-T=${1:-r04}
+T=${1:-r05}
 R=$(pwd)
 export TMPDIR=/tmp
 export GS_HEAD=$(cat $R/.head 2>/dev/null)
