@@ -166,11 +166,15 @@ template <int ALGO, int VBITS, typename T> __device__ __forceinline__ void emit_
 
 // The streaming part shared by every sketcher. walk_unit: flat unit f of a genome (32 symbols: one packed word of DNA, 32 bytes of AA) ->
 // emit(v) for each valid canonical k-mer value that starts... ends in it; walk_genome: the units of genome g assigned to this workgroup.
-template <bool AA, class Emit>
+// RCM: how the strand rule reaches the loop - 2 = at run time through rc_or (every sketcher but the hot one), 0 / 1 = compiled in (canonical / forward only):
+// k_sketch_min is VALU-issue bound and the run-time form turns its two v_or_b32 per k-mer into three-operand v_or3_b32, which issue 1.6x slower
+// (profiles/r02_ubench_valu.txt: 1.75 against 1.08 ns) - 115.7 instead of 112.5 ms per 10 000 genomes (profiles/r05_bench_request_rc_runtime.log)
+template <bool AA, class Emit, int RCM = 2>
 __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
                                           const uint64_t *__restrict__ rec_upre, uint64_t r0, uint64_t r1, uint64_t f, uint32_t k, uint64_t mask, uint32_t rcshift,
-                                          uint64_t rc_or, const Emit &emit)
+                                          uint64_t rc_or_rt, const Emit &emit)
 {
+    const uint64_t rc_or = RCM == 0 ? (uint64_t)0 : RCM == 1 ? ~(uint64_t)0 : rc_or_rt;
     {
         // record owning flat unit f: last r in [r0,r1) with rec_upre[r] <= f
         uint64_t lo = r0, hi = r1;
@@ -257,7 +261,7 @@ __device__ __forceinline__ uint32_t kq_k(uint32_t kq) { return kq & 0xFFu; }
 __device__ __forceinline__ uint64_t kq_rc_or(uint32_t kq) { return (kq & KQ_FWD) ? ~(uint64_t)0 : (uint64_t)0; }
 static inline uint32_t kq_of(const gs_sketch_params *p) { return p->k | (p->data_t == GS_DATA_DNA_FWD ? (uint32_t)KQ_FWD : 0u); }
 __device__ __forceinline__ uint64_t kmer_mask(bool aa, uint32_t k) { return aa ? (((uint64_t)1 << (5 * k)) - 1) : (k == 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1)); }
-template <bool AA, class Emit>
+template <bool AA, class Emit, int RCM = 2>
 __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
                                             const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
                                             uint64_t r0, uint64_t r1, uint64_t units, uint32_t kq, uint32_t part,
@@ -267,12 +271,12 @@ __device__ __forceinline__ void walk_genome(const uint8_t *__restrict__ seq, con
     const uint64_t mask = kmer_mask(AA, k), rc_or = kq_rc_or(kq);
     const uint32_t rcshift = 2 * (k - 1);
     for (uint64_t f = (uint64_t)part * blockDim.x + threadIdx.x; f < units; f += (uint64_t)parts * blockDim.x)
-        walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, emit);
+        walk_unit<AA, Emit, RCM>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, emit);
     emit_finish(emit);
 }
 
 // ---- main kernel of optdens / revoptdens / super / super2: per-slot minimum over all k-mers (SPEC 3.1, 3.2 level 0)
-template <bool AA, bool LDS_TABLE, int ALGO, int VBITS, typename T, bool FILT>
+template <bool AA, bool LDS_TABLE, int ALGO, int VBITS, typename T, bool FILT, int RCM = 0>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
                                                             const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
                                                             const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
@@ -296,10 +300,10 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__rest
     if (FILT) {
         uint64_t *qbase = (uint64_t *)(s_raw_table + (((size_t)m * sizeof(T) + 15) & ~(size_t)15));
         MinEmitF<ALGO, VBITS, T> emit{table, m, zone, qbase + (threadIdx.x >> 6) * SKQ, threadIdx.x & 63, 0u, 0u, EMPTY};
-        walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
+        walk_genome<AA, MinEmitF<ALGO, VBITS, T>, RCM>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
     } else {
         MinEmit<ALGO, VBITS, T, LDS_TABLE> emit{table, m, zone, s_bound};
-        walk_genome<AA>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
+        walk_genome<AA, MinEmit<ALGO, VBITS, T, LDS_TABLE>, RCM>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
     }
     if (LDS_TABLE) {
         __syncthreads();
@@ -594,9 +598,10 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
         const uint64_t *gro = genome_rec_off + g0; const uint64_t *gu = gen_units + g0;
         T *tab = table + g0 * m;
         ProfScope ps(c, FAM_SKETCH);
-#define GS_LAUNCH_MIN(AAV, LDSV, FV)                                                                                    \
+#define GS_LAUNCH_MIN(AAV, LDSV, FV) do { if (!AAV && p->data_t == GS_DATA_DNA_FWD) GS_LAUNCH_MIN_RC(AAV, LDSV, FV, AAV ? 0 : 1); else GS_LAUNCH_MIN_RC(AAV, LDSV, FV, 0); } while (0)
+#define GS_LAUNCH_MIN_RC(AAV, LDSV, FV, RC)                                                                             \
     do {                                                                                                                \
-        auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T, FV>;                                                        \
+        auto kern = k_sketch_min<AAV, LDSV, ALGO, VBITS, T, FV, RC>;                                                    \
         const size_t l0_ = LDSV ? (FV ? lds_f : lds) : ((size_t)2 * m + 15) & ~(size_t)15;    /* slot table (+ survivor queues), or its 2-byte filter */  \
         const size_t l = std::min<size_t>(std::max<size_t>(l0_, c->sketch_min_lds), 160 * 1024 - 256);                                       \
         if (l > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
@@ -607,6 +612,7 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
         else if (filt) GS_LAUNCH_MIN(false, true, true);
         else GS_LAUNCH_MIN(false, true, false);
 #undef GS_LAUNCH_MIN
+#undef GS_LAUNCH_MIN_RC
         GS_HIP_CHECK(hipGetLastError());
     }
     return GS_OK;

@@ -13,7 +13,7 @@ asm = os.path.join(tempfile.gettempdir(), "gs_sketch_isa.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", asm, src],
                       stderr=subprocess.DEVNULL)
 text = open(asm).read()
-a = text.index("_ZN2gs12k_sketch_minILb0ELb1ELi4ELi64EjLb0EEE")      # <DNA, LDS table, optdens, 64-bit values, u32 keys, unfiltered emitter>
+a = text.index("_ZN2gs12k_sketch_minILb0ELb1ELi4ELi64EjLb0ELi0EEE")      # <DNA, LDS table, optdens, 64-bit values, u32 keys, unfiltered emitter, canonical compiled in>
 body = text[a:text.index("s_endpgm", a)].splitlines()
 ins = [l.split()[0] for l in body if l.startswith("\t") and l.strip() and not l.strip().startswith((";", "."))]
 mins = [i for i, op in enumerate(ins) if op == "ds_min_u32"]
