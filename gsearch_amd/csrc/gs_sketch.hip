@@ -107,6 +107,13 @@ struct MinEmitF {
     uint32_t lane;
     mutable uint32_t qn, words;                   // wave-uniform: pending survivors, full-wave words walked
     mutable T thr;                                // wave-uniform: every slot's minimum is <= thr
+    // Round 5, the SPECULATIVE bound: `thr` starts at - and never exceeds - `cap`, a guess of where the largest slot minimum of THIS genome will end
+    // ((m / N)(ln m + c): the coupon-collector tail of N k-mers over m slots). Every k-mer whose key is not below the cap is dropped from the first word
+    // on - no warm-up during which everything passes, ~6 % survivors instead of the ~15 % a running maximum lets through over a 5 Mbp genome - and the
+    // kernel CHECKS the guess afterwards: a slot whose minimum is below the cap has seen every k-mer that could matter to it (only keys >= cap were
+    // dropped), a slot that is not sends the workgroup through the genome again under the running bound alone (same table: minima are idempotent).
+    // The cap is a performance parameter only - the signature never depends on it. EMPTY = no cap.
+    T cap;
     static __device__ __forceinline__ T key_of(uint64_t o1)
     {
         if (ALGO == ALGO_SUPER2) return sizeof(T) == 8 ? (T)o1 : (T)(o1 >> 32);
@@ -147,12 +154,13 @@ struct MinEmitF {
     __device__ __forceinline__ void word_done() const
     {
         words++;
-        if (words <= 8 ? (words & (words - 1)) != 0 : (words & (words <= 128 ? 7 : 15)) != 0) return;     // 1, 2, 4, 8, then every 8th word, every 16th after 128
+        if (cap != (T)~(T)0) { if ((words & 63u) != 0) return; }                                             // under a cap the running maximum only matters late in the genome
+        else if (words <= 8 ? (words & (words - 1)) != 0 : (words & (words <= 128 ? 7 : 15)) != 0) return;     // 1, 2, 4, 8, then every 8th word, every 16th after 128
         T mx = 0;
         for (uint32_t i = lane; i < m; i += 64) { const T x = table[i]; mx = x > mx ? x : mx; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const T y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
-        thr = mx;
+        thr = mx < cap ? mx : cap;
     }
     __device__ __forceinline__ void finish() const
     {
@@ -280,7 +288,7 @@ template <bool AA, bool LDS_TABLE, int ALGO, int VBITS, typename T, bool FILT, i
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
                                                             const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre,
                                                             const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
-                                                            uint32_t k, uint32_t m, uint64_t zone, T *__restrict__ table_out)
+                                                            uint32_t k, uint32_t m, uint64_t zone, T *__restrict__ table_out, float cap_c)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw_table[];
     T *s_table = (T *)s_raw_table;
@@ -299,8 +307,26 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_min(const uint8_t *__rest
     }
     if (FILT) {
         uint64_t *qbase = (uint64_t *)(s_raw_table + (((size_t)m * sizeof(T) + 15) & ~(size_t)15));
-        MinEmitF<ALGO, VBITS, T> emit{table, m, zone, qbase + (threadIdx.x >> 6) * SKQ, threadIdx.x & 63, 0u, 0u, EMPTY};
-        walk_genome<AA, MinEmitF<ALGO, VBITS, T>, RCM>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
+        // speculative bound (MinEmitF::cap): whole genomes only (a part's table is not the genome's), and only where it is a real cut (< 1/4 of the key range)
+        T cap = EMPTY;
+        if (LDS_TABLE && parts == 1 && cap_c != 0.0f) {
+            const float nk = (float)gen_units[g] * 32.0f;                        // k-mers of the genome, from above
+            const float frac = (float)m / nk * (__logf((float)m) + cap_c);
+            if (frac > 0.0f && frac < 0.25f) {
+                const float scale = ALGO == ALGO_SUPER2 ? (sizeof(T) == 8 ? 0x1.0p64f : 0x1.0p32f) : 0x1.0p23f;
+                cap = (T)(frac * scale);
+            }
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            MinEmitF<ALGO, VBITS, T> emit{table, m, zone, qbase + (threadIdx.x >> 6) * SKQ, threadIdx.x & 63, 0u, 0u, cap, cap};
+            walk_genome<AA, MinEmitF<ALGO, VBITS, T>, RCM>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
+            if (cap == EMPTY) break;
+            __syncthreads();
+            int bad = 0;
+            for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) bad |= (int)(s_table[i] >= cap);
+            if (!__syncthreads_or(bad)) break;                                   // every slot's minimum lies below the cap: nothing that was dropped could have mattered
+            cap = EMPTY;                                                         // (~1 genome in 1000 at c = 7: once more, under the running bound alone)
+        }
     } else {
         MinEmit<ALGO, VBITS, T, LDS_TABLE> emit{table, m, zone, s_bound};
         walk_genome<AA, MinEmit<ALGO, VBITS, T, LDS_TABLE>, RCM>(seq, rec_start, rec_len, rec_upre, genome_rec_off[g], genome_rec_off[g + 1], gen_units[g], k, part, parts, emit);
@@ -591,6 +617,8 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
     const bool filt = !aa && ge.use_lds && !(getenv("GS_SKETCH_FILTER") && !atoi(getenv("GS_SKETCH_FILTER"))) && avg_units * 32 >= (uint64_t)64 * m &&
                       (lds_f <= half_cu || (lds > half_cu && lds_f <= 160 * 1024 - 256));
     c->last_sketch[0] = filt; c->last_sketch[1] = ge.use_lds; c->last_sketch[2] = ge.parts; c->last_sketch[3] = 0;
+    // GS_SKETCH_CAP: the c of the speculative bound (m / N)(ln m + c) of the filtered emitter (default 7: ~1 genome in 1000 walks twice); 0 = off
+    const float cap_c = getenv("GS_SKETCH_CAP") ? (float)atof(getenv("GS_SKETCH_CAP")) : 7.0f;
     for (uint64_t g0 = 0; g0 < n_genomes; g0 += 65535) {       // grid.y limit
         uint64_t ng = n_genomes - g0 < 65535 ? n_genomes - g0 : 65535;
         dim3 grid(ge.parts, (uint32_t)ng), block(SK_THREADS);
@@ -605,7 +633,7 @@ static int launch_min(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, 
         const size_t l0_ = LDSV ? (FV ? lds_f : lds) : ((size_t)2 * m + 15) & ~(size_t)15;    /* slot table (+ survivor queues), or its 2-byte filter */  \
         const size_t l = std::min<size_t>(std::max<size_t>(l0_, c->sketch_min_lds), 160 * 1024 - 256);                                       \
         if (l > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l)); \
-        hipLaunchKernelGGL(kern, grid, block, l, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, kq_of(p), m, zone, tab); \
+        hipLaunchKernelGGL(kern, grid, block, l, c->stream, seq, rec_start, rec_len, rec_upre, gro, gu, kq_of(p), m, zone, tab, cap_c); \
     } while (0)
         if (aa) { if (ge.use_lds) GS_LAUNCH_MIN(true, true, false); else GS_LAUNCH_MIN(true, false, false); }
         else if (!ge.use_lds) GS_LAUNCH_MIN(false, false, false);

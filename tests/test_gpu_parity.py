@@ -103,6 +103,12 @@ def test_sketch_early_rejection_is_exact(gpu_ctx, monkeypatch, algo, m):
     monkeypatch.setenv("GS_SKETCH_FILTER", "0")
     plain = sk.sketch_genomes(genomes)
     assert np.array_equal(_bits(got), _bits(plain))
+    monkeypatch.delenv("GS_SKETCH_FILTER")
+    # round 5, the speculative bound of the filtered emitter ((m / N)(ln m + c), checked after the walk): c = 7 above; a guess that is far too tight
+    # (c = -3: most genomes fail the check and are walked again under the running bound) and no cap at all must give the same bits
+    for c in ("-3", "0.5", "0"):
+        monkeypatch.setenv("GS_SKETCH_CAP", c)
+        assert np.array_equal(_bits(sk.sketch_genomes(genomes)), _bits(ref)), c
 
 
 @pytest.mark.parametrize("algo", ["optdens", "revoptdens"])
