@@ -1909,7 +1909,7 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         const uint64_t *__restrict__ gen_units, const uint32_t *__restrict__ list, uint32_t n_items, uint32_t k, uint32_t m, double inv_lnb,
         const uint64_t *__restrict__ ucut, uint32_t *__restrict__ lane_q, uint32_t *__restrict__ lane_perm, unsigned long long *__restrict__ counter,
         uint8_t *__restrict__ cold_flag, uint16_t *__restrict__ sig, uint32_t *__restrict__ gtab, int use_filter, uint32_t queue_off,
-        uint64_t *__restrict__ surv_all, uint32_t surv_cap, uint32_t surv_min_chunks)
+        uint64_t *__restrict__ surv_all, uint32_t surv_cap, uint32_t surv_min_chunks, float spec_c)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_hll[];
     HllShared S;
@@ -1940,7 +1940,55 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         // the filtering the lists save; 1 Mbp 12.0 -> 17.4 ms. Lists from `surv_min_chunks` chunks of 131 072 k-mers on: 64 = 8.4 Mbp.)
         uint64_t *surv_wg = (!COLD && surv_all && nchunks >= surv_min_chunks) ? surv_all + (uint64_t)blockIdx.x * surv_cap : nullptr;
         const uint32_t nwarm = nchunks / 8 ? nchunks / 8 : 1;
-        for (int pass = surv_wg ? -1 : 0; pass < 2 && !outgrown; pass++) {
+        // the minimum register of the workgroup's table -> S.ctl[2] (all lanes return it)
+        auto min_register = [&]() -> uint32_t {
+            __syncthreads();
+            if (threadIdx.x == 0) S.ctl[2] = 0xFFFFFFFFu;
+            __syncthreads();
+            uint32_t lo = 0xFFFFFFFFu;
+            for (uint32_t i = threadIdx.x; i < m; i += T) {
+                // (a global table is only ever written by atomics performed in the L2: read it there too, not through the vector L1)
+                const uint32_t r = GTAB ? __hip_atomic_load(&S.tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.tab[i];
+                if (GTAB && S.filt) S.filt[i] = (uint16_t)r;
+                lo = min(lo, r);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_down((int)lo, o));
+            if ((threadIdx.x & 63) == 0) atomicMin((uint32_t *)&S.ctl[2], lo);
+            __syncthreads();
+            return S.ctl[2];
+        };
+        // Round 5, ONE speculative pass instead of two (the bound of k_sketch_min's filtered emitter): every register ends as the maximum of
+        // k = trunc(1 - log_b x) over one Exp(a)-distributed point per distinct k-mer, so the smallest register of N k-mers sits near
+        // K = 1 - log_b((ln m + G) / (a N)), G Gumbel. With a guess K_g taken at G = c the genome is walked ONCE - level 0 and the walks of the ~m (ln m + c) / N
+        // k-mers whose first point can beat K_g, everything at or below K_g dropped - and the guess is CHECKED: if no register ended below K_g, nothing
+        // that was dropped could have raised one (max semantics) and the table is the exact one; otherwise (c = 7: ~1 genome in 1000; genomes of many
+        // repeated k-mers) the table is kept - registers only grow - and the two exact passes below run over it.
+        bool spec_done = false;
+        if (!COLD && spec_c != 0.0f && units > 0) {
+            const float xg = (__logf((float)m) + spec_c) / ((float)GS_HLL_A * (float)units * 32.0f);
+            uint32_t kg = 0;
+            if (xg > 0.0f && xg < 1.0f) { const float y = 1.0f - __logf(xg) * (float)inv_lnb; kg = y >= 4.0f ? (uint32_t)fminf(y, (float)GS_HLL_Q) - 1u : 0u; }
+            if (kg >= 2) {
+                if (threadIdx.x == 0) { const uint64_t cu = ucut[kg]; S.ctl[0] = kg; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); }
+                __syncthreads();
+                uint64_t *sq = queue_off ? (uint64_t *)(s_hll + queue_off) + (threadIdx.x >> 6) * 128 : nullptr;
+                HllEmit<COLD, GTAB> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, true, sq, threadIdx.x & 63, 0u, ~(uint64_t)0, nullptr, 0u};
+                for (uint32_t ch = 0; ch < nchunks; ch++) {
+                    emit.refresh();
+                    walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, ch, nchunks, emit);
+                    if (__syncthreads_or(S.ctl[3] != 0)) { outgrown = true; break; }
+                }
+                if (!outgrown) {
+                    if (min_register() >= kg) spec_done = true;
+                    else {
+                        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; }
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        for (int pass = surv_wg ? -1 : 0; pass < 2 && !outgrown && !spec_done; pass++) {
             // (queue_off != 0: the warm instantiation has room in LDS for its survivor queues, 128 hashes per wave)
             uint64_t *sq = (!COLD && queue_off) ? (uint64_t *)(s_hll + queue_off) + (threadIdx.x >> 6) * 128 : nullptr;
             uint64_t *surv = pass == 0 ? surv_wg : nullptr;
@@ -1957,21 +2005,8 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
                 walk_genome<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, units, k, ch, nchunks, emit);
                 if (pass <= 0 || ch + 1 == nchunks) {
                     // refresh the lower bound: minimum register (pass A: running, between chunks; after pass A: exact)
-                    __syncthreads();
-                    if (threadIdx.x == 0) S.ctl[2] = 0xFFFFFFFFu;
-                    __syncthreads();
-                    uint32_t lo = 0xFFFFFFFFu;
-                    for (uint32_t i = threadIdx.x; i < m; i += T) {
-                        // (a global table is only ever written by atomics performed in the L2: read it there too, not through the vector L1)
-                        const uint32_t r = GTAB ? __hip_atomic_load(&S.tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.tab[i];
-                        if (GTAB && S.filt) S.filt[i] = (uint16_t)r;
-                        lo = min(lo, r);
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_down((int)lo, o));
-                    if ((threadIdx.x & 63) == 0) atomicMin((uint32_t *)&S.ctl[2], lo);
-                    __syncthreads();
-                    if (threadIdx.x == 0) { const uint32_t kl = S.ctl[2]; const uint64_t cu = ucut[kl]; S.ctl[0] = kl; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); }
+                    const uint32_t kl_ = min_register();
+                    if (threadIdx.x == 0) { const uint32_t kl = kl_; const uint64_t cu = ucut[kl]; S.ctl[0] = kl; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); }
                     __syncthreads();
                 }
                 // the overflow flag is raised by single lanes in mid-walk: every wave must take the SAME decision here (a wave that read
@@ -2024,6 +2059,8 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     // survivor lists of pass A: 2^20 hashes (8 MB) per workgroup - ~8 % of the k-mers of a 5 Mbp genome survive the running cut; a longer genome
     // overflows its list and takes the second walk as before (GS_HLL_SURVIVORS=n: lists of n hashes, 0 = always the second walk)
     uint32_t surv_cap = getenv("GS_HLL_SURVIVORS") ? (uint32_t)std::max(0, std::min(1 << 24, atoi(getenv("GS_HLL_SURVIVORS")))) : (1u << 20);
+    // GS_HLL_SPEC: the c of the speculative single pass (k_sketch_hll; default 7, 0 = the two exact passes only)
+    const float spec_c = getenv("GS_HLL_SPEC") ? (float)atof(getenv("GS_HLL_SPEC")) : 7.0f;
     const uint32_t surv_minch = getenv("GS_HLL_SURVIVORS_MINCHUNKS") ? (uint32_t)std::max(4, atoi(getenv("GS_HLL_SURVIVORS_MINCHUNKS"))) : 64u;
     //  the lists are only allocated when some genome of the batch can reach `surv_minch` chunks - no genome holds more units than the whole
     // batch does -, and a batch whose lists do not fit takes the plain second walk instead of failing the call
@@ -2037,7 +2074,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(HL_T), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, (const uint32_t *)nullptr, \
                            (uint32_t)n_genomes, kq_of(p), m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
-                           gt.as<uint32_t>(), use_filter, queue_off, surv_cap ? sv.as<uint64_t>() : (uint64_t *)nullptr, surv_cap, surv_minch); \
+                           gt.as<uint32_t>(), use_filter, queue_off, surv_cap ? sv.as<uint64_t>() : (uint64_t *)nullptr, surv_cap, surv_minch, spec_c); \
     } while (0)
         if (aa) { if (gtab) GS_LAUNCH_HLL(true, true); else GS_LAUNCH_HLL(true, false); }
         else { if (gtab) GS_LAUNCH_HLL(false, true); else GS_LAUNCH_HLL(false, false); }
@@ -2074,7 +2111,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(cw), dim3(HL_CT), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, dl.as<uint32_t>(), nc, kq_of(p), m, \
                            inv_lnb, dcut.as<uint64_t>(), lq.as<uint32_t>(), lp.as<uint32_t>(), cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
-                           gt.as<uint32_t>(), use_filter, 0u, (uint64_t *)nullptr, 0u, 0u);                                    \
+                           gt.as<uint32_t>(), use_filter, 0u, (uint64_t *)nullptr, 0u, 0u, 0.0f);                              \
     } while (0)
     if (aa) { if (gtab) GS_LAUNCH_HLLC(true, true); else GS_LAUNCH_HLLC(true, false); }
     else { if (gtab) GS_LAUNCH_HLLC(false, true); else GS_LAUNCH_HLLC(false, false); }

@@ -1057,6 +1057,25 @@ def test_sketch_hll_matches_oracle(gpu_ctx, k, m, data, length):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("spec", ["7", "-4", "2", "0"])
+def test_sketch_hll_speculative_single_pass(gpu_ctx, monkeypatch, spec):
+    """round 5: SetSketch in ONE pass under a guessed lower bound of the smallest register (K_g from (ln m + c) / (a N)), checked afterwards; a guess that
+    does not hold (c = -4: far too high for every genome; c = 2: for some; a genome that is one 20 kb segment repeated - its N distinct k-mers are a fraction
+    of what its length says) falls back to the two exact passes over the same table. Same registers as the oracle in every case, c = 0 = the round-4 form."""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_HLL_SPEC", spec)
+    rng = np.random.default_rng(91)
+    k, m = 21, 2000
+    genomes = [[H.dna_ascii(H.rand_dna(rng, n))] for n in (900_000, 600_011, 1_300_000)]
+    rep = H.dna_ascii(H.rand_dna(rng, 20_000))
+    genomes.append([rep * 40])                                              # 800 kb of 20 000 distinct k-mers
+    genomes.append([H.dna_ascii(H.rand_dna(rng, 400_000)), b"ACGTNNACGT", H.dna_ascii(H.rand_dna(rng, 350_007))])
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "hll"))
+    got = sk.sketch_genomes(genomes)
+    ref = _oracle_sketch(k, m, "hll", genomes)
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("cap", ["0", "4096", None])
 def test_sketch_hll_survivor_lists(gpu_ctx, monkeypatch, cap):
     """SetSketch pass B runs over the hashes pass A recorded instead of hashing the genome again (gs_sketch.hip HllEmit::record_wave): without lists
