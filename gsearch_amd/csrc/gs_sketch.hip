@@ -2059,8 +2059,8 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     // survivor lists of pass A: 2^20 hashes (8 MB) per workgroup - ~8 % of the k-mers of a 5 Mbp genome survive the running cut; a longer genome
     // overflows its list and takes the second walk as before (GS_HLL_SURVIVORS=n: lists of n hashes, 0 = always the second walk)
     uint32_t surv_cap = getenv("GS_HLL_SURVIVORS") ? (uint32_t)std::max(0, std::min(1 << 24, atoi(getenv("GS_HLL_SURVIVORS")))) : (1u << 20);
-    // GS_HLL_SPEC: the c of the speculative single pass (k_sketch_hll; default 7, 0 = the two exact passes only)
-    const float spec_c = getenv("GS_HLL_SPEC") ? (float)atof(getenv("GS_HLL_SPEC")) : 7.0f;
+    // GS_HLL_SPEC: the c of the speculative single pass (k_sketch_hll; default 8, 0 = the two exact passes only)
+    const float spec_c = getenv("GS_HLL_SPEC") ? (float)atof(getenv("GS_HLL_SPEC")) : 8.0f;   // (one genome per workgroup and launch tail: a failed guess doubles that workgroup's time)
     const uint32_t surv_minch = getenv("GS_HLL_SURVIVORS_MINCHUNKS") ? (uint32_t)std::max(4, atoi(getenv("GS_HLL_SURVIVORS_MINCHUNKS"))) : 64u;
     //  the lists are only allocated when some genome of the batch can reach `surv_minch` chunks - no genome holds more units than the whole
     // batch does -, and a batch whose lists do not fit takes the plain second walk instead of failing the call
