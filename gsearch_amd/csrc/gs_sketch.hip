@@ -1792,7 +1792,12 @@ constexpr int HL_CT = 256;         // lanes per workgroup of the cold instantiat
 // cannot raise the register and stops after one LDS read; the rest go to atomicMax in memory. Racy plain 16-bit stores can only leave
 // the filter lower, i.e. more conservative: exact. Beyond ~80 000 registers the filter does not fit either (filt == nullptr) and every
 // k above K_low goes to memory.
-struct HllShared { uint32_t *tab; volatile uint32_t *ctl; uint16_t *filt; };   // ctl: [0] klow, [1] work item, [2] scratch min, [3] overflow flag, [4,5] ucut[klow]
+__device__ __forceinline__ uint32_t hll_xthr_bits(uint32_t klow, double inv_lnb)
+{
+    // k(x) = trunc(1 - ln x / ln b) <= klow  <=  x > b^-klow; the margin (2e-5 relative) covers the float rounding and spec_ln's last bits by far
+    return __float_as_uint((float)(exp(-(double)klow / inv_lnb) * (1.0 + 2e-5)));
+}
+struct HllShared { uint32_t *tab; volatile uint32_t *ctl; uint16_t *filt; };   // ctl: [0] klow, [1] work item, [2] scratch min, [3] overflow flag, [4,5] ucut[klow], [7] float bits of a value safely ABOVE b^-klow (x >= it => k(x) <= klow without the logarithm)
 template <bool COLD, bool GTAB>
 struct HllEmit {
     HllShared S; uint32_t m; uint64_t zone_m; double inv_lnb, am;
@@ -1859,9 +1864,14 @@ struct HllEmit {
         const uint32_t st = COLD ? (*stamp)++ : 0, l = threadIdx.x;
         if (COLD) { q[(uint64_t)0 * HL_CT + l] = st; perm[(uint64_t)0 * HL_CT + l] = t; q[(uint64_t)t * HL_CT + l] = st; perm[(uint64_t)t * HL_CT + l] = 0; }
         else if (t != 0) { tpos[0] = t; tval[0] = 0; nt = 1; }
+        const double xthr = (double)__uint_as_float(S.ctl[7]);
         for (uint32_t j = 1; j < m; j++) {
-            const double te = -spec_ln(1.0 - g.u64f());
+            const double uj = g.u64f();
             const double den = GS_HLL_A * (double)(m - j);
+            // (round 5) -ln(1 - u) >= u: the next point lies at or beyond x + u / den; when already that is safely past b^-klow the walk ends here, without
+            // the two logarithms (the spacing and k of the point) - the case for ~94 % of the walkers' second points. Nothing reads the generator afterwards.
+            if (x + uj / den >= xthr) break;
+            const double te = -spec_ln(1.0 - uj);
             x = x + te / den;
             k = hll_k(x, inv_lnb);
             if (k <= klow) break;
@@ -1928,7 +1938,7 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
         if (c >= n_items) break;
         const uint64_t g = list ? list[c] : c;
         for (uint32_t i = threadIdx.x; i < m; i += T) { S.tab[i] = 0; if (GTAB && S.filt) S.filt[i] = 0; }
-        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[3] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; S.ctl[6] = 0; }
+        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[3] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; S.ctl[6] = 0; S.ctl[7] = hll_xthr_bits(0, inv_lnb); }
         __syncthreads();
         const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
         const uint32_t nchunks = (uint32_t)std::max<uint64_t>(1, units / ((uint64_t)T * 8));
@@ -1970,7 +1980,7 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
             uint32_t kg = 0;
             if (xg > 0.0f && xg < 1.0f) { const float y = 1.0f - __logf(xg) * (float)inv_lnb; kg = y >= 4.0f ? (uint32_t)fminf(y, (float)GS_HLL_Q) - 1u : 0u; }
             if (kg >= 2) {
-                if (threadIdx.x == 0) { const uint64_t cu = ucut[kg]; S.ctl[0] = kg; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); }
+                if (threadIdx.x == 0) { const uint64_t cu = ucut[kg]; S.ctl[0] = kg; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); S.ctl[7] = hll_xthr_bits(kg, inv_lnb); }
                 __syncthreads();
                 uint64_t *sq = queue_off ? (uint64_t *)(s_hll + queue_off) + (threadIdx.x >> 6) * 128 : nullptr;
                 HllEmit<COLD, GTAB> emit{S, m, zone_m, inv_lnb, am, q, perm, &stamp, true, sq, threadIdx.x & 63, 0u, ~(uint64_t)0, nullptr, 0u};
@@ -1982,7 +1992,7 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
                 if (!outgrown) {
                     if (min_register() >= kg) spec_done = true;
                     else {
-                        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; }
+                        if (threadIdx.x == 0) { S.ctl[0] = 0; S.ctl[4] = 0xFFFFFFFFu; S.ctl[5] = 0xFFFFFFFFu; S.ctl[7] = hll_xthr_bits(0, inv_lnb); }
                         __syncthreads();
                     }
                 }
@@ -2006,7 +2016,7 @@ __global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_
                 if (pass <= 0 || ch + 1 == nchunks) {
                     // refresh the lower bound: minimum register (pass A: running, between chunks; after pass A: exact)
                     const uint32_t kl_ = min_register();
-                    if (threadIdx.x == 0) { const uint32_t kl = kl_; const uint64_t cu = ucut[kl]; S.ctl[0] = kl; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); }
+                    if (threadIdx.x == 0) { const uint32_t kl = kl_; const uint64_t cu = ucut[kl]; S.ctl[0] = kl; S.ctl[4] = (uint32_t)cu; S.ctl[5] = (uint32_t)(cu >> 32); S.ctl[7] = hll_xthr_bits(kl, inv_lnb); }
                     __syncthreads();
                 }
                 // the overflow flag is raised by single lanes in mid-walk: every wave must take the SAME decision here (a wave that read
