@@ -196,12 +196,15 @@ __device__ __forceinline__ void walk_unit(const uint8_t *__restrict__ seq, const
             uint64_t w = __builtin_bswap64(w64[u]);
             uint64_t fwd = 0, rc = 0;
             if (a0 > rb && k > 1) {
-                uint64_t p = __builtin_bswap64(w64[u - 1]) << (2 * (32 - (k - 1)));
-                for (uint32_t j = 0; j + 1 < k; j++) {
-                    uint64_t c = p >> 62; p <<= 2;
-                    fwd = ((fwd << 2) | c) & mask;
-                    rc = (rc >> 2) | ((3 - c) << rcshift) | rc_or;
-                }
+                // the state after the k-1 bases in front of this word, in closed form (round 5: the loop over them - k-1 = 20 trips of ~9 instructions per 32 k-mers -
+                // was 5.6 of the ~82 VALU instructions per k-mer): the forward window is the low 2(k-1) bits of the previous word; the reverse-complement
+                // register holds base i of those k-1 at bit 2i, complemented - the 2-bit groups in reverse order, one group up
+                const uint64_t pw = __builtin_bswap64(w64[u - 1]);
+                const uint64_t lowm = ((uint64_t)1 << (2 * (k - 1))) - 1;            // k - 1 <= 31
+                fwd = pw & lowm;
+                uint64_t br = __builtin_bitreverse64(fwd);
+                br = ((br >> 1) & 0x5555555555555555ull) | ((br & 0x5555555555555555ull) << 1);      // bit order inside each group back
+                rc = (((~(br >> (2 * (33 - k)))) & lowm) << 2) | rc_or;
             }
             // (rc never exceeds 2k bits and fwd is masked every step: the minimum needs no further mask.) When every lane of the wave
             // holds an interior word - all 32 windows inside its record, the case for all but the first and last word of a record - the
