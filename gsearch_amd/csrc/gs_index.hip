@@ -47,7 +47,9 @@ struct IndexDev {
     // sp_bm[a] (optional, 0 = none): bitmap over b < a of "m - c(a,b) >= J0(a) - 1", the level just below the list's cut - kept for the nodes whose list
     // is shorter than ~ef_construction, where a selection walk reaches candidates of that level (a pair that is not listed has fewer than J0 matches,
     // so the bit says "exactly J0 - 1": all a threshold of cut + 1 asks)
-    const uint32_t *sp_ids; const uint16_t *sp_cnt; const uint64_t *sp_meta; const uint64_t *sp_bm; uint32_t sp_L;
+    // The lists have the length they need (the cut level of a node of a 1.5 M-genome index holds ~0.0036 a + its family, not sp_L): they live in a
+    // grow-in-place arena (VmArena) with the level bitmaps, sp_off[a] = offset of a's ids from sp_base in 32-byte units, its 16-bit counts follow the ids.
+    const uint8_t *sp_base; const uint32_t *sp_off; const uint64_t *sp_meta; const uint64_t *sp_bm; uint32_t sp_L;
     uint64_t n; int64_t entry; int top;
 };
 
@@ -1341,13 +1343,15 @@ __device__ __forceinline__ bool select_check_rows(const IndexDev &ix, const Sear
 template <int NJ, class FH, class FL, class FT>
 __device__ __forceinline__ void sparse_pairs(const IndexDev &ix, uint32_t want, const FH &fhi, const FL &flo, const FT &fT, uint32_t &yes, uint32_t &unk)
 {
-    uint32_t base[NJ], len[NJ], eq = 0, cutok = 0;
+    uint32_t base[NJ], len[NJ], off[NJ], eq = 0, cutok = 0;
     uint32_t top = 1; while (top < ix.sp_L) top <<= 1;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-        base[j] = 0; len[j] = 0;
+        base[j] = 0; len[j] = 0; off[j] = 0;
         if ((want >> j) & 1u) {
-            const uint64_t mt = ix.sp_meta[fhi(j)];
+            const uint32_t h = fhi(j);
+            const uint64_t mt = ix.sp_meta[h];
+            off[j] = ix.sp_off[h];
             if (!SP_VALID(mt)) { unk |= 1u << j; want &= ~(1u << j); }
             else { len[j] = SP_LEN(mt); if (fT(j) <= SP_CUT(mt)) cutok |= 1u << j; }
         }
@@ -1357,7 +1361,7 @@ __device__ __forceinline__ void sparse_pairs(const IndexDev &ix, uint32_t want, 
         for (int j = 0; j < NJ; j++) {
             const uint32_t pp = base[j] + step;
             if (((want >> j) & 1u) && pp <= len[j]) {
-                const uint32_t v = ix.sp_ids[(uint64_t)fhi(j) * ix.sp_L + pp - 1], l = flo(j);
+                const uint32_t v = ((const uint32_t *)(ix.sp_base + ((uint64_t)off[j] << 5)))[pp - 1], l = flo(j);
                 if (v <= l) { base[j] = pp; if (v == l) eq |= 1u << j; }
             }
         }
@@ -1365,7 +1369,7 @@ __device__ __forceinline__ void sparse_pairs(const IndexDev &ix, uint32_t want, 
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         if (!((want >> j) & 1u)) continue;
-        if ((eq >> j) & 1u) { if ((uint32_t)ix.sp_cnt[(uint64_t)fhi(j) * ix.sp_L + base[j] - 1] <= fT(j)) yes |= 1u << j; }
+        if ((eq >> j) & 1u) { if ((uint32_t)((const uint16_t *)(ix.sp_base + ((uint64_t)off[j] << 5) + (uint64_t)4 * len[j]))[base[j] - 1] <= fT(j)) yes |= 1u << j; }
         else if (!((cutok >> j) & 1u)) {                        // not stored: its count is above the cut - decides only thresholds <= cut ...
             const uint32_t h = fhi(j);
             const uint32_t *bm = (fT(j) == SP_CUT(ix.sp_meta[h]) + 1 && ix.sp_bm) ? (const uint32_t *)ix.sp_bm[h] : nullptr;
@@ -1669,13 +1673,15 @@ __global__ void k_cache_rows(uint16_t *__restrict__ rowbase, uint64_t ld, uint64
 // and the list is written in ascending b (chunks in order, lanes in order, a lane's 8 counts in order: ordered compaction by prefix sums).
 // A row whose closest L nodes cannot be separated by level (more than L nodes with >= 63 matches) gets no list (meta 0: the selection streams rows).
 constexpr int SPF_T = 256;
-struct SpArena { unsigned long long base, off, size, stored, noroom; };      // bump allocator of the level bitmaps (device side: the kernel knows who needs one)
+// bump allocator of the lists and the level bitmaps (device side: only the kernel knows how long a list is and who needs a bitmap). base .. base + size is
+// backed by memory (the host maps more of the arena before a launch could run out); bm_bytes / bm_limit: what the bitmaps alone may take
+struct SpArena { unsigned long long base, off, size, stored, noroom, bm_bytes, bm_limit, lists_noroom; };
 __global__ __launch_bounds__(SPF_T) void k_sparse_fill(const uint16_t *__restrict__ rowbase, uint64_t ld, uint64_t a0, uint32_t m, uint32_t L,
-                                                       uint32_t *__restrict__ sp_ids, uint16_t *__restrict__ sp_cnt, uint64_t *__restrict__ sp_meta,
+                                                       uint32_t *__restrict__ sp_off, uint64_t *__restrict__ sp_meta,
                                                        uint64_t *__restrict__ sp_bm, SpArena *__restrict__ arena, uint32_t bm_below_len)
 {
     __shared__ uint32_t hist[64], wsum[SPF_T / 64], s_cut, s_base;
-    __shared__ unsigned long long s_bm;
+    __shared__ unsigned long long s_bm, s_list;
     const uint64_t a = a0 + blockIdx.x;
     const uint16_t *row = rowbase + (uint64_t)blockIdx.x * ld;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1696,12 +1702,20 @@ __global__ __launch_bounds__(SPF_T) void k_sparse_fill(const uint16_t *__restric
         for (int j = 63; j >= 0; j--) { if (run + hist[j] > L) break; run += hist[j]; j0 = (uint32_t)j; }
         s_cut = j0 == 64 ? 0xFFFFFFFFu : m - j0;
         if (j0 != 64 && j0 > m) s_cut = 0xFFFFFFFFu;              // (only when m < 63 and even the pairs with m matches outnumber L: no list)
-        s_base = 0;
+        s_base = 0; s_list = 0;
+        if (s_cut != 0xFFFFFFFFu) {                               // room for `run` entries: 4-byte ids, then their 2-byte counts (32-byte granules)
+            const unsigned long long bytes = ((unsigned long long)run * 6 + 31) & ~31ull;
+            const unsigned long long off = bytes ? atomicAdd(&arena->off, bytes) : 0ull;
+            if (arena->base && off + bytes <= arena->size) s_list = arena->base + off;
+            else { s_cut = 0xFFFFFFFFu; atomicAdd(&arena->lists_noroom, 1ull); }
+        }
+        wsum[0] = run;
     }
     __syncthreads();
-    const uint32_t cut = s_cut;
-    if (cut == 0xFFFFFFFFu) { if (threadIdx.x == 0) { sp_meta[a] = 0; if (sp_bm) sp_bm[a] = 0; } return; }
-    uint32_t *ids = sp_ids + a * L; uint16_t *cnt = sp_cnt + a * L;
+    const uint32_t cut = s_cut, nlist = wsum[0];
+    if (cut == 0xFFFFFFFFu) { if (threadIdx.x == 0) { sp_meta[a] = 0; sp_off[a] = 0; if (sp_bm) sp_bm[a] = 0; } return; }
+    uint32_t *ids = (uint32_t *)s_list; uint16_t *cnt = (uint16_t *)(s_list + (unsigned long long)4 * nlist);
+    __syncthreads();                                              // (wsum is reused by the compaction below)
     for (uint64_t c0 = 0; c0 < a; c0 += (uint64_t)SPF_T * 8) {
         const uint64_t b0 = c0 + (uint64_t)threadIdx.x * 8;
         uint32_t cc[8], nk = 0;
@@ -1716,19 +1730,22 @@ __global__ __launch_bounds__(SPF_T) void k_sparse_fill(const uint16_t *__restric
 #pragma unroll
         for (int w = 0; w < SPF_T / 64; w++) { if (w < (int)wv) off += wsum[w]; tot += wsum[w]; }
 #pragma unroll
-        for (int h = 0; h < 8; h++) if (cc[h] <= cut) { if (off < L) { ids[off] = (uint32_t)(b0 + h); cnt[off] = (uint16_t)cc[h]; } off++; }
+        for (int h = 0; h < 8; h++) if (cc[h] <= cut) { if (off < nlist) { ids[off] = (uint32_t)(b0 + h); cnt[off] = (uint16_t)cc[h]; } off++; }
         __syncthreads();
         if (threadIdx.x == 0) s_base += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        sp_meta[a] = ((uint64_t)1 << 63) | ((uint64_t)(s_base < L ? s_base : L) << 16) | (uint64_t)(cut & 0xFFFFu);
+        sp_meta[a] = ((uint64_t)1 << 63) | ((uint64_t)(s_base < nlist ? s_base : nlist) << 16) | (uint64_t)(cut & 0xFFFFu);
+        sp_off[a] = (uint32_t)((s_list - arena->base) >> 5);
         unsigned long long ptr = 0;
-        if (sp_bm && arena && cut < m && s_base < bm_below_len && a > 0) {        // (cut == m: the whole row is listed, nothing lies below)
-            const unsigned long long bytes = ((a + 31) / 32 * 4 + 15) & ~15ull;
-            const unsigned long long off = atomicAdd(&arena->off, bytes);
-            if (arena->base && off + bytes <= arena->size) { ptr = arena->base + off; atomicAdd(&arena->stored, 1ull); }
-            else atomicAdd(&arena->noroom, 1ull);
+        if (sp_bm && arena->bm_limit && cut < m && s_base < bm_below_len && a > 0) {        // (cut == m: the whole row is listed, nothing lies below)
+            const unsigned long long bytes = ((a + 31) / 32 * 4 + 31) & ~31ull;
+            if (atomicAdd(&arena->bm_bytes, bytes) + bytes <= arena->bm_limit) {
+                const unsigned long long off = atomicAdd(&arena->off, bytes);
+                if (arena->base && off + bytes <= arena->size) { ptr = arena->base + off; atomicAdd(&arena->stored, 1ull); }
+                else atomicAdd(&arena->noroom, 1ull);
+            } else atomicAdd(&arena->noroom, 1ull);
         }
         s_bm = ptr;
         if (sp_bm) sp_bm[a] = ptr;
@@ -1900,8 +1917,10 @@ struct gs_index {
     uint64_t stat_wg_in_flight = 0, stat_adj_row_bytes = 0;
     gs::DevBuf rowptr;
     // sparse pair rows (IndexDev::sp_*): allocated at the first dense insert batch, grown with the index; sp_L = 0: off (GS_SPARSE_ROWS=0, m > 65535, no memory)
-    gs::DevBuf sp_ids, sp_cnt, sp_meta, sp_bm, sp_arena; uint32_t sp_L = 0; bool sp_tried = false;
-    std::vector<gs::DevBuf *> bm_chunks; uint64_t bm_bytes = 0, bm_budget = 0, bm_reserved = 0, bm_chunk_size = 0; uint32_t bm_idle_groups = 0; bool bm_on = true;
+    gs::DevBuf sp_off, sp_meta, sp_bm, sp_arena; uint32_t sp_L = 0; bool sp_tried = false;
+    gs::VmArena sp_vm;                // lists + level bitmaps (grow in place; sp_arena = the device-side bump allocator over it)
+    bool sp_exhausted = false;        // the arena (or the device) is full: lists are still handed out while they fit, nothing more is mapped
+    uint64_t sp_reserved = 0;         // upper bound of the arena bytes handed out so far (worst case per launch; corrected from the device when it runs out)
     std::vector<gs::DevBuf *> slabs;
     uint64_t pair_cache_bytes = 0, pair_cache_budget = 0;
     bool early_cached = false;        // the nodes older than the first cached batch have all-pairs rows (insert_common)
@@ -1927,7 +1946,6 @@ struct gs_index {
         if (jev) (void)hipEventDestroy(jev);
         if (jev_up) (void)hipEventDestroy(jev_up);
         for (auto *b : slabs) delete b;
-        for (auto *b : bm_chunks) delete b;
     }
 };
 
@@ -1974,7 +1992,7 @@ static int index_reserve(gs_index *ix, uint64_t need, uint64_t need_upper)
         struct Arr { DevBuf *b; size_t per; };
         std::vector<Arr> arr = {
             {&ix->data, (size_t)ix->stride}, {&ix->levels, 1}, {&ix->deg0, 4}, {&ix->nbr0, (size_t)8 * M}, {&ix->cnt0, (size_t)8 * M}, {&ix->upidx, 4}, {&ix->rowptr, 8}};
-        if (ix->sp_L && ix->sp_meta.p) { arr.push_back({&ix->sp_ids, (size_t)4 * ix->sp_L}); arr.push_back({&ix->sp_cnt, (size_t)2 * ix->sp_L}); arr.push_back({&ix->sp_meta, 8}); arr.push_back({&ix->sp_bm, 8}); }
+        if (ix->sp_L && ix->sp_meta.p) { arr.push_back({&ix->sp_off, 4}); arr.push_back({&ix->sp_meta, 8}); arr.push_back({&ix->sp_bm, 8}); }
         for (auto &a : arr) {
             DevBuf nb;
             int rc = alloc_or_evict(ix, nb, a.per * ncap); if (rc) return rc;
@@ -2010,7 +2028,7 @@ static IndexDev index_dev(const gs_index *ix)
     d.upidx = ix->upidx.as<int32_t>(); d.degU = ix->degU.as<uint32_t>(); d.nbrU = ix->nbrU.as<uint32_t>();
     d.rowptr = ix->rowptr.as<uint64_t>();
     const bool sp = ix->sp_L && ix->sp_meta.p;
-    d.sp_ids = sp ? ix->sp_ids.as<uint32_t>() : nullptr; d.sp_cnt = sp ? ix->sp_cnt.as<uint16_t>() : nullptr; d.sp_meta = sp ? ix->sp_meta.as<uint64_t>() : nullptr; d.sp_L = sp ? ix->sp_L : 0;
+    d.sp_base = sp ? (const uint8_t *)ix->sp_vm.va : nullptr; d.sp_off = sp ? ix->sp_off.as<uint32_t>() : nullptr; d.sp_meta = sp ? ix->sp_meta.as<uint64_t>() : nullptr; d.sp_L = sp ? ix->sp_L : 0;
     d.sp_bm = sp ? ix->sp_bm.as<uint64_t>() : nullptr;
     d.n = ix->n; d.entry = ix->entry; d.top = ix->top;
     return d;
@@ -2840,35 +2858,35 @@ static int gen_level_host(const gs_index *ix, uint64_t id)
 // entry point comes out of an ef-search on layer 1, not of the greedy descent) are skipped and keep the sorted-array search inside
 // k_hnsw_plan. Leaves the device pointers of W (efc keys per point, sorted), |W| (0xFFFFFFFF = not done) and the evaluation counts.
 namespace gs {
-// sparse pair rows of `nrows` nodes a0.. from their count rows (k_sparse_fill), with room for their level bitmaps: the bitmaps come from chunks of a
-// bump arena the KERNEL allocates from (only it knows which rows need one). The host reserves the worst case - every row takes one - and looks at the
-// real fill level (one 40-byte read back) only when that reservation runs out; chunks stop being added at GS_SPARSE_BITMAP_GB (default 24).
+// sparse pair rows of `nrows` nodes a0.. from their count rows (k_sparse_fill). Lists and level bitmaps come from a bump allocator the KERNEL
+// runs over the index's arena (only it knows how long a list is and which rows need a bitmap). The host keeps the worst case of every launch
+// backed by memory - every row a full list and a bitmap - and looks at the real fill level (one 64-byte read back) only when that bound runs past
+// what is mapped; then more of the arena is mapped (1 GB steps, nothing moves). When the arena (GS_SPARSE_ARENA_GB, default: what the device
+// keeps free next to the signatures and their column copy at the declared capacity) or the device is full the rows get no list: the selection
+// streams signature rows for their pairs, as it did before round 5.
 static int sparse_fill(gs_index *ix, const uint16_t *rows, uint64_t ld, uint64_t a0, uint32_t nrows)
 {
     gs_ctx *c = ix->ctx;
     if (!ix->sp_L || nrows == 0) return GS_OK;
-    if (ix->bm_on && ix->sp_arena.p) {
-        const uint64_t need = (uint64_t)nrows * (((a0 + nrows + 31) / 32) * 4 + 16);
-        if (ix->bm_chunks.empty() || ix->bm_reserved + need > ix->bm_chunk_size) {
-            SpArena h{};
-            GS_HIP_CHECK(hipMemcpyAsync(&h, ix->sp_arena.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-            const uint64_t used = std::min<uint64_t>(h.off, h.size);
-            if (!ix->bm_chunks.empty() && used + need <= ix->bm_chunk_size) ix->bm_reserved = used + need;       // the worst case did not happen: room left
-            else {
-                const uint64_t want = std::max<uint64_t>(4 * need, (uint64_t)512 << 20);
-                if (ix->bm_budget == 0) ix->bm_budget = (uint64_t)((getenv("GS_SPARSE_BITMAP_GB") ? atof(getenv("GS_SPARSE_BITMAP_GB")) : 24.0) * 1e9);
-                gs::DevBuf *ch = (ix->bm_bytes + want <= ix->bm_budget) ? new gs::DevBuf() : nullptr;
-                if (ch && ch->alloc(want) != GS_OK) { (void)hipGetLastError(); delete ch; ch = nullptr; }
-                if (!ch) { ix->bm_on = false; h.base = 0; h.off = 0; h.size = 0; }                              // no more bitmaps: the rows that want one count `noroom`
-                else { ix->bm_chunks.push_back(ch); ix->bm_bytes += want; ix->bm_chunk_size = want; ix->bm_reserved = need; h.base = (unsigned long long)ch->p; h.off = 0; h.size = want; }
-                GS_HIP_CHECK(hipMemcpyAsync(ix->sp_arena.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-                GS_HIP_CHECK(hipStreamSynchronize(c->stream));                                                    // (h is a local)
-            }
-        } else ix->bm_reserved += need;
-    }
+    const uint64_t need = (uint64_t)nrows * ((((uint64_t)ix->sp_L * 6 + 31) & ~(uint64_t)31) + (((a0 + nrows + 31) / 32 * 4 + 31) & ~(uint64_t)31));
+    if (ix->sp_reserved + need > ix->sp_vm.mapped && !ix->sp_exhausted) {
+        SpArena h{};
+        GS_HIP_CHECK(hipMemcpyAsync(&h, ix->sp_arena.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        const uint64_t used = std::min<uint64_t>(h.off, h.size);
+        if (used + need > ix->sp_vm.mapped) {
+            // map ahead: the worst case of this launch + 1 GB, so that the read back above (a stream synchronisation) stays rare
+            const uint64_t want = std::min<uint64_t>(ix->sp_vm.va_bytes, used + need + ix->sp_vm.chunk);
+            // (a failure leaves what is mapped: the kernel turns rows away when it runs out, and the host stops asking - no more read backs)
+            if (!ix->sp_vm.map_to(want) || used + need > ix->sp_vm.mapped) ix->sp_exhausted = true;
+            h.size = ix->sp_vm.mapped; h.base = (unsigned long long)ix->sp_vm.va; h.off = used;
+            GS_HIP_CHECK(hipMemcpyAsync(ix->sp_arena.p, &h, 24, hipMemcpyHostToDevice, c->stream));      // base, off (unchanged), size
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));                                                    // (h is a local)
+        }
+        ix->sp_reserved = used + need;
+    } else ix->sp_reserved += need;
     const uint32_t below = (uint32_t)std::min<uint64_t>(ix->sp_L, (uint64_t)ix->prm.ef_construction + ix->prm.ef_construction / 4);
-    hipLaunchKernelGGL(k_sparse_fill, dim3(nrows), dim3(SPF_T), 0, c->stream, rows, ld, a0, ix->prm.m, ix->sp_L, ix->sp_ids.as<uint32_t>(), ix->sp_cnt.as<uint16_t>(),
+    hipLaunchKernelGGL(k_sparse_fill, dim3(nrows), dim3(SPF_T), 0, c->stream, rows, ld, a0, ix->prm.m, ix->sp_L, ix->sp_off.as<uint32_t>(),
                        ix->sp_meta.as<uint64_t>(), ix->sp_bm.as<uint64_t>(), ix->sp_arena.as<SpArena>(), below);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
@@ -3099,26 +3117,35 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             // sparse pair rows (round 5): allocated here, at the first dense batch of the index (they cost sp_L x 6 bytes per node of capacity)
             if (!ix->sp_tried) {
                 ix->sp_tried = true;
-                const char *eo = getenv("GS_SPARSE_ROWS"), *el = getenv("GS_SPARSE_L");
-                // list length: what the device can afford next to the signatures and their column copy AT THE DECLARED CAPACITY (hnsw_params.capacity: 1.5 M in
-                // gsearch) - 6 bytes per entry and node -, between 2048 and 8192; a level of chance matches must fit whole
-                uint32_t autoL = 4096;
-                {
-                    const uint64_t capd = std::max<uint64_t>(ix->prm.capacity, ix->cap);
-                    const uint64_t fixed = 2 * (uint64_t)ix->stride * capd + ((uint64_t)32 << 30);
-                    const uint64_t room = c->hbm_bytes > fixed ? c->hbm_bytes - fixed : 0;
-                    autoL = (uint32_t)std::max<uint64_t>(2048, std::min<uint64_t>(8192, room / (6 * capd) / 512 * 512));
-                }
+                const char *eo = getenv("GS_SPARSE_ROWS"), *el = getenv("GS_SPARSE_L"), *ea = getenv("GS_SPARSE_ARENA_GB"), *eb = getenv("GS_SPARSE_BITMAP_GB");
+                // what the lists and bitmaps may take: what the device keeps free next to the signatures and their column copy AT THE DECLARED CAPACITY
+                // (hnsw_params.capacity: 1.5 M in gsearch) and 40 GB of everything else (adjacency, count matrices, join scratch, the caller's own buffers).
+                // List length: up to 8192 entries - a level of chance matches must fit whole -, less when even half-full lists would not fit
+                const uint64_t capd = std::max<uint64_t>(ix->prm.capacity, ix->cap);
+                const uint64_t fixed = 2 * (uint64_t)ix->stride * capd + ((uint64_t)40 << 30);
+                uint64_t room = c->hbm_bytes > fixed ? c->hbm_bytes - fixed : 0;
+                if (ea) room = (uint64_t)(atof(ea) * 1e9);
+                room = std::min<uint64_t>(room, (uint64_t)120 << 30);                       // (32-bit offsets in 32-byte units reach 128 GB)
+                const uint32_t autoL = (uint32_t)std::max<uint64_t>(2048, std::min<uint64_t>(8192, room / (3 * capd) / 512 * 512));
                 ix->sp_L = (eo && !atoi(eo)) ? 0u : (uint32_t)std::max(64, std::min(32768, el ? atoi(el) : (int)autoL));
+                if (ix->sp_L && !ea && room < ((uint64_t)2 << 30)) ix->sp_L = 0;
+                // (GS_SPARSE_ARENA_CHUNK_MB: the mapping step, 1 GB; tests make it small to fill an arena of a few MB and watch it grow in place)
+                const size_t vm_chunk = getenv("GS_SPARSE_ARENA_CHUNK_MB") ? (size_t)(atof(getenv("GS_SPARSE_ARENA_CHUNK_MB")) * 1048576.0) : ((size_t)1 << 30);
                 if (ix->sp_L) {
-                    if (ix->sp_ids.alloc((size_t)4 * ix->sp_L * ix->cap) != GS_OK || ix->sp_cnt.alloc((size_t)2 * ix->sp_L * ix->cap) != GS_OK || ix->sp_meta.alloc((size_t)8 * ix->cap) != GS_OK ||
-                        ix->sp_bm.alloc((size_t)8 * ix->cap) != GS_OK || ix->sp_arena.alloc(64) != GS_OK) {
-                        (void)hipGetLastError(); ix->sp_ids.release(); ix->sp_cnt.release(); ix->sp_meta.release(); ix->sp_bm.release(); ix->sp_arena.release(); ix->sp_L = 0;
+                    if (!ix->sp_vm.reserve(c->device, std::max<uint64_t>(room, 65536), vm_chunk) || ix->sp_off.alloc((size_t)4 * ix->cap) != GS_OK || ix->sp_meta.alloc((size_t)8 * ix->cap) != GS_OK ||
+                        ix->sp_bm.alloc((size_t)8 * ix->cap) != GS_OK || ix->sp_arena.alloc(sizeof(gs::SpArena)) != GS_OK) {
+                        (void)hipGetLastError(); ix->sp_vm.release(); ix->sp_off.release(); ix->sp_meta.release(); ix->sp_bm.release(); ix->sp_arena.release(); ix->sp_L = 0;
                     } else {
+                        GS_HIP_CHECK(hipMemsetAsync(ix->sp_off.p, 0, (size_t)4 * ix->cap, c->stream));
                         GS_HIP_CHECK(hipMemsetAsync(ix->sp_meta.p, 0, (size_t)8 * ix->cap, c->stream));
                         GS_HIP_CHECK(hipMemsetAsync(ix->sp_bm.p, 0, (size_t)8 * ix->cap, c->stream));
-                        GS_HIP_CHECK(hipMemsetAsync(ix->sp_arena.p, 0, 64, c->stream));
-                        ix->bm_on = !(getenv("GS_SPARSE_BITMAP_GB") && atof(getenv("GS_SPARSE_BITMAP_GB")) <= 0);
+                        gs::SpArena h{};
+                        h.base = (unsigned long long)ix->sp_vm.va;
+                        h.bm_limit = (unsigned long long)((eb ? atof(eb) : 24.0) * 1e9);
+                        if ((double)h.bm_limit > 0.6 * (double)room) h.bm_limit = (unsigned long long)(0.6 * (double)room);
+                        GS_HIP_CHECK(hipMemcpyAsync(ix->sp_arena.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+                        GS_HIP_CHECK(hipStreamSynchronize(c->stream));                  // (h is a local)
+                        ix->sp_reserved = 0;
                     }
                 }
                 // the nodes inserted before this batch have no count rows to take their lists from: one all-pairs tile pass over them (like the dense
@@ -3146,7 +3173,16 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
             else {
                 const size_t rows_wanted = can_group ? (size_t)grp_n * B : (size_t)B;
                 if (!(b0 >= grp_b0 && b0 < grp_end)) {                                    // a new group (or single batch) starts: the buffer may grow now
-                    if (ix->mat.bytes < 2 * rows_wanted * slab_ld && (rc = alloc_or_evict(ix, ix->mat, 2 * rows_wanted * slab_ld))) return rc;
+                    // (with 25 % of headroom, up to the declared capacity: the row length follows the index, and a buffer that is a few rows short at every
+                    // insert call costs a multi-GB hipFree + hipMalloc per call - 183 of them in a 1.5 M-genome build fed 8192 genomes at a time)
+                    const size_t want = 2 * rows_wanted * slab_ld;
+                    if (ix->mat.bytes < want) {
+                        const size_t at_cap = 2 * rows_wanted * gs::round_up(std::max<uint64_t>(ix->prm.capacity, ix->cap), 8);
+                        const size_t ask = std::max(want, std::min(want + want / 4, at_cap));
+                        rc = alloc_or_evict(ix, ix->mat, ask);
+                        if (rc && ask > want) { (void)hipGetLastError(); rc = alloc_or_evict(ix, ix->mat, want); }
+                        if (rc) return rc;
+                    }
                 }
                 out16 = (b0 >= grp_b0 && b0 < grp_end) ? ix->mat.as<uint16_t>() + (b0 - grp_b0) * slab_ld : ix->mat.as<uint16_t>();
             }
@@ -3256,8 +3292,9 @@ static int insert_common(gs_index *ix, const void *sigs, bool on_dev, uint64_t n
         }
         gs::SpArena ar{};
         if (ix->sp_arena.p) GS_HIP_CHECK(hipMemcpy(&ar, ix->sp_arena.p, sizeof(ar), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[GS_SPARSE] n %llu L %u: nodes with a list %llu (at capacity %llu), dense-cache bytes %llu; selection chunks through the lists %llu, candidates checked by streaming rows %llu (both since the index was made); level bitmaps %llu in %llu bytes of chunks, turned away %llu\n",
-                (unsigned long long)ix->n, ix->sp_L, (unsigned long long)with, (unsigned long long)full, (unsigned long long)ix->pair_cache_bytes, ev[2], ev[1], ar.stored, (unsigned long long)ix->bm_bytes, ar.noroom);
+        fprintf(stderr, "[GS_SPARSE] n %llu L %u: nodes with a list %llu (at capacity %llu, turned away %llu), dense-cache bytes %llu; selection chunks through the lists %llu, candidates checked by streaming rows %llu (both since the index was made); arena %.4f GB used of %.4f mapped (%.2f reserved), level bitmaps %llu in %.2f GB, turned away %llu\n",
+                (unsigned long long)ix->n, ix->sp_L, (unsigned long long)with, (unsigned long long)full, ar.lists_noroom, (unsigned long long)ix->pair_cache_bytes, ev[2], ev[1],
+                std::min(ar.off, ar.size) / 1e9, ix->sp_vm.mapped / 1e9, ix->sp_vm.va_bytes / 1e9, ar.stored, std::min(ar.bm_bytes, ar.bm_limit) / 1e9, ar.noroom);
     }
     return GS_OK;
 }

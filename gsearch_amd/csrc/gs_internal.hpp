@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -161,6 +162,7 @@ int run_length_encode_u64(gs_ctx *c, const uint64_t *sorted, uint64_t n, uint64_
 inline size_t kind_bytes(int kind) { return kind == GS_KIND_U16 ? 2 : (kind == GS_KIND_U64 ? 8 : 4); }
 inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
+inline bool mem_verbose() { static const bool v = getenv("GS_MEM_VERBOSE") != nullptr; return v; }   // trace of the allocations of 256 MB and more (stderr)
 struct DevBuf {   // owning device allocation
     void *p = nullptr; size_t bytes = 0;
     DevBuf() = default;
@@ -172,12 +174,77 @@ struct DevBuf {   // owning device allocation
     {
         release();
         if (n == 0) n = 16;
-        GS_HIP_CHECK(hipMalloc(&p, n));
+        const hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess || mem_verbose()) {
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            if (e != hipSuccess) {     // say how much was asked for and what the device had left: "out of memory" alone does not tell a 54 GB block from a 1 MB one
+                p = nullptr;
+                gs::set_error("hipMalloc of %zu bytes failed: %s (%zu of %zu bytes free on the device)", n, hipGetErrorString(e), fr, tot);
+                return GS_ERR_HIP;
+            }
+            if (n >= ((size_t)256 << 20)) fprintf(stderr, "[GS_MEM] + %.2f GB (free after %.2f of %.2f GB)\n", n / 1e9, fr / 1e9, tot / 1e9);
+        }
         bytes = n;
         return GS_OK;
     }
     int ensure(size_t n) { return (n <= bytes && p) ? GS_OK : alloc(n); }
     template <class T> T *as() const { return (T *)p; }
+};
+
+// A device buffer that GROWS IN PLACE (round 5): one reserved range of virtual addresses, physical memory mapped into it 1 GB at a time
+// (hipMemAddressReserve / hipMemCreate / hipMemMap; the chunk size is a parameter so that tests can fill an arena of a few MB). What is already there keeps its address and its content, growing costs neither a second
+// copy next to the first nor a memcpy - the sparse pair rows of an index that is still being built live here (gs_index.hip), addressed by
+// 32-bit offsets from base(). Chunks of more than 2 GB are refused by hipMemSetAccess on this runtime (tools/ubench/vmm_probe.hip).
+struct VmArena {
+    size_t chunk = (size_t)1 << 30;
+    void *va = nullptr; size_t va_bytes = 0, mapped = 0; int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    VmArena() = default;
+    VmArena(const VmArena &) = delete;
+    VmArena &operator=(const VmArena &) = delete;
+    ~VmArena() { release(); }
+    static bool supported(int dev)
+    {
+        int sup = 0;
+        return hipDeviceGetAttribute(&sup, hipDeviceAttributeVirtualMemoryManagementSupported, dev) == hipSuccess && sup != 0;
+    }
+    // address space only (no memory yet); bytes is rounded up to whole chunks. false: not available
+    bool reserve(int dev, size_t bytes, size_t chunk_bytes = (size_t)1 << 30)
+    {
+        release();
+        if (!supported(dev)) return false;
+        chunk = std::max<size_t>(chunk_bytes / 65536 * 65536, 65536);
+        bytes = (bytes + chunk - 1) / chunk * chunk;
+        if (hipMemAddressReserve(&va, bytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); va = nullptr; return false; }
+        va_bytes = bytes; device = dev; mapped = 0;
+        return true;
+    }
+    // at least `bytes` of the range backed by memory. false: the range or the device is full (what is mapped stays)
+    bool map_to(size_t bytes)
+    {
+        if (bytes > va_bytes) return false;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice; acc.location.id = device; acc.flags = hipMemAccessFlagsProtReadWrite;
+        while (mapped < bytes) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipMemMap((char *)va + mapped, chunk, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+            if (hipMemSetAccess((char *)va + mapped, chunk, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap((char *)va + mapped, chunk); (void)hipMemRelease(h); return false; }
+            handles.push_back(h); mapped += chunk;
+            if (mem_verbose()) fprintf(stderr, "[GS_MEM] arena: %.2f GB mapped of %.2f GB reserved\n", mapped / 1e9, va_bytes / 1e9);
+        }
+        return true;
+    }
+    void release()
+    {
+        for (size_t i = 0; i < handles.size(); i++) { (void)hipMemUnmap((char *)va + i * chunk, chunk); (void)hipMemRelease(handles[i]); }
+        handles.clear();
+        if (va) (void)hipMemAddressFree(va, va_bytes);
+        va = nullptr; va_bytes = 0; mapped = 0;
+    }
 };
 
 // Per-context scratch: a call's temporaries come from numbered grow-only slots instead of hipMalloc/hipFree (allocating and freeing

@@ -779,7 +779,8 @@ def test_insert_prepass_builds_the_oracle_graph(gpu_ctx, monkeypatch, dtype, M, 
 
 
 @pytest.mark.parametrize("L,grp,data", [("4096", None, "families"), ("192", None, "families"), ("192", "1", "families"), ("64", "3", "families"),
-                                        ("4096", None, "noise"), ("512", None, "noise"), ("512", "0", "noise")])
+                                        ("4096", None, "noise"), ("512", None, "noise"), ("512", "0", "noise"),
+                                        ("4096", "grow", "families"), ("512", "full", "noise")])
 def test_insert_with_sparse_pair_rows_builds_the_oracle_graph(gpu_ctx, monkeypatch, capfd, L, grp, data):
     """round 5: with the dense pair cache switched off (GS_PAIR_CACHE_GB=0 - what a build beyond ~400 k genomes runs into) the selection heuristic
     takes c(e,s) from the SPARSE pair rows: every node keeps the counts of its <= L closest older nodes and a cut; a pair that is not listed lies above
@@ -787,7 +788,8 @@ def test_insert_with_sparse_pair_rows_builds_the_oracle_graph(gpu_ctx, monkeypat
     list of 4096 holds a family and the best of the chance level, lists of 192 / 64 are cut inside the family (candidates above the cut: the level bitmap
     one level below the cut, then the streaming path, must agree too). "noise": 21 000 unrelated rows over a narrow value band - every pair agrees in
     ~16 +- 4 of 96 slots, so the lists are cut in the middle of the bulk and the selection walks are long. grp "0": without the level bitmaps
-    (GS_SPARSE_BITMAP_GB=0). Graph (levels, degrees, neighbour ids AND their counts) == oracle; batches joined in groups without a slab (group buffer)."""
+    (GS_SPARSE_BITMAP_GB=0). "grow": the arena the lists live in is mapped 4 MB at a time (it grows in place under the lists already written); "full": an arena
+    of 24 MB that fills up half-way - the later nodes get no list and their pairs are checked by streaming rows. Graph (levels, degrees, neighbour ids AND their counts) == oracle; batches joined in groups without a slab (group buffer)."""
     import gsearch_amd as G
     monkeypatch.setenv("GS_DIST_MODE", "dense")
     monkeypatch.setenv("GS_PAIR_CACHE_GB", "0")
@@ -795,6 +797,10 @@ def test_insert_with_sparse_pair_rows_builds_the_oracle_graph(gpu_ctx, monkeypat
     monkeypatch.setenv("GS_SPARSE_VERBOSE", "1")
     if grp == "0":
         monkeypatch.setenv("GS_SPARSE_BITMAP_GB", "0")
+    elif grp == "grow":
+        monkeypatch.setenv("GS_SPARSE_ARENA_GB", "1"); monkeypatch.setenv("GS_SPARSE_ARENA_CHUNK_MB", "4")
+    elif grp == "full":
+        monkeypatch.setenv("GS_SPARSE_ARENA_GB", "0.024"); monkeypatch.setenv("GS_SPARSE_ARENA_CHUNK_MB", "2")
     elif grp is not None:
         monkeypatch.setenv("GS_INSERT_GROUP", grp)
     m, M, efc = 96, 10, 48
@@ -813,7 +819,13 @@ def test_insert_with_sparse_pair_rows_builds_the_oracle_graph(gpu_ctx, monkeypat
     last = [l for l in err.splitlines() if l.startswith("[GS_SPARSE]")][-1]
     f = last.replace(",", " ").replace(":", " ").replace("(", " ").replace(")", " ").replace(";", " ").split()
     with_list = int(f[f.index("list") + 1]); chunks = int(f[f.index("lists") + 1]); dense_bytes = int(f[f.index("bytes") + 1])
-    assert dense_bytes == 0 and with_list == len(db) and chunks > (len(db) if data == "noise" else 1000), last
+    away = int(f[f.index("away") + 1]); mapped = float(f[f.index("mapped") - 1])
+    if grp == "full":
+        assert dense_bytes == 0 and 0 < with_list < len(db) and with_list + away == len(db) and mapped <= 0.0262, last             # (24 MB rounded up to whole 2 MiB steps)
+    else:
+        assert dense_bytes == 0 and with_list == len(db) and away == 0 and chunks > (len(db) if data == "noise" else 1000), last
+    if grp == "grow":
+        assert 0.008 < mapped < 0.5, last                                # several 4 MB steps, far from the 1 GB it may take
     g = hn.export_graph()
     assert np.array_equal(g["levels"], og["levels"]) and np.array_equal(g["deg0"], og["deg0"])
     for i in range(len(db)):
