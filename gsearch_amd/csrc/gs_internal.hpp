@@ -195,7 +195,7 @@ struct DevBuf {   // owning device allocation
 // A device buffer that GROWS IN PLACE (round 5): one reserved range of virtual addresses, physical memory mapped into it 1 GB at a time
 // (hipMemAddressReserve / hipMemCreate / hipMemMap; the chunk size is a parameter so that tests can fill an arena of a few MB). What is already there keeps its address and its content, growing costs neither a second
 // copy next to the first nor a memcpy - the sparse pair rows of an index that is still being built live here (gs_index.hip), addressed by
-// 32-bit offsets from base(). Chunks of more than 2 GB are refused by hipMemSetAccess on this runtime (tools/ubench/vmm_probe.hip).
+// 32-bit offsets from base(). Chunks of more than 2 GB are refused by hipMemSetAccess on this runtime (tools/ubench_vmm.hip).
 struct VmArena {
     size_t chunk = (size_t)1 << 30;
     void *va = nullptr; size_t va_bytes = 0, mapped = 0; int device = 0;

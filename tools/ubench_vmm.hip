@@ -1,3 +1,4 @@
+// build: hipcc -O2 --offload-arch=gfx950 -o tools/ubench_vmm tools/ubench_vmm.hip   (measured: profiles/r05_ubench_vmm.txt)
 // Probe: does this device / runtime support HIP virtual memory management (reserve an address range, map physical chunks into it as needed)?
 // Prints the allocation granularity and the time to create + map + set access for chunks, then checks a kernel can write across chunk borders.
 #include <hip/hip_runtime.h>
@@ -65,9 +66,31 @@ int main()
     for (size_t i = 0; i < nchunks; i++) { CK(hipMemUnmap((char *)va + i * chunk, chunk)); CK(hipMemRelease(h[i])); }
     CK(hipMemAddressFree(va, (size_t)256 << 30));
     CK(hipMemGetInfo(&fr, &tot)); printf("after release: free %zu of %zu\n", fr, tot);
-    // hipMalloc + memcpy path for comparison: 8 GB
-    { void *p; auto t0 = std::chrono::steady_clock::now(); CK(hipMalloc(&p, (size_t)8 << 30)); auto t1 = std::chrono::steady_clock::now(); CK(hipFree(p)); auto t2 = std::chrono::steady_clock::now();
-      printf("hipMalloc 8 GB %.2f ms, hipFree %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count()); }
+    // hipMalloc for comparison, three times over (the first large allocation of a process pays for more than itself), then the same 8 GB as 1 GB mappings
+    for (int rep = 0; rep < 3; rep++) {
+        void *p; auto t0 = std::chrono::steady_clock::now(); CK(hipMalloc(&p, (size_t)8 << 30)); auto t1 = std::chrono::steady_clock::now();
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        CK(hipEventRecord(a)); fill<<<(unsigned)((((size_t)8 << 30) / 8 + 255) / 256), 256>>>((unsigned long long *)p, 0, ((size_t)8 << 30) / 8); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+        auto t2 = std::chrono::steady_clock::now(); CK(hipFree(p)); auto t3 = std::chrono::steady_clock::now();
+        printf("hipMalloc 8 GB %.2f ms, first fill %.2f ms, hipFree %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, std::chrono::duration<double, std::milli>(t3 - t2).count());
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        void *v2 = nullptr; CK(hipMemAddressReserve(&v2, (size_t)8 << 30, 0, nullptr, 0));
+        hipMemGenericAllocationHandle_t hh[8];
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 8; i++) { CK(hipMemCreate(&hh[i], chunk, &prop, 0)); CK(hipMemMap((char *)v2 + i * chunk, chunk, 0, hh[i], 0)); CK(hipMemSetAccess((char *)v2 + i * chunk, chunk, &acc, 1)); }
+        CK(hipDeviceSynchronize());
+        auto t1 = std::chrono::steady_clock::now();
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        CK(hipEventRecord(a)); fill<<<(unsigned)((((size_t)8 << 30) / 8 + 255) / 256), 256>>>((unsigned long long *)v2, 0, ((size_t)8 << 30) / 8); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+        auto t2 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 8; i++) { CK(hipMemUnmap((char *)v2 + i * chunk, chunk)); CK(hipMemRelease(hh[i])); }
+        CK(hipMemAddressFree(v2, (size_t)8 << 30));
+        auto t3 = std::chrono::steady_clock::now();
+        printf("8 x 1 GB mapped %.2f ms, first fill %.2f ms, released %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), ms, std::chrono::duration<double, std::milli>(t3 - t2).count());
+    }
     printf("OK\n");
     return 0;
 }
