@@ -746,6 +746,123 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
     io.nT = nT; io.evals += s_cnt[2]; io.pops = st_p2; io.nlog = s_cnt[3];
 }
 
+// wave-wide register moves for the PQ front (one key per lane of wavefront 0): DPP wave shifts and v_readlane instead of __shfl (ds_bpermute: an LDS
+// round trip per 32 bits - the 64-bit min-reduction and the shuffles of one insertion cost more than the merge they replaced)
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v)          // lane i <- lane i - 1 (lane 0 keeps its value)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t wave_shl1_u64(uint64_t v)          // lane i <- lane i + 1 (lane 63 keeps its value)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x130, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, false);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)   // l wave-uniform
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
+}
+// PQ (late round 5; see the kernel): refill of the front / compaction of the overflow U. All lanes call. src[0..nU) -> dst: keys whose count lies above
+// `dlimit` are dropped (dead: nothing that large is ever popped again). sel: the front is empty and takes the <= 64 smallest keys of what is left -
+// the smallest live key fixes the count level, and an id boundary `cut` is found by histogram refinement: 256 bins over the id range, as many
+// leading bins as fit the quota, then the bin that straddles it is binned again (ids are distinct inside a level, so bins of one id always resolve;
+// <= 4 rounds for 2^32 ids, one in practice). Leaves the new front in wavefront 0's registers and its first three keys in S.W[fb..], the new
+// length of U in S.scal[4] (the caller swaps the buffers). LDS scratch: S.hist[0..256), S.N (staging), S.scal[5..6], S.wsum[32..40).
+__device__ __forceinline__ void pq_rebuild(const IndexDev &ix, const DenseLds &S, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t capC, uint32_t nU,
+                                           bool sel, uint32_t dlimit, uint64_t &pkey, uint64_t &pv, uint32_t &nP, uint32_t fb)
+{
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = nU < capC ? nU : capC;
+    unsigned long long *smin = (unsigned long long *)&S.scal[5];
+    uint32_t *cnt = (uint32_t *)&S.scal[6];                  // [0] selected, [1] kept
+    uint32_t *ctl = S.wsum + 32;                             // [0] done, [1..2] cut (64 bit), [3] quota used so far
+    __syncthreads();                                         // U's appends (global stores of wavefront 0) are in; the pop's LDS scratch is dead
+    if (threadIdx.x == 0) { *smin = ~0ull; cnt[0] = 0; cnt[1] = 0; }
+    __syncthreads();
+    uint32_t cmin = 0; uint64_t cut = 0; bool has = false;
+    if (sel) {
+        uint64_t mn = ~(uint64_t)0;
+        for (uint32_t i = threadIdx.x; i < n; i += DT) { const uint64_t k = src[i]; if (KCNT(k) <= dlimit && k < mn) mn = k; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint64_t y = __shfl_xor(mn, o); mn = y < mn ? y : mn; }
+        if (lane == 0 && mn != ~(uint64_t)0) atomicMin(smin, (unsigned long long)mn);
+        __syncthreads();
+        const uint64_t kmin = *smin;
+        has = kmin != ~(uint64_t)0;
+        if (has) {
+            cmin = KCNT(kmin);
+            uint32_t bits = 1; while (bits < 32 && ((uint64_t)1 << bits) < ix.n) bits++;
+            uint32_t lo = 0, acc = 0;
+            for (;;) {
+                const uint32_t sh = bits > 8 ? bits - 8 : 0;
+                __syncthreads();                             // the round before has read hist / ctl
+                if (threadIdx.x < 256) S.hist[threadIdx.x] = 0;
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < n; i += DT) {
+                    const uint64_t k = src[i];
+                    if (KCNT(k) == cmin && KID(k) >= lo) { const uint32_t r = KID(k) - lo; if ((r >> sh) < 256u) atomicAdd(&S.hist[r >> sh], 1u); }
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    const uint32_t h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2], h3 = S.hist[4 * lane + 3];
+                    const uint32_t sum = h0 + h1 + h2 + h3;
+                    uint32_t inc = sum;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+                    const uint32_t room = 64u - acc;
+                    const uint32_t c0 = inc - sum + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;      // inclusive running totals: monotone, so the bins that fit are a prefix
+                    uint32_t j = (c0 <= room) + (c1 <= room) + (c2 <= room) + (c3 <= room);
+                    uint32_t tk = c3 <= room ? c3 : (c2 <= room ? c2 : (c1 <= room ? c1 : (c0 <= room ? c0 : 0u)));
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { j += __shfl_xor(j, o); const uint32_t y = __shfl_xor(tk, o); tk = y > tk ? y : tk; }
+                    if (lane == 0) {
+                        const bool all = j == 256u;
+                        const uint64_t cu = all ? (uint64_t)lo + ((uint64_t)256 << sh) : (uint64_t)lo + ((uint64_t)j << sh);
+                        ctl[0] = (all || sh == 0 || acc + tk >= 32u) ? 1u : 0u;
+                        ctl[1] = (uint32_t)cu; ctl[2] = (uint32_t)(cu >> 32); ctl[3] = acc + tk;
+                    }
+                }
+                __syncthreads();
+                cut = (uint64_t)ctl[1] | ((uint64_t)ctl[2] << 32); acc = ctl[3];
+                if (ctl[0]) break;
+                lo = (uint32_t)cut; bits = sh;                // inside the bin that straddles the quota
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += DT) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint64_t k = i < n ? src[i] : ~(uint64_t)0;
+        const bool live = i < n && KCNT(k) <= dlimit;
+        const bool isS = live && has && KCNT(k) == cmin && (uint64_t)KID(k) < cut, isK = live && !isS;
+        const uint64_t bS = __ballot(isS), bK = __ballot(isK);
+        uint32_t baseS = 0, baseK = 0;
+        if (lane == 0) { if (bS) baseS = atomicAdd(&cnt[0], (uint32_t)__popcll(bS)); if (bK) baseK = atomicAdd(&cnt[1], (uint32_t)__popcll(bK)); }
+        baseS = __shfl(baseS, 0); baseK = __shfl(baseK, 0);
+        if (isS) { const uint32_t pos = baseS + (uint32_t)__popcll(bS & ((1ull << lane) - 1)); if (pos < 64u) S.N[pos] = k; }
+        if (isK) dst[baseK + (uint32_t)__popcll(bK & ((1ull << lane) - 1))] = k;
+    }
+    __syncthreads();
+    const uint32_t nsel = cnt[0] < 64u ? cnt[0] : 64u, nkeep = cnt[1];
+    if (sel && wv == 0) {                                    // rank sort of the <= 64 selected keys
+        const uint64_t k = lane < nsel ? S.N[lane] : ~(uint64_t)0;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nsel; j++) rank += (S.N[j] < k);
+        if (lane < nsel) S.N[64 + rank] = k;
+    }
+    __syncthreads();
+    if (sel && wv == 0) {
+        pkey = lane < nsel ? S.N[64 + lane] : ~(uint64_t)0;
+        nP = nsel;
+        pv = (nkeep && nsel) ? __shfl(pkey, (int)nsel - 1) : ~(uint64_t)0;      // everything left in U is larger than everything taken
+        if (lane < 3) S.W[fb + lane] = pkey;
+    }
+    if (threadIdx.x == 0) S.scal[4] = nkeep;
+    __syncthreads();
+}
+
 // ONEG: max_nb_conn > 128 (adjacency rows of up to 512 ids): all 512 lanes form ONE group that expands a candidate, then does the visited
 // hint + lookups of the next one and fetches the row of the one after - the three stages the two 256-lane halves otherwise share out
 // WLOG (insert-time pre-pass): every accepted key is also appended to a per-workgroup log; R is always "the ef smallest
@@ -769,6 +886,17 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     const uint32_t visg_words = SPLIT && ix.n > vis_w ? (uint32_t)((ix.n - vis_w + 31) / 32) : 0u;
     uint32_t st_pops = 0, st_acc = 0, st_p1 = 0, st_p2 = 0;                 // work counters (workgroup-uniform): pops / accepting pops / pops before dmax reached tau, of this workgroup (< 2^32)
     constexpr bool PHASE2 = true;       // (round 4: also with the visited bitmap in global memory - indexes beyond ~600 k nodes: test-and-set through L2 atomics)
+    // PQ (late round 5): the waiting candidates are a FRONT of up to 64 keys, sorted, one per lane in the registers of wavefront 0 (insert = ballot +
+    // shuffle, no LDS array to merge into, no barrier per key), over an UNSORTED overflow U in global memory that every key beyond the front's fence `pv`
+    // is simply appended to (max(front) <= pv <= min(U)). The front publishes its first three keys to LDS after every change - all the other waves ever
+    // need - and is refilled from U by selection (the <= 64 smallest keys of U's best count level, `pq_rebuild`) when it runs empty, every ~50-90 pops in
+    // the flood regime. It replaces G (sorted, global) + its LDS window + N (sorted, LDS) and with them the rank sort of the accepted keys, the N merge
+    // and the fold of N into G of every accepting pop: 6.7 k of that pop's 10.3 k cycles (NOTES.md round 4, GS_TRAV_PROFILE). -DGS_DENSE_PQ_OFF: the old form.
+#ifdef GS_DENSE_PQ_OFF
+    constexpr bool PQ = false;
+#else
+    constexpr bool PQ = true;
+#endif
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, n_pop = 0, n_merge = 0;   // GS_TRAV_PROFILE: cycle stamps of workgroup 0
     long long tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tna = 0;
     constexpr uint32_t CN = ONEG ? 512u : (uint32_t)DCN;         // capacity of N: >= 2M (an empty N takes a whole expansion), one key per lane in its merge
@@ -838,8 +966,13 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         uint32_t nR = 1, nT = 1, nG = 0, headG = 0, wbase = 0, wn = 0, nN = 1, headN = 0;
         uint32_t dmax = INF_CNT, tieT = 0;                       // worst count of a full R / #keys of R tied at it
         uint64_t Tmax = 0;                                       // T[knbn-1] once T is full
+        // PQ: this lane's key of the front (wavefront 0 only; ~0 = empty), the fence, the sizes of front and overflow, where the last compaction left U
+        uint64_t pkey = ~(uint64_t)0, pv = ~(uint64_t)0;
+        uint32_t nP = 1, nU = 0, nU_lc = 0;
         __syncthreads();
         if (threadIdx.x < 3) { S.W[threadIdx.x] = ~(uint64_t)0; S.N[1 + threadIdx.x] = ~(uint64_t)0; }
+        if (PQ && threadIdx.x < 8) S.W[threadIdx.x] = threadIdx.x == 0 ? KEY(ep_cnt, ep) : ~(uint64_t)0;
+        if (PQ && threadIdx.x == 0) pkey = KEY(ep_cnt, ep);
         if (threadIdx.x == 0) {
             S.T[0] = KEY(ep_cnt, ep); S.N[0] = KEY(ep_cnt, ep);
             if (WLOG) wl[0] = KEY(ep_cnt, ep);
@@ -865,6 +998,26 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         bool phase2 = false;
         for (;;) {
             if (PHASE2 && dmax == tau && !(cap_log & 1u)) { phase2 = true; break; }       // R holds efs keys <= tau (or n < efs): the rest is order-free
+            uint64_t c, c1, c2;
+            const bool full = nR == efs;
+            const uint32_t fb = (it & 1u) * 4u;                      // PQ: the front's first three keys are published twice over, by pop parity
+            if (PQ) {
+                c = S.W[fb]; c1 = S.W[fb + 1]; c2 = S.W[fb + 2];
+                // the front is empty: refill it from U; U has outgrown its buffer: drop its dead keys (counts above dmax)
+                const bool empty = c == ~(uint64_t)0, crowded = nU + maxdeg > capC && nU - nU_lc >= maxdeg;
+                if (empty && nU == 0) break;
+                if (empty || crowded) {
+                    pq_rebuild(ix, S, Cb[cur], Cb[cur ^ 1], capC, nU, empty, full ? dmax : INF_CNT, pkey, pv, nP, fb);
+                    cur ^= 1; nU = (uint32_t)S.scal[4]; nU_lc = nU;
+                    continue;
+                }
+                if (KCNT(c) > dmax) break;                           // dmax is INF_CNT until R is full; the front's head is the smallest waiting key
+                if (wv == 0) {                                       // pop: the front moves down one lane; what the next pop sees if this one accepts nothing
+                    pkey = wave_shl1_u64(pkey); if (lane == 63) pkey = ~(uint64_t)0;
+                    nP--;
+                    if (lane < 3) S.W[(fb ^ 4u) + lane] = pkey;
+                }
+            } else {
             if (headG < nG && headG - wbase >= wn) {                 // refill the LDS window of G
                 __syncthreads();
                 wbase = headG; wn = nG - headG < (uint32_t)DWIN ? nG - headG : (uint32_t)DWIN;
@@ -878,13 +1031,12 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             // the search exactly like "no candidate" does)
             const uint64_t g0 = S.W[wo], g1 = S.W[wo + 1], g2 = S.W[wo + 2];
             const uint64_t n0 = S.N[headN], n1 = S.N[headN + 1], n2 = S.N[headN + 2];
-            const uint64_t c = g0 < n0 ? g0 : n0;
+            c = g0 < n0 ? g0 : n0;
             if (c == ~(uint64_t)0) break;
-            const bool full = nR == efs;
             if (KCNT(c) > dmax) break;                               // dmax is INF_CNT until R is full
-            uint64_t c1, c2;
             if (g0 < n0) { headG++; c1 = g1 < n0 ? g1 : n0; c2 = g1 < n0 ? (g2 < n0 ? g2 : n0) : (g1 < n1 ? g1 : n1); }
             else { headN++; c1 = g0 < n1 ? g0 : n1; c2 = g0 < n1 ? (g1 < n1 ? g1 : n1) : (g0 < n2 ? g0 : n2); }
+            }
             const long long p0 = PROF ? clock64() : 0;
             uint32_t id = 0, cntv = 0; bool unv = false;
             if (ONEG || half == (it & 1)) {
@@ -1030,7 +1182,45 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             if (na == 0) continue;
             n_merge++; st_acc++;
             // accepted keys: histogram update, compaction (ballot prefix) into As, then rank-sort the na (usually 1-5) keys into A
-            {
+            uint64_t minA = 0;
+            const uint32_t fbn = (it & 1u) * 4u;                     // (it has moved on: the slot the next pop reads)
+            if (PQ) {
+                if (acc) { hist_add<VLDS>(hs, ci, 1); S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey; }
+                lds_barrier();
+                if (wv == 0) {
+                    // wavefront 0 takes the accepted keys 64 at a time: beyond the fence -> appended to U as they are (one coalesced store); below
+                    // it -> into the sorted front, one after the other (position = ballot of "my key is smaller", everything behind moves up one
+                    // lane, a full front hands its largest key to U and the fence comes down to the new largest)
+                    uint64_t tany = 0;                                 // some accepted key lies below T's largest: T has to take this pop's keys in
+                    uint64_t *U = Cb[cur];
+                    uint32_t nu = nU;
+                    for (uint32_t b0 = 0; b0 < na; b0 += 64) {
+                        const uint64_t k = b0 + lane < na ? S.As[b0 + lane] : ~(uint64_t)0;
+                        tany |= __ballot(k < Tmax);
+                        const bool toU = k != ~(uint64_t)0 && k >= pv;
+                        const uint64_t bu = __ballot(toU);
+                        if (toU) { const uint32_t pos = nu + (uint32_t)__popcll(bu & ((1ull << lane) - 1)); if (pos < capC) U[pos] = k; }
+                        nu += (uint32_t)__popcll(bu);
+                        uint64_t pend = __ballot(k != ~(uint64_t)0 && k < pv);
+                        while (pend) {
+                            const int l = __ffsll((long long)pend) - 1;
+                            pend &= pend - 1;
+                            const uint64_t kk = readlane_u64(k, l);
+                            if (kk >= pv) { if (lane == 0 && nu < capC) U[nu] = kk; nu++; continue; }      // the fence has come down since
+                            const uint32_t pos = (uint32_t)__popcll(__ballot(pkey < kk));
+                            const uint64_t ev = readlane_u64(pkey, 63), up = wave_shr1_u64(pkey);
+                            pkey = lane < pos ? pkey : (lane == pos ? kk : up);
+                            if (ev != ~(uint64_t)0) { if (lane == 0 && nu < capC) U[nu] = ev; nu++; }
+                            else nP++;
+                            if (nP == 64) pv = readlane_u64(pkey, 63);
+                        }
+                    }
+                    if (lane < 3) S.W[fbn + lane] = pkey;
+                    if (lane == 0) { S.scal[4] = nu; S.scal[5] = tany ? 0 : ~(uint64_t)0; }
+                }
+                lds_barrier();
+                nU = (uint32_t)S.scal[4]; minA = S.scal[5];
+            } else {
                 if (acc) { hist_add<VLDS>(hs, ci, 1); S.As[aoff + (uint32_t)__popcll(ab & ((1ull << lane) - 1))] = mykey; }
                 lds_barrier();
                 if (threadIdx.x < na) {
@@ -1042,12 +1232,12 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 }
                 lds_barrier();
             }
-            if (WLOG) { if (nlog + na <= cap_log && threadIdx.x < na) wl[nlog + threadIdx.x] = S.A[threadIdx.x]; nlog += na; }
+            if (WLOG) { if (nlog + na <= cap_log && threadIdx.x < na) wl[nlog + threadIdx.x] = PQ ? S.As[threadIdx.x] : S.A[threadIdx.x]; nlog += na; }
             {   // the candidate order has changed: start loading the adjacency of the two candidates that now come first
-                // (first two of merge(A, {c1, c2})) so that the loads overlap with the rest of the merge
-                const uint64_t a0 = S.A[0], a1 = na > 1 ? S.A[1] : ~(uint64_t)0;
-                const uint64_t n1 = a0 < c1 ? a0 : c1;
-                const uint64_t n2 = a0 < c1 ? (a1 < c1 ? a1 : c1) : (a0 < c2 ? a0 : c2);
+                // (first two of merge(A, {c1, c2}); PQ: the front as wavefront 0 has just published it) so that the loads overlap with the rest of the merge
+                const uint64_t a0 = PQ ? 0 : S.A[0], a1 = PQ ? 0 : (na > 1 ? S.A[1] : ~(uint64_t)0);
+                const uint64_t n1 = PQ ? S.W[fbn] : (a0 < c1 ? a0 : c1);
+                const uint64_t n2 = PQ ? S.W[fbn + 1] : (a0 < c1 ? (a1 < c1 ? a1 : c1) : (a0 < c2 ? a0 : c2));
                 if (!ONEG) {
                     const uint64_t want = half == (it & 1) ? n1 : n2;
                     if (want != ~(uint64_t)0 && pk != want) {
@@ -1097,6 +1287,24 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
             } else nR += na;
             const uint32_t dnew = dmax;                              // INF_CNT while R is not full
             const long long q2 = PROF ? clock64() : 0;
+            if (PQ) {
+                // T <- knbn smallest of T u A, only when A reaches into it (1-2 % of the pops): that merge wants A sorted
+                if (nT < knbn || minA < Tmax) {
+                    if (threadIdx.x < na) {
+                        const uint64_t k = S.As[threadIdx.x];
+                        uint32_t rank = 0;
+#pragma unroll 8
+                        for (uint32_t j = 0; j < na; j++) rank += (S.As[j] < k);
+                        S.A[rank] = k;
+                    }
+                    lds_barrier();
+                    const SmallA sa = load_small_a(S.A, na);
+                    nT = dense_merge_T(S.T, nT, S.A, na, knbn, sa);
+                    if (nT == knbn) Tmax = S.T[knbn - 1];
+                }
+                if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const long long q4 = clock64(); t_e += q4 - p4; tq1 += q1 - p4; tq2 += q2 - q1; tq4 += q4 - q2; tna += na; }
+                continue;
+            }
             const SmallA sa = load_small_a(S.A, na);
             // T <- knbn smallest of T u A (only when A reaches into it)
             if (nT < knbn || S.A[0] < Tmax) {
@@ -1180,6 +1388,11 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
         const long long tm2 = tm ? clock64() : 0;
         if (PHASE2 && phase2) {
             Phase2IO io{nT, evals, 0u, tm, 0, 0, wl, cap_log, nlog};
+            if (PQ) {                                                // the waiting candidates as phase 2 reads them: "G" = U (it only filters), "N" = the front
+                if (wv == 0) { S.N[lane] = pkey; if (lane == 0) S.scal[6] = nP; }
+                __syncthreads();
+                headG = 0; nG = nU < capC ? nU : capC; headN = 0; nN = (uint32_t)S.scal[6];
+            }
             dense_phase2<ONEG, WLOG, SPLIT>(ix, S, vis, matrow, tau, knbn, Cb[cur], Cb[cur ^ 1], headG, nG, headN, nN, Tmax, io, vis_w, visg);
             nT = io.nT; evals = io.evals; st_pops += io.pops; st_p2 += io.pops; nlog = io.nlog;
             if (tm) { atomicAdd(&stats[13], (unsigned long long)(io.c_build - tm2)); atomicAdd(&stats[14], (unsigned long long)(io.c_drain - io.c_build)); }
