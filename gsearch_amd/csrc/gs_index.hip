@@ -765,84 +765,163 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)   // l wave-
     return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
 }
 // PQ (late round 5; see the kernel): refill of the front / compaction of the overflow U. All lanes call. src[0..nU) -> dst: keys whose count lies above
-// `dlimit` are dropped (dead: nothing that large is ever popped again). sel: the front is empty and takes the <= 64 smallest keys of what is left -
-// the smallest live key fixes the count level, and an id boundary `cut` is found by histogram refinement: 256 bins over the id range, as many
-// leading bins as fit the quota, then the bin that straddles it is binned again (ids are distinct inside a level, so bins of one id always resolve;
-// <= 4 rounds for 2^32 ids, one in practice). Leaves the new front in wavefront 0's registers and its first three keys in S.W[fb..], the new
-// length of U in S.scal[4] (the caller swaps the buffers). LDS scratch: S.hist[0..256), S.N (staging), S.scal[5..6], S.wsum[32..40).
+// `dlimit` are dropped (dead: nothing that large is ever popped again). sel: the front is empty and takes the <= 64 smallest keys of what is left:
+// a histogram over the count LEVELS (relative to the smallest live key's) says which levels fit whole, and inside the level that straddles the quota
+// an id boundary is found by histogram refinement - 256 bins over the id range, as many leading bins as fit, then the bin that straddles the rest is
+// binned again (ids are distinct inside a level, so bins of one id always resolve; <= 4 rounds for 2^32 ids, one in practice). The selection is
+// "key < cutkey". The level the front was last cut in is, as a rule, where the next refill starts, so its two histograms are made speculatively
+// during the pass that finds the smallest key: a refill is then two passes over U (four keys in flight per lane), three when the guess fails.
+// Leaves the new front in wavefront 0's registers and its first three keys in S.W[fb..], the new length of U in S.scal[4] (the caller swaps the
+// buffers). LDS scratch: S.hist[0..256) (ids), S.N[128..256) (levels), S.N[0..128) (staging), S.scal[5..6], S.wsum[32..40).
 __device__ __forceinline__ void pq_rebuild(const IndexDev &ix, const DenseLds &S, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t capC, uint32_t nU,
-                                           bool sel, uint32_t dlimit, uint64_t &pkey, uint64_t &pv, uint32_t &nP, uint32_t fb)
+                                           bool sel, uint32_t dlimit, uint64_t &pkey, uint64_t &pv, uint32_t &nP, uint32_t fb, unsigned long long &stat)
 {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t n = nU < capC ? nU : capC;
+    uint32_t rounds = 0;
     unsigned long long *smin = (unsigned long long *)&S.scal[5];
     uint32_t *cnt = (uint32_t *)&S.scal[6];                  // [0] selected, [1] kept
-    uint32_t *ctl = S.wsum + 32;                             // [0] done, [1..2] cut (64 bit), [3] quota used so far
+    uint32_t *ctl = S.wsum + 32;                             // [0] done, [1..2] cut (64 bit), [3] quota used so far, [4] the level the histograms were made for, [5] levels that fit whole
+    uint32_t *lvl = (uint32_t *)(S.N + 128);                 // 256 level bins
+    constexpr int NF = 4;                                    // keys of U in flight per lane: the passes are chains of global round trips otherwise
+    __syncthreads();                                         // every wave is done with the pop before (S.scal[4..5], its LDS scratch)
+    if (threadIdx.x == 0) {
+        *smin = ~0ull; cnt[0] = 0; cnt[1] = 0;
+        ctl[4] = pv != ~(uint64_t)0 ? KCNT(pv) : 0xFFFFFFFFu;
+    }
+    if (threadIdx.x < 256) { S.hist[threadIdx.x] = 0; lvl[threadIdx.x] = 0; }
     __syncthreads();                                         // U's appends (global stores of wavefront 0) are in; the pop's LDS scratch is dead
-    if (threadIdx.x == 0) { *smin = ~0ull; cnt[0] = 0; cnt[1] = 0; }
-    __syncthreads();
-    uint32_t cmin = 0; uint64_t cut = 0; bool has = false;
+    uint64_t cutkey = 0;
+    uint32_t bits = 1; while (bits < 32 && ((uint64_t)1 << bits) < ix.n) bits++;
+    // level tally: the two or three levels that hold nearly everything go through ballots (one LDS atomic per wave instead of one per key on one address)
+    auto tally_level = [&](bool on, uint32_t d) {
+#pragma unroll
+        for (uint32_t t = 0; t < 3; t++) { const uint64_t bb = __ballot(on && d == t); if (bb && lane == 0) atomicAdd(&lvl[t], (uint32_t)__popcll(bb)); }
+        if (on && d >= 3) atomicAdd(&lvl[d < 255u ? d : 255u], 1u);
+    };
     if (sel) {
+        const uint32_t guess = ctl[4], sh0 = bits > 8 ? bits - 8 : 0;
         uint64_t mn = ~(uint64_t)0;
-        for (uint32_t i = threadIdx.x; i < n; i += DT) { const uint64_t k = src[i]; if (KCNT(k) <= dlimit && k < mn) mn = k; }
+        for (uint32_t i0 = 0; i0 < n; i0 += NF * DT) {
+            uint64_t kf[NF];
+#pragma unroll
+            for (int u = 0; u < NF; u++) { const uint32_t i = i0 + u * DT + threadIdx.x; kf[u] = i < n ? src[i] : ~(uint64_t)0; }
+#pragma unroll
+            for (int u = 0; u < NF; u++) {
+                const uint64_t k = kf[u];
+                const bool live = k != ~(uint64_t)0 && KCNT(k) <= dlimit;
+                if (live && k < mn) mn = k;
+                tally_level(live && KCNT(k) >= guess, KCNT(k) - guess);
+                if (live && KCNT(k) == guess) atomicAdd(&S.hist[KID(k) >> sh0], 1u);
+            }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint64_t y = __shfl_xor(mn, o); mn = y < mn ? y : mn; }
         if (lane == 0 && mn != ~(uint64_t)0) atomicMin(smin, (unsigned long long)mn);
         __syncthreads();
         const uint64_t kmin = *smin;
-        has = kmin != ~(uint64_t)0;
-        if (has) {
-            cmin = KCNT(kmin);
-            uint32_t bits = 1; while (bits < 32 && ((uint64_t)1 << bits) < ix.n) bits++;
-            uint32_t lo = 0, acc = 0;
-            for (;;) {
-                const uint32_t sh = bits > 8 ? bits - 8 : 0;
-                __syncthreads();                             // the round before has read hist / ctl
-                if (threadIdx.x < 256) S.hist[threadIdx.x] = 0;
+        if (kmin != ~(uint64_t)0) {
+            const uint32_t cmin = KCNT(kmin);
+            if (cmin != guess) {                             // the guess failed (first refill of a query, a level ran out): the level tally again, from cmin
                 __syncthreads();
-                for (uint32_t i = threadIdx.x; i < n; i += DT) {
-                    const uint64_t k = src[i];
-                    if (KCNT(k) == cmin && KID(k) >= lo) { const uint32_t r = KID(k) - lo; if ((r >> sh) < 256u) atomicAdd(&S.hist[r >> sh], 1u); }
+                if (threadIdx.x < 256) lvl[threadIdx.x] = 0;
+                __syncthreads();
+                for (uint32_t i0 = 0; i0 < n; i0 += NF * DT) {
+                    uint64_t kf[NF];
+#pragma unroll
+                    for (int u = 0; u < NF; u++) { const uint32_t i = i0 + u * DT + threadIdx.x; kf[u] = i < n ? src[i] : ~(uint64_t)0; }
+#pragma unroll
+                    for (int u = 0; u < NF; u++) { const uint64_t k = kf[u]; tally_level(k != ~(uint64_t)0 && KCNT(k) <= dlimit, KCNT(k) - cmin); }     // (nothing live lies below cmin)
                 }
                 __syncthreads();
-                if (wv == 0) {
-                    const uint32_t h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2], h3 = S.hist[4 * lane + 3];
-                    const uint32_t sum = h0 + h1 + h2 + h3;
-                    uint32_t inc = sum;
+            }
+            if (wv == 0) {                                   // the levels that fit whole
+                const uint32_t h0 = lvl[4 * lane], h1 = lvl[4 * lane + 1], h2 = lvl[4 * lane + 2], h3 = lvl[4 * lane + 3];
+                const uint32_t sum = h0 + h1 + h2 + h3;
+                uint32_t inc = sum;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
-                    const uint32_t room = 64u - acc;
-                    const uint32_t c0 = inc - sum + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;      // inclusive running totals: monotone, so the bins that fit are a prefix
-                    uint32_t j = (c0 <= room) + (c1 <= room) + (c2 <= room) + (c3 <= room);
-                    uint32_t tk = c3 <= room ? c3 : (c2 <= room ? c2 : (c1 <= room ? c1 : (c0 <= room ? c0 : 0u)));
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+                const uint32_t c0 = inc - sum + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;
+                uint32_t j = (c0 <= 64u) + (c1 <= 64u) + (c2 <= 64u) + (c3 <= 64u);
+                uint32_t tk = c3 <= 64u ? c3 : (c2 <= 64u ? c2 : (c1 <= 64u ? c1 : (c0 <= 64u ? c0 : 0u)));
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { j += __shfl_xor(j, o); const uint32_t y = __shfl_xor(tk, o); tk = y > tk ? y : tk; }
-                    if (lane == 0) {
-                        const bool all = j == 256u;
-                        const uint64_t cu = all ? (uint64_t)lo + ((uint64_t)256 << sh) : (uint64_t)lo + ((uint64_t)j << sh);
-                        ctl[0] = (all || sh == 0 || acc + tk >= 32u) ? 1u : 0u;
-                        ctl[1] = (uint32_t)cu; ctl[2] = (uint32_t)(cu >> 32); ctl[3] = acc + tk;
+                for (int o = 32; o > 0; o >>= 1) { j += __shfl_xor(j, o); const uint32_t y = __shfl_xor(tk, o); tk = y > tk ? y : tk; }
+                if (lane == 0) { ctl[5] = j; ctl[3] = tk; }
+            }
+            __syncthreads();
+            const uint32_t Lc = ctl[5];
+            uint32_t acc = ctl[3];
+            if (Lc >= 255u) cutkey = Lc == 256u ? ~(uint64_t)0 : KEY(cmin + 255u, 0);      // everything fits / everything below the clipped tail does
+            else if (acc >= 48u) cutkey = KEY(cmin + Lc, 0);                                 // whole levels fill the front well enough
+            else {
+                // the level that straddles the quota: an id boundary inside it
+                const uint32_t lc = cmin + Lc;
+                bool have_hist = Lc == 0 && cmin == guess;
+                uint32_t lo = 0; uint64_t cut = 0;
+                for (;;) {
+                    const uint32_t sh = bits > 8 ? bits - 8 : 0;
+                    if (!have_hist) {
+                        __syncthreads();                     // the round before has read hist / ctl
+                        if (threadIdx.x < 256) S.hist[threadIdx.x] = 0;
+                        __syncthreads();
+                        for (uint32_t i0 = 0; i0 < n; i0 += NF * DT) {
+                            uint64_t kf[NF];
+#pragma unroll
+                            for (int u = 0; u < NF; u++) { const uint32_t i = i0 + u * DT + threadIdx.x; kf[u] = i < n ? src[i] : ~(uint64_t)0; }
+#pragma unroll
+                            for (int u = 0; u < NF; u++) {
+                                const uint64_t k = kf[u];
+                                if (KCNT(k) == lc && KID(k) >= lo) { const uint32_t r = KID(k) - lo; if ((r >> sh) < 256u) atomicAdd(&S.hist[r >> sh], 1u); }
+                            }
+                        }
+                        __syncthreads();
                     }
+                    have_hist = false;
+                    if (wv == 0) {
+                        const uint32_t h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2], h3 = S.hist[4 * lane + 3];
+                        const uint32_t sum = h0 + h1 + h2 + h3;
+                        uint32_t inc = sum;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+                        const uint32_t room = 64u - acc;
+                        const uint32_t c0 = inc - sum + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;      // inclusive running totals: monotone, so the bins that fit are a prefix
+                        uint32_t j = (c0 <= room) + (c1 <= room) + (c2 <= room) + (c3 <= room);
+                        uint32_t tk = c3 <= room ? c3 : (c2 <= room ? c2 : (c1 <= room ? c1 : (c0 <= room ? c0 : 0u)));
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) { j += __shfl_xor(j, o); const uint32_t y = __shfl_xor(tk, o); tk = y > tk ? y : tk; }
+                        if (lane == 0) {
+                            const bool all = j == 256u;
+                            const uint64_t cu = all ? (uint64_t)lo + ((uint64_t)256 << sh) : (uint64_t)lo + ((uint64_t)j << sh);
+                            ctl[0] = (all || sh == 0 || acc + tk >= 48u) ? 1u : 0u;      // (a fuller front is refilled less often: worth one more pass below 48 keys)
+                            ctl[1] = (uint32_t)cu; ctl[2] = (uint32_t)(cu >> 32); ctl[3] = acc + tk;
+                        }
+                    }
+                    __syncthreads();
+                    cut = (uint64_t)ctl[1] | ((uint64_t)ctl[2] << 32); acc = ctl[3];
+                    if (ctl[0]) break;
+                    lo = (uint32_t)cut; bits = sh; rounds++;  // inside the bin that straddles the quota
                 }
-                __syncthreads();
-                cut = (uint64_t)ctl[1] | ((uint64_t)ctl[2] << 32); acc = ctl[3];
-                if (ctl[0]) break;
-                lo = (uint32_t)cut; bits = sh;                // inside the bin that straddles the quota
+                cutkey = ((uint64_t)lc << 32) + cut;          // (cut = 2^32: the whole level)
             }
         }
     }
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < n; i0 += DT) {
-        const uint32_t i = i0 + threadIdx.x;
-        const uint64_t k = i < n ? src[i] : ~(uint64_t)0;
-        const bool live = i < n && KCNT(k) <= dlimit;
-        const bool isS = live && has && KCNT(k) == cmin && (uint64_t)KID(k) < cut, isK = live && !isS;
-        const uint64_t bS = __ballot(isS), bK = __ballot(isK);
-        uint32_t baseS = 0, baseK = 0;
-        if (lane == 0) { if (bS) baseS = atomicAdd(&cnt[0], (uint32_t)__popcll(bS)); if (bK) baseK = atomicAdd(&cnt[1], (uint32_t)__popcll(bK)); }
-        baseS = __shfl(baseS, 0); baseK = __shfl(baseK, 0);
-        if (isS) { const uint32_t pos = baseS + (uint32_t)__popcll(bS & ((1ull << lane) - 1)); if (pos < 64u) S.N[pos] = k; }
-        if (isK) dst[baseK + (uint32_t)__popcll(bK & ((1ull << lane) - 1))] = k;
+    for (uint32_t i0 = 0; i0 < n; i0 += NF * DT) {
+        uint64_t kf[NF];
+#pragma unroll
+        for (int u = 0; u < NF; u++) { const uint32_t i = i0 + u * DT + threadIdx.x; kf[u] = i < n ? src[i] : ~(uint64_t)0; }
+#pragma unroll
+        for (int u = 0; u < NF; u++) {
+            const uint64_t k = kf[u];
+            const bool live = k != ~(uint64_t)0 && KCNT(k) <= dlimit;
+            const bool isS = live && k < cutkey, isK = live && !isS;
+            const uint64_t bS = __ballot(isS), bK = __ballot(isK);
+            uint32_t baseS = 0, baseK = 0;
+            if (lane == 0) { if (bS) baseS = atomicAdd(&cnt[0], (uint32_t)__popcll(bS)); if (bK) baseK = atomicAdd(&cnt[1], (uint32_t)__popcll(bK)); }
+            baseS = (uint32_t)__builtin_amdgcn_readfirstlane((int)baseS); baseK = (uint32_t)__builtin_amdgcn_readfirstlane((int)baseK);
+            if (isS) { const uint32_t pos = baseS + (uint32_t)__popcll(bS & ((1ull << lane) - 1)); if (pos < 64u) S.N[pos] = k; }
+            if (isK) dst[baseK + (uint32_t)__popcll(bK & ((1ull << lane) - 1))] = k;
+        }
     }
     __syncthreads();
     const uint32_t nsel = cnt[0] < 64u ? cnt[0] : 64u, nkeep = cnt[1];
@@ -856,10 +935,12 @@ __device__ __forceinline__ void pq_rebuild(const IndexDev &ix, const DenseLds &S
     if (sel && wv == 0) {
         pkey = lane < nsel ? S.N[64 + lane] : ~(uint64_t)0;
         nP = nsel;
-        pv = (nkeep && nsel) ? __shfl(pkey, (int)nsel - 1) : ~(uint64_t)0;      // everything left in U is larger than everything taken
+        pv = (nkeep && nsel) ? readlane_u64(pkey, (int)nsel - 1) : ~(uint64_t)0;      // everything left in U is larger than everything taken
         if (lane < 3) S.W[fb + lane] = pkey;
     }
     if (threadIdx.x == 0) S.scal[4] = nkeep;
+    // (work counters of this workgroup, flushed with the others at the end of the kernel: refills in bits 0..23, compactions in 24..39, selection rounds beyond the first in 40..63)
+    stat += (sel ? 1ull : (1ull << 24)) + ((unsigned long long)rounds << 40);
     __syncthreads();
 }
 
@@ -884,6 +965,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     const uint32_t vis_w = SPLIT ? vis_w_arg : 0u;
     const uint32_t nb = dense_nblocks(ix.m), hwords = nb * (HB / 2), vis_words = SPLIT ? (vis_w >> 5) : (uint32_t)((ix.n + 31) / 32);
     const uint32_t visg_words = SPLIT && ix.n > vis_w ? (uint32_t)((ix.n - vis_w + 31) / 32) : 0u;
+    unsigned long long st_pq = 0;                                        // PQ: refills / compactions / extra selection rounds (pq_rebuild)
     uint32_t st_pops = 0, st_acc = 0, st_p1 = 0, st_p2 = 0;                 // work counters (workgroup-uniform): pops / accepting pops / pops before dmax reached tau, of this workgroup (< 2^32)
     constexpr bool PHASE2 = true;       // (round 4: also with the visited bitmap in global memory - indexes beyond ~600 k nodes: test-and-set through L2 atomics)
     // PQ (late round 5): the waiting candidates are a FRONT of up to 64 keys, sorted, one per lane in the registers of wavefront 0 (insert = ballot +
@@ -1007,7 +1089,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
                 const bool empty = c == ~(uint64_t)0, crowded = nU + maxdeg > capC && nU - nU_lc >= maxdeg;
                 if (empty && nU == 0) break;
                 if (empty || crowded) {
-                    pq_rebuild(ix, S, Cb[cur], Cb[cur ^ 1], capC, nU, empty, full ? dmax : INF_CNT, pkey, pv, nP, fb);
+                    pq_rebuild(ix, S, Cb[cur], Cb[cur ^ 1], capC, nU, empty, full ? dmax : INF_CNT, pkey, pv, nP, fb, st_pq);
                     cur ^= 1; nU = (uint32_t)S.scal[4]; nU_lc = nU;
                     continue;
                 }
@@ -1446,7 +1528,7 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     }
 #undef GS_DROW
 #undef GS_DROWX
-    if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], (unsigned long long)st_pops); atomicAdd(&stats[2], (unsigned long long)st_acc); atomicAdd(&stats[5], (unsigned long long)st_p1); atomicAdd(&stats[6], (unsigned long long)st_p2); }
+    if (stats && threadIdx.x == 0) { atomicAdd(&stats[1], (unsigned long long)st_pops); atomicAdd(&stats[2], (unsigned long long)st_acc); atomicAdd(&stats[5], (unsigned long long)st_p1); atomicAdd(&stats[6], (unsigned long long)st_p2); if (st_pq) atomicAdd(&stats[15], st_pq); }
     if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&prof[0], (unsigned long long)t_a); atomicAdd(&prof[1], (unsigned long long)t_b); atomicAdd(&prof[2], (unsigned long long)t_c);
         atomicAdd(&prof[3], (unsigned long long)t_d); atomicAdd(&prof[4], (unsigned long long)t_e); atomicAdd(&prof[5], (unsigned long long)n_pop); atomicAdd(&prof[6], (unsigned long long)n_merge);
@@ -2692,7 +2774,8 @@ int gs_index_search_stats(gs_index *ix, uint64_t out[8], int reset)
             fprintf(stderr, "[GS_TRAV_PHASES] workgroup 0, %llu queries: cycles per query tau scan %.0f, phase 1 %.0f, phase 2 %.0f, output %.0f\n", h[12],
                     (double)h[8] / h[12], (double)h[9] / h[12], (double)h[10] / h[12], (double)h[11] / h[12]),
             fprintf(stderr, "[GS_TRAV_PHASES]   inside phase 2: work list + Bloom build %.0f, drain %.0f, merge into T %.0f\n", (double)h[13] / h[12], (double)h[14] / h[12],
-                    ((double)h[10] - (double)h[13] - (double)h[14]) / h[12]);
+                    ((double)h[10] - (double)h[13] - (double)h[14]) / h[12]),
+            fprintf(stderr, "[GS_TRAV_PHASES]   phase 1 front, all workgroups: refills %llu, compactions %llu, selection rounds beyond the first %llu\n", h[15] & 0xFFFFFFull, (h[15] >> 24) & 0xFFFFull, h[15] >> 40);
     }
     out[3] = ix->stat_wg_in_flight; out[4] = ix->stat_adj_row_bytes;
     return GS_OK;

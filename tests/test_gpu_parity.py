@@ -708,6 +708,39 @@ def test_dense_traversal_placements_and_regimes(gpu_ctx, monkeypatch, vis, regim
         assert (want[1] == 1.0).mean() > 0.3                      # the data really is tie-heavy
 
 
+@pytest.mark.parametrize("vis", ["lds", "split"])
+def test_dense_traversal_front_refill_on_dense_tie_levels(gpu_ctx, monkeypatch, capfd, vis):
+    """late round 5: the waiting candidates of k_hnsw_search_dense are a 64-key sorted front in the registers of wavefront 0 over an unsorted overflow,
+    refilled with the smallest keys of the overflow's best count level by histogram selection (pq_rebuild). Here the levels are DENSE: 40 000 noise rows
+    over six values (every pair agrees in 5 +- 2 of 32 slots: a dozen count levels of thousands of nodes each) and ef = 6000 (the API's limit at this
+    max_nb_conn), so a level of the overflow holds a few dozen keys per id bin (256 bins of 256 ids, 157 of them populated): a refill that stops below
+    48 keys with the next bin not fitting goes into the selection's second round (binning inside the bin that straddles the quota) - the counters of
+    workgroup 0 (GS_TRAV_PHASES) say that it happened. ids, distances, counts and evaluation counts == oracle."""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    monkeypatch.setenv("GS_DENSE_VIS", vis)
+    monkeypatch.setenv("GS_SPLIT_W", "16384")
+    monkeypatch.setenv("GS_TRAV_PHASES", "1")
+    m = 32
+    db = np.random.default_rng(11).integers(0, 6, (40000, m)).astype(np.float32)
+    oix = O.Index(np.float32, m, 12, 48, seed=29)
+    oix.parallel_insert(db, batch=256)
+    hn = G.Hnsw.new(12, 100000, 16, 48, G.DistHamming(), seed=29, insert_batch=256)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    q = np.concatenate([np.random.default_rng(12).integers(0, 6, (48, m)).astype(np.float32), db[100:108]])
+    for knbn, ef in ((10, 6000), (30, 900)):
+        hn.search_stats(reset=True)
+        got, want = hn.search_arrays(q, knbn, ef), oix.parallel_search(q, knbn, ef)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+        assert want[3].mean() > (20000 if ef == 6000 else 5000)
+        hn.search_stats()                                               # GS_TRAV_PHASES: prints the refill counters of the call
+        line = [l for l in capfd.readouterr().err.splitlines() if "phase 1 front" in l][-1].replace(",", " ").split()
+        refills, rounds = int(line[line.index("refills") + 1]), int(line[-1])
+        assert refills >= 3 * len(q) and (ef != 6000 or rounds >= 1), line
+
+
 @pytest.mark.parametrize("vis", ["lds", "global", "split"])
 @pytest.mark.parametrize("M,regime", [(160, "spread"), (140, "ties"), (200, "tiny_ef")])
 def test_dense_traversal_wide_adjacency(gpu_ctx, monkeypatch, vis, M, regime):
