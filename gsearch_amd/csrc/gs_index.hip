@@ -2621,23 +2621,29 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     const uint32_t efs = std::max(ef, knbn);
     const uint32_t maxdeg = 2 * ix->prm.max_nb_conn;
     const size_t lds = search_lds_bytes(efs, maxdeg);
-    GS_REQUIRE(lds <= 160 * 1024 - 64, GS_ERR_UNSUPPORTED, "ef=%u needs %zu bytes of LDS (max ~%u with M=%u)", efs, lds,
-               (unsigned)((160 * 1024 - 64 - 32 * maxdeg - 1024) / 24), ix->prm.max_nb_conn);
-    GS_REQUIRE(2 * (size_t)efs + maxdeg + 64 <= (size_t)SMAXI * ST, GS_ERR_UNSUPPORTED, "ef=%u too large for the in-LDS merge", efs);
     GS_REQUIRE(maxdeg <= ST, GS_ERR_UNSUPPORTED, "max_nb_conn too large");
+    const DistMode mode = env_mode();
+    // The sorted-array traversal (k_hnsw_search) keeps its ef best keys in LDS: ef <= ~6700. The dense strategy keeps a histogram instead and takes any
+    // ef up to 65535 (hnsw_rs' parallel_search has no limit; gsearch itself asks for 5000, gsearch.rs:893): a larger ef goes that way whatever the cost
+    // model says - when the index allows the dense traversal at all
+    const bool fits_sorted = lds <= 160 * 1024 - 64 && 2 * (size_t)efs + maxdeg + 64 <= (size_t)SMAXI * ST;
+    const bool dense_able = ix->prm.m <= 65535 && maxdeg <= (uint32_t)DT && efs <= 65535u && knbn <= (uint32_t)(TMAXI * DT) && mode != MODE_GATHER && !getenv("GS_DENSE_LEGACY") &&
+                            dense_lds_bytes(ix->prm.m, knbn, maxdeg, ix->n, false, maxdeg > (uint32_t)DT / 2 ? 512u : (uint32_t)DCN) <= 160 * 1024 - 1024;
+    GS_REQUIRE(fits_sorted || dense_able, GS_ERR_UNSUPPORTED, "ef=%u needs %zu bytes of LDS in the sorted-array traversal (max ~%u with M=%u) and this index / mode does not admit the dense one (m <= 65535, ef <= 65535, GS_DIST_MODE != gather)",
+               efs, lds, (unsigned)((160 * 1024 - 64 - 32 * maxdeg - 1024) / 24), ix->prm.max_nb_conn);
+    const bool force_dense = !fits_sorted;
     const uint32_t vis_words = (uint32_t)((ix->n + 31) / 32);
     int rc;
     if ((rc = ix->visited.ensure((size_t)4 * vis_words * c->n_cu))) return rc;
     if ((rc = ix->counter.ensure(64))) return rc;
     const uint8_t *q = (const uint8_t *)q_padded_dev;
-    const DistMode mode = env_mode();
     uint64_t done = 0;
     DevBuf tmp_evals;
     // a traversal evaluates at least min(n, ef) nodes (R must fill before the stop rule can fire): when that lower bound already
     // makes the dense strategy cheaper there is nothing to probe
     const bool eligible = mode == MODE_AUTO && ix->prm.m <= 65535 && ix->n >= 4096;
     const bool lb_dense = eligible && dense_pays(ix, (double)std::min<uint64_t>(ix->n, efs) / (double)ix->n, nq);
-    if (eligible && !lb_dense && ix->search_frac < 0 && nq >= 256) {
+    if (eligible && !lb_dense && ix->search_frac < 0 && nq >= 256 && !force_dense) {
         // probe: the first queries go the gather way and tell which fraction of the graph a traversal evaluates
         const uint64_t np = 128;
         uint64_t *ev = evals;
@@ -2653,7 +2659,7 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
     const uint64_t rest = nq - done;
     // evaluated fraction: measured by an earlier search, else the one the insertions of this index measured (same graph, ef_construction)
     const double frac_known = ix->search_frac >= 0 ? ix->search_frac : ix->insert_frac;
-    bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || lb_dense || (eligible && frac_known >= 0 && rest >= 1 && dense_pays(ix, frac_known, rest)));
+    bool dense = ix->prm.m <= 65535 && (mode == MODE_DENSE || force_dense || lb_dense || (eligible && frac_known >= 0 && rest >= 1 && dense_pays(ix, frac_known, rest)));
     if (!dense) {
         if (rest) {
             uint64_t *ev = evals ? evals + done : nullptr;

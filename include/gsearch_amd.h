@@ -209,7 +209,10 @@ int      gs_index_get_ids(gs_index *, uint64_t first, uint64_t n, uint64_t *ids_
  * node number is the insertion order, which IS d_id unless the caller gave its own ids (gs_index_parallel_insert_ids / gs_index_set_ids) - ties
  * are then still broken by insertion order, not by the caller's id - or the index came from gs_index_load_hnswrs of a dump with ids other than
  * 0..n-1, whose nodes are renumbered in data-file order (layer-major). Unused tail slots: id = UINT64_MAX, distance = +inf.
- * evals_out (optional): number of DistHamming evaluations spent per query. */
+ * evals_out (optional): number of DistHamming evaluations spent per query.
+ * ef: gsearch asks for 5000 (gsearch.rs:893). Up to ~6700 (at max_nb_conn <= 128) either traversal serves; beyond that, up to 65535, the call takes the
+ * dense strategy (count matrix + look-up traversal) whatever the cost model says, and is GS_ERR_UNSUPPORTED where that is not possible
+ * (m > 65535, GS_DIST_MODE=gather). */
 int      gs_index_parallel_search(gs_index *, const void *queries, uint64_t nq, uint32_t knbn, uint32_t ef,
                                   uint64_t *ids_out, float *dist_out, uint32_t *count_out, uint64_t *evals_out);
 int      gs_index_parallel_search_dev(gs_index *, const void *queries_dev, uint64_t nq, uint32_t knbn, uint32_t ef,
