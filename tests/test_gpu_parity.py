@@ -708,6 +708,26 @@ def test_dense_traversal_placements_and_regimes(gpu_ctx, monkeypatch, vis, regim
         assert (want[1] == 1.0).mean() > 0.3                      # the data really is tie-heavy
 
 
+@pytest.mark.parametrize("knbn,ef", [(1, 1), (1, 2), (3, 3), (5, 63), (50, 64), (50, 65), (64, 64), (100, 100), (130, 700)])
+def test_dense_traversal_small_and_odd_ef(gpu_ctx, monkeypatch, knbn, ef):
+    """ef and knbn around the sizes the candidate front is built on (64 keys, one per lane of a wavefront): ef = 1 (the entry point's own rule), ef below,
+    at and just above 64, knbn above 64 (T spans more than the front), on noise rows (every pair agrees in 19 +- 4 of 96 slots: dense count levels) - dense strategy == oracle, evaluation counts included"""
+    import gsearch_amd as G
+    monkeypatch.setenv("GS_DIST_MODE", "dense")
+    m = 96
+    db = np.random.default_rng(502).integers(0, 5, (3000, m)).astype(np.float32)
+    oix = O.Index(np.float32, m, 10, 40, seed=31)
+    oix.parallel_insert(db, batch=128)
+    hn = G.Hnsw.new(10, 100000, 16, 40, G.DistHamming(), seed=31, insert_batch=128)
+    hn.set_extend_candidates(True)
+    hn.parallel_insert(db)
+    q = np.concatenate([np.random.default_rng(503).integers(0, 5, (100, m)).astype(np.float32), db[7:11]])
+    got, want = hn.search_arrays(q, knbn, ef), oix.parallel_search(q, knbn, ef)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    assert want[3].mean() > min(2500, 15 * ef)                           # the searches really walk the graph
+
+
 @pytest.mark.parametrize("vis", ["lds", "split"])
 def test_dense_traversal_front_refill_on_dense_tie_levels(gpu_ctx, monkeypatch, capfd, vis):
     """late round 5: the waiting candidates of k_hnsw_search_dense are a 64-key sorted front in the registers of wavefront 0 over an unsorted overflow,
