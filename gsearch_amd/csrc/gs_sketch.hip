@@ -1916,8 +1916,13 @@ struct HllEmit {
 };
 template <bool GTAB> __device__ __forceinline__ void emit_full_wave(const HllEmit<false, GTAB> &e, uint64_t v, uint64_t r, uint64_t p) { if (e.sq) e.full(v); else e(v, r, p); }
 template <bool GTAB> __device__ __forceinline__ void emit_finish(const HllEmit<false, GTAB> &e) { e.finish(); }
-template <bool AA, bool COLD, bool GTAB>
-__global__ __launch_bounds__(COLD ? HL_CT : HL_T) void k_sketch_hll(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
+// TIGHT (warm form only): 128 VGPRs at most. The 72 kB register table lets two workgroups share a CU, the 160 registers the compiler takes by itself (the
+// walker's double-precision logarithms) let only ONE: 2 waves per SIMD, VALU issue 55 % busy, 40 % of the wave cycles waiting (profiles/r05_hll_pmc.txt).
+// Capped, 31 registers of the walker spill and two workgroups are resident: 512 genomes of 1 / 2 / 3 / 5 / 20 Mbp in 6.7 / 7.0 / 8.3 / 9.8 / 25.2 ms against
+// 8.0 / 8.4 / 9.4 / 11.9 / 30.6 (5 Mbp: 2.1 -> 2.6e11 k-mers/s, 3.0e11 at 2048 genomes). The uncapped instantiation stays for batches of very short
+// genomes (< 16 k-mers per register: the walker is most of the work there) and for A/B (GS_HLL_TIGHT=0).
+template <bool AA, bool COLD, bool GTAB, bool TIGHT = false>
+__global__ __launch_bounds__(COLD ? HL_CT : HL_T, (!COLD && TIGHT) ? 4 : 1) void k_sketch_hll(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start,
         const uint64_t *__restrict__ rec_len, const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off,
         const uint64_t *__restrict__ gen_units, const uint32_t *__restrict__ list, uint32_t n_items, uint32_t k, uint32_t m, double inv_lnb,
         const uint64_t *__restrict__ ucut, uint32_t *__restrict__ lane_q, uint32_t *__restrict__ lane_perm, unsigned long long *__restrict__ counter,
@@ -2081,9 +2086,13 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
     if (surv_cap && sv.alloc((size_t)8 * surv_cap * wgs) != GS_OK) { (void)hipGetLastError(); surv_cap = 0; }
     {
         ProfScope ps(c, FAM_SKETCH);
-#define GS_LAUNCH_HLL(AAV, GV)                                                                                                 \
+    // (GS_HLL_TIGHT=0/1 overrides the choice for A/B)
+    const double per_reg = 32.0 * (double)total_units / (double)std::max<uint64_t>(n_genomes, 1) / (double)m;       // (a unit is 32 symbols)
+    const bool tight = getenv("GS_HLL_TIGHT") ? atoi(getenv("GS_HLL_TIGHT")) != 0 : per_reg >= 16.0;       // (measured from 55 k-mers per register up: always)
+#define GS_LAUNCH_HLL(AAV, GV) do { if (tight) GS_LAUNCH_HLL_T(AAV, GV, true); else GS_LAUNCH_HLL_T(AAV, GV, false); } while (0)
+#define GS_LAUNCH_HLL_T(AAV, GV, TV)                                                                                           \
     do {                                                                                                                       \
-        auto kern = k_sketch_hll<AAV, false, GV>;                                                                              \
+        auto kern = k_sketch_hll<AAV, false, GV, TV>;                                                                          \
         if (lds > 48 * 1024) GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(HL_T), lds, c->stream, seq, rec_start, rec_len, rec_upre, genome_rec_off, gen_units, (const uint32_t *)nullptr, \
                            (uint32_t)n_genomes, kq_of(p), m, inv_lnb, dcut.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr, cnt.as<unsigned long long>(), cold.as<uint8_t>(), sig_out, \
@@ -2092,6 +2101,7 @@ static int run_hll(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, con
         if (aa) { if (gtab) GS_LAUNCH_HLL(true, true); else GS_LAUNCH_HLL(true, false); }
         else { if (gtab) GS_LAUNCH_HLL(false, true); else GS_LAUNCH_HLL(false, false); }
 #undef GS_LAUNCH_HLL
+#undef GS_LAUNCH_HLL_T
     }
     GS_HIP_CHECK(hipGetLastError());
     std::vector<uint8_t> h(n_genomes);
