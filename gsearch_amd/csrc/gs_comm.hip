@@ -146,10 +146,17 @@ __global__ void k_topk_unpack(const uint8_t *__restrict__ blocks, uint64_t block
 {
     const int r = blockIdx.y;
     const uint8_t *b = blocks + (uint64_t)r * block_bytes;
-    uint64_t row0 = 0;
-    for (int q = 0; q < r; q++) row0 += *(const uint64_t *)(blocks + (uint64_t)q * block_bytes);
+    // EVERY header is checked before anything is scattered: a block of another shape would otherwise move the rows of the ranks behind it
+    // past the end of all_ids / all_dist before the host ever sees the flag. A bad header anywhere: nobody writes.
+    uint64_t row0 = 0; bool any_bad = false;
+    for (int q = 0; q < n_ranks; q++) {
+        const uint8_t *h = blocks + (uint64_t)q * block_bytes;
+        const uint64_t nqq = *(const uint64_t *)h;
+        any_bad |= ((const uint32_t *)h)[2] != knbn || ((const uint32_t *)h)[3] != GS_TOPK_MAGIC || nqq > nq_max;
+        if (q < r) row0 += nqq;
+    }
+    if (any_bad) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(bad, 1u); return; }
     const uint64_t nq = *(const uint64_t *)b;
-    if (((const uint32_t *)b)[2] != knbn || ((const uint32_t *)b)[3] != GS_TOPK_MAGIC || nq > nq_max) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(bad, 1u); return; }
     if (threadIdx.x == 0 && blockIdx.x == 0) counts[r] = nq;
     const uint64_t n = nq * knbn;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {

@@ -43,7 +43,10 @@ struct ThreadWorkers {
             {
                 std::lock_guard<std::mutex> lk(c->workers_mu);
                 auto it = c->workers.find(me);
-                if (it != c->workers.end()) { w = it->second; c->workers.erase(it); }
+                if (it != c->workers.end()) {
+                    w = it->second; c->workers.erase(it);
+                    if (w->pins > 0) { w->orphan = true; w = nullptr; }      // a snapshot of the table (profile read, failure sweep) still holds it: its unpin destroys it
+                }
             }
             if (w) { std::lock_guard<std::recursive_mutex> wl(w->mu); }      // (nobody else can hold it: only this thread used it; taken for the memory order)
             if (w) destroy_worker(w);
@@ -71,16 +74,16 @@ gs_ctx *worker_ctx(gs_ctx *c)
         if (c->owner_thread == std::thread::id{}) c->owner_thread = me;
         if (c->owner_thread == me) return c;
         auto it = c->workers.find(me);
-        if (it != c->workers.end()) { it->second->last_use = ++c->use_tick; return it->second; }
+        if (it != c->workers.end()) { it->second->last_use = ++c->use_tick; it->second->pins++; return it->second; }
         if (c->workers.size() >= cap) {
-            // full: evict the least recently used worker nobody is inside of (try_lock), else share the main context for this call
+            // full: evict the least recently used worker that is not pinned (nobody between worker_ctx() and worker_unpin(), no snapshot holding it), else share
+            // the main context for this call
             auto victim = c->workers.end();
             for (auto jt = c->workers.begin(); jt != c->workers.end(); ++jt)
-                if (victim == c->workers.end() || jt->second->last_use < victim->second->last_use) victim = jt;
-            if (victim == c->workers.end() || !victim->second->mu.try_lock()) return c;
+                if (jt->second->pins == 0 && (victim == c->workers.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+            if (victim == c->workers.end()) return c;
             evicted = victim->second;
             c->workers.erase(victim);
-            evicted->mu.unlock();
         }
     }
     if (evicted) destroy_worker(evicted);
@@ -93,6 +96,7 @@ gs_ctx *worker_ctx(gs_ctx *c)
     {
         std::lock_guard<std::mutex> lk(c->workers_mu);
         w->last_use = ++c->use_tick;
+        w->pins = 1;
         c->workers[me] = w;
     }
     bool known = false;
@@ -104,21 +108,36 @@ gs_ctx *worker_ctx(gs_ctx *c)
 void worker_done(gs_ctx *c, gs_ctx *w)
 {
     if (!c || !w || w == c) return;
+    { std::lock_guard<std::mutex> lk(c->workers_mu); for (int i = 0; i < 4; i++) c->last_sketch[i] = w->last_sketch[i]; }      // (w is still pinned by this thread)
+    worker_unpin(c, w);
+}
+void worker_unpin(gs_ctx *c, gs_ctx *w)
+{
+    bool destroy = false;
+    { std::lock_guard<std::mutex> lk(c->workers_mu); destroy = --w->pins == 0 && w->orphan; }
+    if (destroy) { { std::lock_guard<std::recursive_mutex> wl(w->mu); } destroy_worker(w); }
+}
+// the workers of c, each pinned: the caller unpins every one of them when it is done
+static std::vector<gs_ctx *> pinned_workers(gs_ctx *c)
+{
+    std::vector<gs_ctx *> ws;
     std::lock_guard<std::mutex> lk(c->workers_mu);
-    for (int i = 0; i < 4; i++) c->last_sketch[i] = w->last_sketch[i];
+    for (auto &w : c->workers) { w.second->pins++; ws.push_back(w.second); }
+    return ws;
 }
 // a call on a worker failed on the device (typically: its scratch did not fit beside the other workers' pools): give every idle worker's pool back
 void on_worker_failed(gs_ctx *c)
 {
     (void)hipGetLastError();
-    std::vector<gs_ctx *> ws;
-    { std::lock_guard<std::mutex> lk(c->workers_mu); for (auto &w : c->workers) ws.push_back(w.second); }
+    std::vector<gs_ctx *> ws = pinned_workers(c);
     for (gs_ctx *w : ws) {
-        if (!w->mu.try_lock()) continue;
-        (void)hipSetDevice(w->device);
-        (void)hipStreamSynchronize(w->stream);
-        delete (ScratchPool *)w->scratch_pool; w->scratch_pool = nullptr;
-        w->mu.unlock();
+        if (w->mu.try_lock()) {
+            (void)hipSetDevice(w->device);
+            (void)hipStreamSynchronize(w->stream);
+            delete (ScratchPool *)w->scratch_pool; w->scratch_pool = nullptr;
+            w->mu.unlock();
+        }
+        worker_unpin(c, w);
     }
     (void)hipGetLastError();
 }
@@ -251,14 +270,14 @@ int gs_ctx_profile_read(gs_ctx *c, int family, double *total_ms, uint64_t *launc
     double tot = s.total_ms; uint64_t nl = s.launches;
     if (reset) { s.total_ms = 0; s.launches = 0; }
     if (!c->parent) {                                               // the launches of this context's worker threads belong to the same totals
-        std::vector<gs_ctx *> ws;
-        { std::lock_guard<std::mutex> lk(c->workers_mu); for (auto &w : c->workers) ws.push_back(w.second); }
+        std::vector<gs_ctx *> ws = gs::pinned_workers(c);
+        int wrc = GS_OK;
         for (gs_ctx *w : ws) {
             double t = 0; uint64_t n = 0;
-            const int rc = gs_ctx_profile_read(w, family, &t, &n, reset);
-            if (rc) return rc;
-            tot += t; nl += n;
+            if (wrc == GS_OK && (wrc = gs_ctx_profile_read(w, family, &t, &n, reset)) == GS_OK) { tot += t; nl += n; }
+            gs::worker_unpin(c, w);
         }
+        if (wrc) return wrc;
     }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = nl;

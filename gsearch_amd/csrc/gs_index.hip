@@ -2703,7 +2703,9 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
         // batch b + 1 here and the sketches the caller queued on its own stream. The traversal scratch (visited / candidate arrays / query counter) is per
         // index: launches on tstream follow one another.
         const uint64_t maxq = match_join_max_queries(), parts = (nq + maxq - 1) / maxq, jq = (nq + parts - 1) / parts;
-        struct SGuard { gs_ctx *c; hipStream_t main; ~SGuard() { c->stream = main; } } sg{c, c->stream};
+        // (leaving this scope - also through a failing dense_counts / search_launch - waits for what is queued on tstream: traversal kernels must not go on
+        // writing ids / dist / evals, nor use ix->visited / cbuf, after the call has returned an error; on success the wait is an event on the main stream below)
+        struct SGuard { gs_ctx *c; hipStream_t main; hipStream_t t; bool ok = false; ~SGuard() { c->stream = main; if (!ok) (void)hipStreamSynchronize(t); } } sg{c, c->stream, ix->tstream};
         for (uint64_t q0 = 0; q0 < nq; q0 += jq) {
             const uint64_t nb = std::min(jq, nq - q0);
             if ((rc = dense_counts(ix, q + q0 * ix->stride, nb, ix->n, ix->mat.as<uint16_t>() + q0 * ld, ld))) return rc;
@@ -2717,6 +2719,7 @@ static int search_dev(gs_index *ix, const void *q_padded_dev, uint64_t nq, uint3
         }
         GS_HIP_CHECK(hipEventRecord(ix->tev_done, ix->tstream));
         GS_HIP_CHECK(hipStreamWaitEvent(c->stream, ix->tev_done, 0));
+        sg.ok = true;
         return GS_OK;
     }
     for (uint64_t q0 = done; q0 < nq; q0 += QB) {

@@ -64,6 +64,10 @@ struct gs_ctx {
     std::map<std::thread::id, gs_ctx *> workers; std::mutex workers_mu;
     gs_ctx *parent = nullptr;
     uint64_t last_use = 0, use_tick = 0;   // LRU stamps of the worker table (under workers_mu)
+    // A worker is PINNED (under the parent's workers_mu) from the moment worker_ctx() hands it out, or a snapshot of the table copies its pointer, until
+    // worker_unpin(): eviction only takes workers with pins == 0, and a worker whose thread exits while a snapshot still holds it is only marked
+    // `orphan` - the last unpin destroys it (the LRU eviction could free a worker between worker_ctx() and the body's lock).
+    int pins = 0; bool orphan = false;
     uint32_t sketch_min_lds = 0;             // the slot-min sketch kernel asks for at least this much LDS per workgroup (co-residency shaping of the request pipeline; 0 = what it needs)
     uint32_t last_sketch[4] = {0, 0, 0, 0};   // gs_ctx_last_sketch_info: {filtered emitter, slot table in LDS, workgroups per genome, launches} of the last slot-min sketch call
     // One context = one stream and one scratch pool. The reference clones its sketcher into --nbthreads workers and calls it, DistHamming
@@ -82,6 +86,7 @@ namespace gs {
 // (GS_THREAD_CONTEXTS=0: always `c` - every call of every thread queues on the one context, as before round 4)
 gs_ctx *worker_ctx(gs_ctx *c);
 void worker_done(gs_ctx *parent, gs_ctx *worker);
+void worker_unpin(gs_ctx *parent, gs_ctx *worker);
 void on_worker_failed(gs_ctx *parent);
 // run a synchronous host-pointer call on the calling thread's worker context; a device failure there (a worker's scratch pool beside 63 others)
 // releases the idle workers' pools and repeats the call on the parent, where it queues as every call did before worker contexts existed

@@ -1269,6 +1269,18 @@ def test_context_is_safe_for_concurrent_calls(gpu_ctx):
     assert not errors, errors
 
 
+def test_worker_table_of_one_under_many_threads(gpu_ctx):
+    """with the worker table full (GS_THREAD_CONTEXTS_MAX=1) every further thread evicts the least recently used worker - which used to be
+    possible while that worker's thread was between worker_ctx() and its body's lock, or in worker_done(). Workers are pinned now; six threads on a
+    table of one worker must finish with every sketch equal to the single-threaded one (own process: the cap is read once per process)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GS_THREAD_CONTEXTS_MAX="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_ctx_probe.py"), "6", "10", "2", "200000"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "genomes/s" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
+
+
 def test_comm_allgather_single_rank(gpu_ctx):
     """C-level multi-GPU helper (gs_comm_*, RCCL): a one-rank communicator gathers the rank's own top-k block; the N > 1 exchange is the
     same call (covered for layout by the gloo world-size-2 test of the packed Python exchange)"""
