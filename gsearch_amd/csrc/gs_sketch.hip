@@ -1585,13 +1585,616 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
     return GS_OK;
 }
 
-// prob driver: runs of genomes the bucketed form suits go through it in chunks, the rest (and what it flags) through the sorted form
+// =====================================================================================================
+// prob, TIERED form (round 6; DESIGN.md 3.1 "ProbMinHash3a, tiers"). Two observations carry it:
+//  (1) every copy of a k-mer v draws from the same RNG(H(v)), so its first truncated-exponential draw x1 is a property of the VALUE, and its smallest point
+//      is h1 = x1 / w. With thr >= max_b q[b] (final), v can only matter when x1 <= w thr: a k-mer whose x1 lies in [T thr, (T + 1) thr) needs a multiplicity
+//      above T to matter at all - at thr ~ 0.04 (5 Mbp, s = 18000) 96 % of the k-mers need w >= 2, 85 % need w >= 5.
+//  (2) an UPPER bound c >= w is enough to drop such a k-mer (1 / c and the product are monotone in c, in IEEE arithmetic too), and a count-min cell - the sum
+//      of the multiplicities of everything that shares the cell - is one: one non-returning 16-bit LDS add per k-mer instead of a CAS insert with probing.
+// So a bucket is counted twice: pass A adds every k-mer to its count-min cell; pass B reads the cell, draws x1 and drops the k-mer when even c copies could
+// not bring its first point under thr (nor keep it alive for pass 2: 1 / c > thr). What is not dropped - the ~thr fraction that matters as singletons, the
+// real repeats, and the false alarms of shared cells - enters the exact LDS hash table (CAS + duplicate count, as in k_prob_buckets: ALL copies of a value
+// see the same cell, so they enter or stay out together and the multiplicity is exact), and the table is swept by the cheap test / full generator of the
+// bucketed form. thr starts at a SPECULATIVE cap (m / N)(ln m + c) per genome (total k-mers N: the point process has rate sum w = N whatever the repeats) and
+// is verified afterwards: max_b q[b] <= cap proves that nothing dropped could have been a slot minimum (a dropped point lies above the cap, hence above a
+// point that stayed in its slot); a genome that fails the check, overflows a slice or a table is redone by the bucketed form (exact fallback).
+// The partition is ONE pass without a count pass: a workgroup walks its tiles of the genome twice (count, place), counting-sorts each tile of <= 32 768
+// k-mers by bucket in LDS and appends run by run to its PRIVATE slice of every bucket (fixed capacity: mean + 5 sigma; an overflow flags the genome) - 4 bytes
+// per k-mer cross HBM twice (the in-bucket id of a bijection of the values, pt_bucket / pt_value) where the two-level partition moved 8 + 8 + 4 + 4.
+// =====================================================================================================
+constexpr int PT_T = 1024;            // lanes of the partition kernel = units (32 symbols) per tile
+constexpr int PT_LGMAX = 11;          // buckets per genome <= 2048 (three LDS arrays of NB words beside the 128 kB tile)
+constexpr int PT_AVG = 4096;          // k-mers per bucket aimed at (2048 .. 4096)
+constexpr int PT_MINB = 256;          // fewer k-mers per bucket than this: the bucketed / sorted forms
+constexpr int PT2_T = 512;            // lanes of the bucket kernel
+constexpr int PT_CM = 8192;           // count-min cells per bucket (16 bits each)
+constexpr int PT_Q = 1536;            // ids queued for the exact table per bucket
+// The tiered form's bijection of the vbits-bit values is cheaper than pb_hash (one 32-bit multiplication instead of a 64-bit one - the bucket kernel undoes it
+// once per k-mer and is bound by exactly these quarter-rate multiplications): id = the low sh bits of the value as they are, bucket = its top lg bits XOR a
+// lg-bit hash of the id. Given (bucket, id) the top bits come back by the same XOR. Buckets are as even as the hash of the low 31 bits; whatever indexes a
+// table by the id hashes it first (the raw low bits of a k-mer are its last bases).
+__device__ __forceinline__ uint32_t pt_mix(uint32_t id, uint32_t lg) { return lg ? (id * 0x9E3779B1u) >> (32 - lg) : 0u; }
+__device__ __forceinline__ uint32_t pt_bucket(uint64_t v, uint32_t sh, uint32_t lg, uint32_t idmask) { return (uint32_t)(v >> sh) ^ pt_mix((uint32_t)v & idmask, lg); }
+__device__ __forceinline__ uint64_t pt_value(uint32_t bk, uint32_t id, uint32_t sh, uint32_t lg) { return ((uint64_t)(bk ^ pt_mix(id, lg)) << sh) | (uint64_t)id; }
+struct PtCountEmit {
+    uint32_t *cnt; uint32_t sh, lg, idmask;
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { atomicAdd(&cnt[pt_bucket(v, sh, lg, idmask)], 1u); }
+};
+struct PtPlaceEmit {
+    uint32_t *pos, *ids; uint32_t sh, lg, idmask;
+    __device__ __forceinline__ void operator()(uint64_t v, uint64_t, uint64_t) const { ids[atomicAdd(&pos[pt_bucket(v, sh, lg, idmask)], 1u)] = (uint32_t)v & idmask; }
+};
+// grid (parts, genomes of the chunk). vals32[g_vbase[gl] + (b * parts + part) * g_cap[gl] + i] = i-th id this part found for bucket b; cnt[(g_boff[gl] + b) * parts + part] = how many.
+template <bool AA>
+__global__ __launch_bounds__(PT_T) void k_prob_part1(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
+                                                     const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
+                                                     uint64_t g0, uint32_t kq, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff,
+                                                     const uint64_t *__restrict__ g_vbase, const uint32_t *__restrict__ g_cap, uint32_t parts, uint32_t *__restrict__ vals32,
+                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ ovf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pt[];
+    __shared__ uint32_t s_w[16];
+    const uint32_t gl = blockIdx.y, part = blockIdx.x;
+    const uint64_t g = g0 + gl;
+    const uint32_t sh = g_sh[gl], NB = 1u << (vbits - sh), cap = g_cap[gl];
+    uint32_t *s_cnt = s_pt, *s_start = s_pt + NB, *s_cur = s_pt + 2 * NB, *s_ids = s_pt + 3 * NB;       // s_cnt doubles as the placement cursor of walk B
+    const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
+    const uint32_t k = kq_k(kq);
+    const uint64_t mask = kmer_mask(AA, k), rc_or = kq_rc_or(kq);
+    const uint32_t idmask = (uint32_t)(((uint64_t)1 << sh) - 1), lg = vbits - sh;      // sh <= 31
+    const uint32_t rcshift = 2 * (k - 1);
+    const uint64_t tiles = (units + PT_T - 1) / PT_T, t_lo = tiles * part / parts, t_hi = tiles * (part + 1) / parts;
+    uint32_t *out = vals32 + g_vbase[gl];
+    for (uint32_t b = threadIdx.x; b < NB; b += PT_T) s_cur[b] = 0;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t CH = NB > (uint32_t)PT_T ? NB / PT_T : 1u;     // consecutive buckets per lane in the prefix
+    bool over = false;
+    for (uint64_t t = t_lo; t < t_hi; t++) {
+        for (uint32_t b = threadIdx.x; b < NB; b += PT_T) s_cnt[b] = 0;
+        __syncthreads();
+        const uint64_t f = t * PT_T + threadIdx.x;
+        if (f < units) { PtCountEmit e{s_cnt, sh, lg, idmask}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, e); }
+        __syncthreads();
+        // exclusive prefix of the bucket counts -> s_start, and the cursors of walk B
+        uint32_t loc = 0;
+        for (uint32_t c = 0; c < CH; c++) { const uint32_t b = threadIdx.x * CH + c; if (b < NB) loc += s_cnt[b]; }
+        uint32_t inc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - loc;
+        for (uint32_t w = 0; w < wv; w++) run += s_w[w];
+        for (uint32_t c = 0; c < CH; c++) { const uint32_t b = threadIdx.x * CH + c; if (b < NB) { const uint32_t x = s_cnt[b]; s_start[b] = run; s_cnt[b] = run; run += x; } }
+        __syncthreads();
+        if (f < units) { PtPlaceEmit e{s_cnt, s_ids, sh, lg, idmask}; walk_unit<AA>(seq, rec_start, rec_len, rec_upre, r0, r1, f, k, mask, rcshift, rc_or, e); }
+        __syncthreads();
+        // run by run to this part's slices: half a wavefront per bucket (a run is ~16-32 ids)
+        const uint32_t hw = threadIdx.x >> 5, hl = threadIdx.x & 31;
+        for (uint32_t b = hw; b < NB; b += PT_T / 32) {
+            const uint32_t a = s_start[b], e = s_cnt[b], cur = s_cur[b], nb = e - a;
+            if (nb == 0) continue;
+            if (cur + nb > cap) { over = true; continue; }
+            uint32_t *dst = out + ((uint64_t)b * parts + part) * cap + cur;
+            for (uint32_t i = hl; i < nb; i += 32) dst[i] = s_ids[a + i];
+            if (hl == 0) s_cur[b] = cur + nb;
+        }
+        __syncthreads();
+    }
+    if (over) ovf[gl] = 1;
+    uint32_t *cg = cnt + (uint64_t)g_boff[gl] * parts;
+    for (uint32_t b = threadIdx.x; b < NB; b += PT_T) cg[(uint64_t)b * parts + part] = s_cur[b];
+}
+
+// DNA form of k_prob_part1 with ONE walk per tile (the two-walk form above stays for amino acids): a lane keeps the 32 k-mers of its unit in registers - the id
+// and (bucket, rank), the rank being what the counting atomic returns - so that after the prefix over the bucket counts each id goes straight to
+// s_ids[start[bucket] + rank]: no second walk (the walk is ~half of the kernel's instructions), no second atomic.
+template <bool CHECK>
+__device__ __forceinline__ void pt_walk_dna(uint64_t w, uint64_t fwd, uint64_t rc, uint64_t mask, uint32_t rcshift, uint64_t rc_or, uint32_t jlo, uint32_t jhi, uint32_t sh, uint32_t lg,
+                                            uint32_t idmask, uint32_t *s_cnt, uint32_t (&idr)[32], uint32_t (&pkr)[32])
+{
+#pragma unroll
+    for (uint32_t j = 0; j < 32; j++) {
+        const uint64_t c = w >> 62; w <<= 2;
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((3 - c) << rcshift) | rc_or;
+        const uint64_t v = fwd < rc ? fwd : rc;
+        const uint32_t id = (uint32_t)v & idmask, b = (uint32_t)(v >> sh) ^ pt_mix(id, lg);
+        idr[j] = id;
+        if (!CHECK || (j >= jlo && j < jhi)) pkr[j] = (b << 16) | atomicAdd(&s_cnt[b], 1u);      // rank < 32 768: 15 bits
+        else pkr[j] = 0xFFFFFFFFu;
+    }
+}
+__global__ __launch_bounds__(PT_T) void k_prob_part1_dna(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
+                                                         const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
+                                                         uint64_t g0, uint32_t kq, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff,
+                                                         const uint64_t *__restrict__ g_vbase, const uint32_t *__restrict__ g_cap, uint32_t parts, uint32_t *__restrict__ vals32,
+                                                         uint32_t *__restrict__ cnt, uint32_t *__restrict__ ovf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pt[];
+    __shared__ uint32_t s_w[16];
+    const uint32_t gl = blockIdx.y, part = blockIdx.x;
+    const uint64_t g = g0 + gl;
+    const uint32_t sh = g_sh[gl], NB = 1u << (vbits - sh), cap = g_cap[gl];
+    uint32_t *s_cnt = s_pt, *s_start = s_pt + NB, *s_cur = s_pt + 2 * NB + 1, *s_ids = s_pt + 3 * NB + 4;      // s_start has NB + 1 entries (the total closes the last bucket)
+    const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], units = gen_units[g];
+    const uint32_t k = kq_k(kq);
+    const uint64_t mask = kmer_mask(false, k), rc_or = kq_rc_or(kq);
+    const uint32_t idmask = (uint32_t)(((uint64_t)1 << sh) - 1), lg = vbits - sh;
+    const uint32_t rcshift = 2 * (k - 1);
+    const uint64_t tiles = (units + PT_T - 1) / PT_T, t_lo = tiles * part / parts, t_hi = tiles * (part + 1) / parts;
+    uint32_t *out = vals32 + g_vbase[gl];
+    const uint64_t *w64 = (const uint64_t *)seq;
+    for (uint32_t b = threadIdx.x; b < NB; b += PT_T) s_cur[b] = 0;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t CH = NB > (uint32_t)PT_T ? NB / PT_T : 1u;
+    bool over = false;
+    // a lane's unit of a tile: the packed word, the word in front of it (the k - 1 bases before the unit) and which of its 32 windows are k-mers of its record.
+    // The unit of tile t + 1 is fetched while tile t is worked on: with one workgroup per CU nothing else hides the two dependent round trips to HBM.
+    struct Unit { uint64_t w, pw; uint32_t jlo, jhi; bool init; };
+    auto fetch = [&](uint64_t t) -> Unit {
+        Unit un{0, 0, 0, 0, false};
+        const uint64_t f = t * PT_T + threadIdx.x;
+        if (t < t_hi && f < units) {
+            uint64_t lo = r0, hi = r1;
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (rec_upre[mid] <= f) lo = mid; else hi = mid; }
+            const uint64_t rb = rec_start[lo], re = rb + rec_len[lo];
+            const uint64_t u = (rb >> 5) + (f - rec_upre[lo]), a0 = u << 5, first_valid = rb + k - 1;
+            un.w = w64[u];
+            un.init = a0 > rb && k > 1;
+            if (un.init) un.pw = w64[u - 1];
+            un.jlo = first_valid > a0 ? (uint32_t)std::min<uint64_t>(first_valid - a0, 32) : 0u;
+            un.jhi = re > a0 ? (uint32_t)std::min<uint64_t>(re - a0, 32) : 0u;
+            if (un.jhi <= un.jlo) { un.jlo = 0; un.jhi = 0; }
+        }
+        return un;
+    };
+    Unit cur = fetch(t_lo);
+    for (uint64_t t = t_lo; t < t_hi; t++) {
+        for (uint32_t b = threadIdx.x; b < NB; b += PT_T) s_cnt[b] = 0;
+        const Unit nxt = fetch(t + 1);
+        __syncthreads();
+        uint32_t idr[32], pkr[32];
+        {
+            const uint64_t w = __builtin_bswap64(cur.w);
+            uint64_t fwd = 0, rc = 0;
+            if (cur.init) {
+                // the state after the k - 1 bases in front of the word, in closed form (walk_unit)
+                const uint64_t pw = __builtin_bswap64(cur.pw);
+                const uint64_t lowm = ((uint64_t)1 << (2 * (k - 1))) - 1;
+                fwd = pw & lowm;
+                uint64_t br = __builtin_bitreverse64(fwd);
+                br = ((br >> 1) & 0x5555555555555555ull) | ((br & 0x5555555555555555ull) << 1);
+                rc = (((~(br >> (2 * (33 - k)))) & lowm) << 2) | rc_or;
+            }
+            const bool have = cur.jhi > cur.jlo, full = cur.jlo == 0 && cur.jhi == 32;
+            if (__ballot(full) == __ballot(true)) pt_walk_dna<false>(w, fwd, rc, mask, rcshift, rc_or, 0, 32, sh, lg, idmask, s_cnt, idr, pkr);      // (wavefront-uniform)
+            else if (__ballot(have)) pt_walk_dna<true>(w, fwd, rc, mask, rcshift, rc_or, cur.jlo, cur.jhi, sh, lg, idmask, s_cnt, idr, pkr);
+            else {
+#pragma unroll
+                for (int j = 0; j < 32; j++) pkr[j] = 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+        uint32_t loc = 0;
+        for (uint32_t c = 0; c < CH; c++) { const uint32_t b = threadIdx.x * CH + c; if (b < NB) loc += s_cnt[b]; }
+        uint32_t inc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - loc;
+        for (uint32_t w = 0; w < wv; w++) run += s_w[w];
+        for (uint32_t c = 0; c < CH; c++) { const uint32_t b = threadIdx.x * CH + c; if (b < NB) { s_start[b] = run; run += s_cnt[b]; } }
+        if (threadIdx.x == PT_T - 1) s_start[NB] = run;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; j++) if (pkr[j] != 0xFFFFFFFFu) s_ids[s_start[pkr[j] >> 16] + (pkr[j] & 0xFFFFu)] = idr[j];
+        __syncthreads();
+        // to this part's slices: a wavefront takes 64 buckets at a time - their ids are one contiguous stretch of s_ids - and every lane finds the bucket of its
+        // position by a 6-step search over the 64 starts (four positions per lane in flight: one run per trip of a half wavefront was a chain of three LDS round
+        // trips per ~16 ids, a quarter of the kernel). Lanes on consecutive positions of a bucket store to consecutive addresses.
+        for (uint32_t b0 = wv * 64; b0 < NB; b0 += (PT_T / 64) * 64) {
+            const uint32_t nbk = NB - b0 < 64u ? NB - b0 : 64u;
+            const uint32_t p0 = s_start[b0], p1 = s_start[b0 + nbk];
+            for (uint32_t pb = p0; pb < p1; pb += 256) {
+                uint32_t id4[4], bk4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t pos = pb + q * 64 + lane;
+                    uint32_t lo = 0, hi = nbk;                      // last bucket of the 64 whose start is <= pos
+                    if (pos < p1) {
+                        id4[q] = s_ids[pos];
+#pragma unroll
+                        for (int st = 0; st < 6; st++) { const uint32_t mid = (lo + hi) >> 1; if (hi - lo > 1) { if (s_start[b0 + mid] <= pos) lo = mid; else hi = mid; } }
+                    }
+                    bk4[q] = b0 + lo;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t pos = pb + q * 64 + lane;
+                    if (pos < p1) {
+                        const uint32_t b = bk4[q], at = s_cur[b] + (pos - s_start[b]);
+                        if (at < cap) out[((uint64_t)b * parts + part) * cap + at] = id4[q]; else over = true;
+                    }
+                }
+            }
+            if (lane < nbk) { const uint32_t b = b0 + lane; s_cur[b] = std::min(s_cur[b] + s_cnt[b], cap); }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    if (over) ovf[gl] = 1;
+    uint32_t *cg = cnt + (uint64_t)g_boff[gl] * parts;
+    for (uint32_t b = threadIdx.x; b < NB; b += PT_T) cg[(uint64_t)b * parts + part] = s_cur[b];
+}
+
+__global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restrict__ vals32, const uint64_t *__restrict__ g_vbase, const uint32_t *__restrict__ g_cap,
+                                                         const uint32_t *__restrict__ cnt, uint32_t parts, uint32_t vbits, const uint32_t *__restrict__ g_sh,
+                                                         const uint32_t *__restrict__ g_boff, uint32_t ng, uint32_t lg_max, uint32_t m, uint64_t zone, ProbConst pc,
+                                                         uint64_t *__restrict__ q, uint64_t *__restrict__ thr, uint32_t *__restrict__ wmax, PbLists L, uint32_t *__restrict__ ovf)
+{
+    // LDS per workgroup: 16 kB table + 8 kB duplicate counts + 16 kB count-min + 6 kB queue + 5 kB candidates = 51 kB (three workgroups per CU: <= 53 760 B)
+    __shared__ __attribute__((aligned(16))) uint32_t tab[PB_TAB];
+    __shared__ __attribute__((aligned(16))) uint32_t dup[PB_TAB / 2];
+    __shared__ __attribute__((aligned(16))) uint32_t cm[PT_CM / 2];
+    __shared__ unsigned long long s_mx;
+    __shared__ uint32_t s_q[PT_Q];
+    __shared__ uint64_t sc_v[PB_CST], sc_h[PB_CST]; __shared__ uint32_t sc_b[PB_CST];
+    __shared__ uint32_t s_nc, s_ns;
+    const uint32_t EMPTY = 0xFFFFFFFFu;
+    const uint32_t seg = L.cand_cap / gridDim.x;
+    uint32_t my_nc = 0;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr uint32_t NW = PT2_T / 64;
+    constexpr int KPL = 8;                                        // ids per lane held in registers between the two passes (more: re-read from the slices)
+    const uint64_t n_items = (uint64_t)ng << lg_max;              // bucket-major over the chunk, as k_prob_buckets
+    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint32_t jpos = (uint32_t)(item / ng), gl = (uint32_t)(item % ng);
+        const uint32_t sh = g_sh[gl], lg = vbits - sh, rs = lg_max - lg;
+        if (jpos & ((1u << rs) - 1u)) continue;                    // (workgroup-uniform) this genome has fewer buckets: it takes part at every 2^rs-th position
+        const uint32_t bk = jpos >> rs;
+        const uint64_t fb = (uint64_t)g_boff[gl] + bk;
+        uint64_t *qg = q + (uint64_t)gl * m;
+        const bool pf = L.prof && blockIdx.x == 0 && threadIdx.x == 0;
+        long long t0 = pf ? clock64() : 0, t1;
+#define GS_PSTAMP(i) do { if (pf) { t1 = clock64(); atomicAdd(&L.prof[i], (unsigned long long)(t1 - t0)); t0 = t1; } } while (0)
+        const uint32_t capg = g_cap[gl];
+        const uint32_t *base = vals32 + g_vbase[gl] + (uint64_t)bk * parts * capg;
+        // ---- this wavefront's share of the bucket's slices: whole slices (parts >= 8) or an equal piece of one; the ids go to registers at once (every load
+        //      in flight together: the slices are cold in HBM and a load per loop trip was a round trip per trip)
+        const uint32_t mycnt = lane < parts ? cnt[fb * parts + lane] : 0u;      // (every wavefront reads the counts itself: no barrier in front of the loads)
+        uint32_t n = mycnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+        const uint32_t IT = capg >> 6;                             // 64-id trips per slice (the capacity is a multiple of 64)
+        uint32_t lo = 0, hi = 0, p_small = 0, NU;
+        if (parts >= NW) NU = (parts / NW) * IT;
+        else {
+            const uint32_t sub = NW / parts, piece = wv / parts; p_small = wv % parts;
+            const uint32_t np = (uint32_t)__shfl((int)mycnt, (int)p_small);
+            lo = (uint32_t)((uint64_t)np * piece / sub); hi = (uint32_t)((uint64_t)np * (piece + 1) / sub);
+            NU = (hi - lo + 63) >> 6;
+        }
+        auto key_at = [&](uint32_t u, uint32_t &id) -> bool {      // u-th trip of this wavefront: the lane's id, or false
+            if (parts >= NW) {
+                const uint32_t p = wv + NW * (u / IT), i = (u % IT) * 64 + lane;
+                if (p >= parts || i >= (uint32_t)__shfl((int)mycnt, (int)p)) return false;
+                id = base[(uint64_t)p * capg + i];
+                return true;
+            }
+            const uint32_t i = lo + u * 64 + lane;
+            if (i >= hi) return false;
+            id = base[(uint64_t)p_small * capg + i];
+            return true;
+        };
+        uint32_t kreg[KPL]; uint32_t kval = 0;                     // kval: bit u = kreg[u] holds an id
+#pragma unroll
+        for (int u = 0; u < KPL; u++) { kreg[u] = 0; if ((uint32_t)u < NU && key_at(u, kreg[u])) kval |= 1u << u; }
+        __syncthreads();                                           // the previous bucket's LDS is dead
+        for (uint32_t s = threadIdx.x; s < PB_TAB / 4; s += PT2_T) ((uint4 *)tab)[s] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        for (uint32_t s = threadIdx.x; s < PB_TAB / 8; s += PT2_T) ((uint4 *)dup)[s] = make_uint4(0, 0, 0, 0);
+        for (uint32_t s = threadIdx.x; s < PT_CM / 8; s += PT2_T) ((uint4 *)cm)[s] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) { s_nc = 0; s_ns = 0; s_mx = 0; }
+        uint64_t thr_b = __hip_atomic_load(&thr[gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((jpos & ((1u << (lg_max > 5 ? lg_max - 5 : 0)) - 1u)) == 0 && jpos != 0) {      // 31 times per genome: rescan q[], publish the tighter bound
+            unsigned long long mx = 0;
+            for (uint32_t i0 = 0; i0 < m; i0 += 8 * PT2_T) {
+                unsigned long long x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + u * PT2_T + threadIdx.x; x[u] = i < m ? __hip_atomic_load(&qg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) mx = x[u] > mx ? x[u] : mx;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+            __syncthreads();
+            if (lane == 0) atomicMax(&s_mx, mx);
+            __syncthreads();
+            const unsigned long long t = s_mx;
+            if (threadIdx.x == 0) atomicMin((unsigned long long *)&thr[gl], t);
+            if (t < thr_b) thr_b = t;
+        }
+        const double thr_d = __longlong_as_double((long long)thr_b);
+        const double thr_m = thr_d * (1.0 + 0x1.0p-40);
+        __syncthreads();
+        if (n == 0) continue;                                      // (workgroup-uniform)
+        GS_PSTAMP(0);
+        auto cell_of = [&](uint32_t id) -> uint32_t { return (id * 0x9E3779B1u) >> 19; };      // 13 bits: PT_CM cells (the product pt_mix takes its lg bits from: one multiplication)
+        const bool wide = n > 65535u;                              // a 16-bit cell could wrap: everything counts as "many copies" (and overflows the table: redone)
+        // ---- pass A: every k-mer into its count-min cell (one non-returning LDS add)
+        if (!wide) {
+#pragma unroll
+            for (int u = 0; u < KPL; u++) if (kval & (1u << u)) { const uint32_t c = cell_of(kreg[u]); atomicAdd(&cm[c >> 1], 1u << ((c & 1) * 16)); }
+            for (uint32_t u = KPL; u < NU; u++) { uint32_t id; if (key_at(u, id)) { const uint32_t c = cell_of(id); atomicAdd(&cm[c >> 1], 1u << ((c & 1) * 16)); } }
+        }
+        __syncthreads();
+        GS_PSTAMP(1);
+        // ---- pass B: first draw of every k-mer against the bound its cell allows. What may matter (~1 id in 12) is QUEUED, compacted across the wavefront:
+        //      a CAS insert with its probe loop inside the twelve unrolled trips was ~100 scalar mask instructions per trip for a handful of lanes
+        auto first_draw = [&](uint64_t v) -> double {
+            const uint64_t s0 = splitmix_mix(v + GS_GAMMA), s3 = splitmix_mix(v + 4 * GS_GAMMA);
+            return pc.c1 * ((double)((rotl64(s0 + s3, 23) + s0) >> 12) * 0x1.0p-52);
+        };
+        auto keep_b = [&](uint32_t id) -> bool {
+            const uint32_t ce = cell_of(id);
+            const uint32_t c = wide ? 0xFFFFu : ((cm[ce >> 1] >> ((ce & 1) * 16)) & 0xFFFFu);      // >= the multiplicity of this value
+            const double x0 = first_draw(pt_value(bk, id, sh, lg));
+            // even c copies leave its first point above every slot minimum (x1 / w > thr), and it is dead in pass 2 (1 / w > thr), for every w <= c: tested without
+            // the division - x0 > c thr (1 + 2^-40) implies fl(fl(1 / w) x0) > thr (the margin covers the three roundings), and with x0 < 1 also 1 / w > thr
+            return !(x0 < 1.0 && x0 > (double)c * thr_m);
+        };
+        auto queue_b = [&](bool valid, uint32_t id) {
+            const bool keep = valid && keep_b(id);
+            const uint64_t bal = __ballot(keep);
+            if (bal) {                                               // (wavefront-uniform)
+                uint32_t qb = 0;
+                if (lane == 0) qb = atomicAdd(&s_ns, (uint32_t)__popcll(bal));
+                qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+                const uint32_t at = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (keep && at < (uint32_t)PT_Q) s_q[at] = id;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < KPL; u++) if ((uint32_t)u < NU) queue_b((kval >> u) & 1u, kreg[u]);
+        for (uint32_t u = KPL; u < NU; u++) { uint32_t id = 0; const bool ok = key_at(u, id); queue_b(ok, id); }
+        __syncthreads();
+        GS_PSTAMP(2);
+        // ---- the queued ids enter the exact table on dense wavefronts: CAS + duplicate count as in k_prob_buckets; the lane whose CAS created an entry owns it
+        bool over = false;
+        auto insert_id = [&](uint32_t id) -> uint32_t {
+            uint32_t s = (id * 0x85EBCA6Bu) >> 20;                  // 12 bits: PB_TAB slots (the raw id is the k-mer's last bases)
+            for (uint32_t probe = 0; probe < PB_TAB; probe++) {
+                const uint32_t old = atomicCAS(&tab[s], EMPTY, id);
+                if (old == EMPTY) return s;
+                if (old == id) {
+                    const uint32_t before = atomicAdd(&dup[s >> 1], 1u << ((s & 1) * 16));
+                    if (((before >> ((s & 1) * 16)) & 0xFFFFu) == 0xFFFFu) over = true;
+                    return 0xFFFFFFFFu;
+                }
+                s = (s + 1) & (PB_TAB - 1);
+            }
+            over = true;
+            return 0xFFFFFFFFu;
+        };
+        const uint32_t nq = s_ns;
+        const bool queued = nq <= (uint32_t)PT_Q;
+        uint32_t own[PT_Q / PT2_T];
+        if (queued) {
+#pragma unroll
+            for (int t = 0; t < PT_Q / PT2_T; t++) { const uint32_t i = t * PT2_T + threadIdx.x; own[t] = i < nq ? insert_id(s_q[i]) : 0xFFFFFFFFu; }
+        } else {
+            // more than the queue holds (a loose bound over a large bucket): every id straight into the table, one rolled loop; the entries come from a table sweep
+            for (uint32_t u = 0; u < NU; u++) { uint32_t id = 0; if (key_at(u, id) && keep_b(id)) (void)insert_id(id); }
+        }
+        if (over) ovf[gl] = 1;
+        __syncthreads();
+        GS_PSTAMP(3);
+        // ---- the exact (value, multiplicity) pairs, as in k_prob_buckets
+        uint32_t wloc = 0;
+        auto count_of = [&](uint32_t s) -> uint32_t { return 1u + ((dup[s >> 1] >> ((s & 1) * 16)) & 0xFFFFu); };
+        auto entry = [&](uint32_t s) {
+            const uint64_t v = pt_value(bk, tab[s], sh, lg);
+            const uint32_t w = count_of(s);
+            wloc = w > wloc ? w : wloc;
+            const double winv = w == 1 ? 1.0 : 1.0 / (double)w;
+            const bool alive2 = !(winv > thr_d);
+            Rng rg; rg.seed(v);
+            const double x = texp_sample(pc, rg);
+            const double h = 0.0 + winv * x;
+            if (h > thr_d && !alive2) return;                        // the exact multiplicity: the false alarms of shared cells end here
+            const uint32_t b = (uint32_t)rng_uint(rg, (uint64_t)m, zone);
+            if (!(h > thr_d)) {
+                const uint64_t hb = (uint64_t)__double_as_longlong(h);
+                uint64_t *slot = qg + b;
+                if (hb <= __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    (void)__hip_atomic_fetch_min((unsigned long long *)slot, (unsigned long long)hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t sp = atomicAdd(&s_nc, 1u);
+                    if (sp < (uint32_t)PB_CST) { sc_v[sp] = v; sc_h[sp] = hb; sc_b[sp] = b; }
+                    else {
+                        const uint32_t pos = atomicAdd(L.n_cand, 1u);
+                        if (pos < L.ovf_cap) { const uint32_t o = L.cand_cap + pos; L.cand_v[o] = v; L.cand_h[o] = hb; L.cand_gb[o] = (uint64_t)gl * m + b; }
+                    }
+                }
+            }
+            if (alive2) {
+                const uint32_t pos = atomicAdd(L.n_act, 1u);
+                if (pos < L.act_cap) {
+                    L.akey[pos] = v; L.agl[pos] = gl; L.acnt[pos] = w;
+                    L.astate[pos] = rg.s0; L.astate[(uint64_t)L.act_cap + pos] = rg.s1; L.astate[2 * (uint64_t)L.act_cap + pos] = rg.s2; L.astate[3 * (uint64_t)L.act_cap + pos] = rg.s3;
+                }
+            }
+        };
+        if (pf) { atomicAdd(&L.prof[6], (unsigned long long)nq); atomicAdd(&L.prof[7], 1ull); atomicAdd(&L.prof[8], (unsigned long long)n); }
+        if (queued) {
+#pragma unroll
+            for (int t = 0; t < PT_Q / PT2_T; t++) if (own[t] != 0xFFFFFFFFu) entry(own[t]);
+        } else { for (uint32_t s = threadIdx.x; s < PB_TAB; s += PT2_T) if (tab[s] != EMPTY) entry(s); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)wloc, o); wloc = y > wloc ? y : wloc; }
+        if (lane == 0 && wloc > 1 && wloc > __hip_atomic_load(&wmax[gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&wmax[gl], wloc);
+        __syncthreads();
+        GS_PSTAMP(4);
+        const uint32_t nst = s_nc < (uint32_t)PB_CST ? s_nc : (uint32_t)PB_CST;
+        if (pf) atomicAdd(&L.prof[9], (unsigned long long)s_nc);
+        if (nst) {
+            if (my_nc + nst > seg) { if (threadIdx.x == 0) atomicMax(L.n_cand, 0xFFFFFFFFu); }
+            else {
+                const uint32_t cb = blockIdx.x * seg + my_nc;
+                for (uint32_t i = threadIdx.x; i < nst; i += PT2_T) { L.cand_v[cb + i] = sc_v[i]; L.cand_h[cb + i] = sc_h[i]; L.cand_gb[cb + i] = (uint64_t)gl * m + sc_b[i]; }
+                my_nc += nst;
+            }
+        }
+        GS_PSTAMP(5);
+#undef GS_PSTAMP
+    }
+    if (threadIdx.x == 0) L.seg_n[blockIdx.x] = my_nc;
+}
+
+// one chunk of genomes [g0, g0 + ng) through the tiered form; lgs = log2(buckets) per genome (host plan). redo as run_prob_buckets.
+static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *upre,
+                          const uint64_t *genome_rec_off, const uint64_t *gunits, uint64_t g0, uint32_t ng, const uint64_t *hk, const uint32_t *lgs, const ProbConst &pc,
+                          void *sig_rows, std::vector<uint8_t> &redo)
+{
+    const uint32_t m = p->sketch_size, k = p->k;
+    const bool aa = p->data_t == GS_DATA_AA;
+    const int sigbits = gs_value_bits(p);
+    const uint64_t zone = uint_zone(m);
+    int rc;
+    const uint32_t vbits = aa ? 5 * k : 2 * k;
+    uint64_t maxk = 0; uint32_t nbmax = 1, nbt = 0;
+    for (uint32_t i = 0; i < ng; i++) maxk = std::max(maxk, hk[i]);
+    // parts per genome (one for the chunk): ~8 tiles of 32 768 k-mers each at least, a power of two (the bucket kernel deals slices to its eight wavefronts)
+    uint32_t parts = 1;
+    { const uint64_t tiles = maxk / ((uint64_t)PT_T * 32) + 1; while (parts < 32 && (uint64_t)parts * 2 * 8 <= tiles) parts *= 2; }
+    if (getenv("GS_PROB_PARTS")) { parts = 1; const uint32_t want = (uint32_t)atoi(getenv("GS_PROB_PARTS")); while (parts * 2 <= want && parts < 32) parts *= 2; }
+    // per genome: shift, flat bucket offset, slice capacity (mean + 5 sigma of a slice's Poisson-like fill), offset of its slices (in 4-byte ids)
+    std::vector<uint32_t> info(3 * (size_t)ng + 1); std::vector<uint64_t> vbase(ng); std::vector<uint64_t> capbits(ng); std::vector<double> capd(ng);
+    uint32_t *sh = info.data(), *boff = sh + ng, *cap = boff + ng + 1;
+    uint64_t T32 = 0;
+    const double cap_c = getenv("GS_PROB_CAP_C") ? atof(getenv("GS_PROB_CAP_C")) : 10.0;     // P(a genome fails the check) = e^-c
+    for (uint32_t i = 0; i < ng; i++) {
+        const uint32_t lg = lgs[i];
+        sh[i] = vbits - lg; boff[i] = nbt; nbt += 1u << lg; nbmax = std::max(nbmax, 1u << lg);
+        const double e = (double)hk[i] / ((double)(1u << lg) * parts);
+        cap[i] = ((uint32_t)(e + 5.0 * sqrt(e) + 16.0) + 63u) & ~63u;       // (a multiple of 64: the bucket kernel reads a slice in whole wavefront trips)
+        vbase[i] = T32; T32 += ((uint64_t)parts << lg) * cap[i];
+        // speculative cap of max_b q[b]: the points of a genome form a process of rate N (its k-mers with multiplicity) over m slots
+        const double t = (double)m / (double)hk[i] * (log((double)m) + cap_c);
+        capd[i] = t > 0.0 ? t : 0x1.0p-1000;
+        memcpy(&capbits[i], &capd[i], 8);
+    }
+    boff[ng] = nbt;
+    PoolBuf dinfo(c, 0), dvb(c, 2), cnt(c, 3), vals(c, 8), q(c, 9), qprev(c, 10), sig(c, 11), sigpass(c, 12), thr(c, 13), wmax(c, 14), qmax(c, 15), ctr(c, 7);
+    PoolBuf cv(c, 16), chh(c, 17), cgb(c, 18), akey(c, 19), agl(c, 24), acnt(c, 25), astate(c, 26), ph(c, 27), pb(c, 37), ovf(c, 38), segn(c, 28);
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)ng * m * 16 + 65536, (uint64_t)1 << 30), ovf_cap = cand_cap / 4, act_cap = 1u << 24;
+    if ((rc = dinfo.alloc(4 * info.size())) || (rc = dvb.alloc(8 * (size_t)ng)) || (rc = cnt.alloc((size_t)4 * nbt * parts)) || (rc = vals.alloc(4 * (size_t)T32 + 64)) ||
+        (rc = q.alloc((size_t)8 * ng * m)) || (rc = qprev.alloc((size_t)8 * ng * m)) || (rc = sig.alloc((size_t)8 * ng * m)) || (rc = sigpass.alloc((size_t)8 * ng * m)) ||
+        (rc = thr.alloc(8 * (size_t)ng)) || (rc = wmax.alloc(4 * (size_t)ng)) || (rc = qmax.alloc(8 * (size_t)ng)) || (rc = ctr.alloc(64)) ||
+        (rc = cv.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = chh.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = cgb.alloc((size_t)8 * (cand_cap + ovf_cap))) ||
+        (rc = ovf.alloc(4 * (size_t)ng)) || (rc = segn.alloc((size_t)4 * c->n_cu * 8)) ||
+        (rc = akey.alloc((size_t)8 * act_cap)) || (rc = agl.alloc((size_t)4 * act_cap)) || (rc = acnt.alloc((size_t)4 * act_cap)) || (rc = astate.alloc((size_t)32 * act_cap)))
+        return rc;
+    const uint32_t *d_sh = dinfo.as<uint32_t>(), *d_boff = d_sh + ng, *d_cap = d_boff + ng + 1;
+    GS_HIP_CHECK(hipMemcpyAsync(dinfo.p, info.data(), 4 * info.size(), hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(dvb.p, vbase.data(), 8 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(thr.p, capbits.data(), 8 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_prob_init, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), ng * (uint64_t)m);
+    {
+        std::vector<uint32_t> ones(ng, 1u);
+        GS_HIP_CHECK(hipMemcpyAsync(wmax.p, ones.data(), 4 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));               // (the host vectors above go out of use here)
+    }
+    GS_HIP_CHECK(hipMemsetAsync(ovf.p, 0, 4 * (size_t)ng, c->stream));
+    GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));          // [2] n_cand, [3] n_act, [4] n_active genomes
+    uint32_t *ctr32 = ctr.as<uint32_t>();
+    {
+        ProfScope ps(c, FAM_SKETCH);
+        const size_t lds = ((size_t)3 * nbmax + 8 + (size_t)PT_T * 32) * 4;
+        dim3 grid(parts, ng), block(PT_T);
+#define GS_LAUNCH_PT1(AAV)                                                                                                  \
+    do {                                                                                                                    \
+        auto kern = k_prob_part1<AAV>;                                                                                      \
+        GS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipLaunchKernelGGL(kern, grid, block, lds, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, kq_of(p), vbits, d_sh, d_boff, dvb.as<uint64_t>(), d_cap, \
+                           parts, vals.as<uint32_t>(), cnt.as<uint32_t>(), ovf.as<uint32_t>());                             \
+    } while (0)
+        if (aa) GS_LAUNCH_PT1(true);
+        else if (getenv("GS_PROB_TWOWALK")) GS_LAUNCH_PT1(false);
+        else {
+            GS_HIP_CHECK(hipFuncSetAttribute((const void *)k_prob_part1_dna, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_prob_part1_dna, grid, block, lds, c->stream, seq, rec_start, rec_len, upre, genome_rec_off, gunits, g0, kq_of(p), vbits, d_sh, d_boff, dvb.as<uint64_t>(), d_cap,
+                               parts, vals.as<uint32_t>(), cnt.as<uint32_t>(), ovf.as<uint32_t>());
+        }
+#undef GS_LAUNCH_PT1
+        GS_HIP_CHECK(hipGetLastError());
+        PbLists L{cv.as<uint64_t>(), chh.as<uint64_t>(), cgb.as<uint64_t>(), cand_cap, ovf_cap, ctr32 + 2, segn.as<uint32_t>(), akey.as<uint64_t>(), agl.as<uint32_t>(), acnt.as<uint32_t>(),
+                  astate.as<uint64_t>(), act_cap, ctr32 + 3, nullptr};
+        DevBuf profbuf;
+        if (getenv("GS_PROB_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); L.prof = profbuf.as<unsigned long long>(); }
+        int per_cu = 3;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_prob_tiers, PT2_T, 0);
+        uint32_t lg_max = 0; while ((1u << lg_max) < nbmax) lg_max++;
+        const uint32_t wgs = (uint32_t)std::min<uint64_t>((uint64_t)ng << lg_max, (uint64_t)c->n_cu * std::min(std::max(per_cu, 1), 8));
+        hipLaunchKernelGGL(k_prob_tiers, dim3(wgs), dim3(PT2_T), 0, c->stream, vals.as<uint32_t>(), dvb.as<uint64_t>(), d_cap, cnt.as<uint32_t>(), parts, vbits, d_sh, d_boff, ng, lg_max,
+                           m, zone, pc, q.as<uint64_t>(), thr.as<uint64_t>(), wmax.as<uint32_t>(), L, ovf.as<uint32_t>());
+        if (L.prof) {
+            unsigned long long h[16];
+            GS_HIP_CHECK(hipMemcpyAsync(h, L.prof, 128, hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            const double it = (double)std::max<unsigned long long>(h[7], 1);
+            fprintf(stderr, "[GS_PROB_PROFILE] tiers: workgroup 0 of %u (%d per CU, %u parts): %llu buckets, keys/bucket %.0f, queued %.0f, candidates %.1f | cycles per bucket: load+zero+thr %.0f, count %.0f, draw+queue %.0f, insert %.0f, entries %.0f, flush %.0f\n",
+                    wgs, per_cu, parts, h[7], h[8] / it, h[6] / it, h[9] / it, h[0] / it, h[1] / it, h[2] / it, h[3] / it, h[4] / it, h[5] / it);
+        }
+        hipLaunchKernelGGL(k_prob_claim_list, dim3(wgs + 1), dim3(256), 0, c->stream, cv.as<uint64_t>(), chh.as<uint64_t>(), cgb.as<uint64_t>(), segn.as<uint32_t>(), cand_cap / wgs, wgs,
+                           cand_cap, ctr32 + 2, ovf_cap, q.as<uint64_t>(), sigpass.as<uint64_t>());
+        hipLaunchKernelGGL(k_prob_fold, dim3(ng), dim3(256), 0, c->stream, m, 1u, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), wmax.as<uint32_t>(),
+                           qmax.as<double>(), ctr32 + 4);
+        GS_HIP_CHECK(hipGetLastError());
+    }
+    uint32_t hc[8]; std::vector<uint32_t> hovf(ng); std::vector<double> hq(ng);
+    GS_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, 32, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(hovf.data(), ovf.p, 4 * (size_t)ng, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(hq.data(), qmax.p, 8 * (size_t)ng, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    redo.assign(ng, 0);
+    if (hc[2] > ovf_cap || hc[3] > act_cap) { redo.assign(ng, 1); return GS_OK; }
+    // the speculation is checked here: q only decreases in later passes, so a maximum under the cap after pass 1 stays there
+    for (uint32_t i = 0; i < ng; i++) redo[i] = (hovf[i] || !(hq[i] <= capd[i])) ? 1 : 0;
+    uint32_t na = hc[4];
+    const uint32_t n_list = hc[3];
+    if (na && n_list) {
+        if ((rc = ph.alloc((size_t)8 * n_list)) || (rc = pb.alloc((size_t)4 * n_list))) return rc;
+        const uint32_t lg = std::max<uint32_t>(1, std::min<uint32_t>((n_list + 255) / 256, (uint32_t)c->n_cu * 16));
+        for (uint32_t it = 2; na; it++) {
+            GS_HIP_CHECK(hipMemsetAsync(ctr32 + 4, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_prob_point_act, dim3(lg), dim3(256), 0, c->stream, akey.as<uint64_t>(), agl.as<uint32_t>(), acnt.as<uint32_t>(), n_list, act_cap, m, zone, pc, it,
+                               qmax.as<double>(), q.as<uint64_t>(), astate.as<uint64_t>(), ph.as<uint64_t>(), pb.as<uint32_t>());
+            hipLaunchKernelGGL(k_prob_claim_act, dim3(lg), dim3(256), 0, c->stream, akey.as<uint64_t>(), agl.as<uint32_t>(), n_list, m, q.as<uint64_t>(), ph.as<uint64_t>(), pb.as<uint32_t>(),
+                               sigpass.as<uint64_t>());
+            hipLaunchKernelGGL(k_prob_fold, dim3(ng), dim3(256), 0, c->stream, m, it, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), wmax.as<uint32_t>(),
+                               qmax.as<double>(), ctr32 + 4);
+            GS_HIP_CHECK(hipGetLastError());
+            GS_HIP_CHECK(hipMemcpyAsync(&na, ctr32 + 4, 4, hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+    }
+    if (sigbits == 32) hipLaunchKernelGGL(k_prob_write<uint32_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint32_t *)sig_rows);
+    else hipLaunchKernelGGL(k_prob_write<uint64_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint64_t *)sig_rows);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+// prob driver: runs of genomes the tiered form suits go through it in chunks; what it flags, and the genomes it does not suit, go through the bucketed form
+// (chunks again), and what that one flags or does not suit through the sorted form
 static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, uint64_t seq_bytes, const uint64_t *rec_start, const uint64_t *rec_len,
                     uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out)
 {
     const uint32_t m = p->sketch_size, k = p->k;
     const char *e = getenv("GS_PROB_IMPL");
     if (e && !strcmp(e, "sort")) return run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off, n_genomes, sig_out);
+    const bool tiers_on = !(e && !strcmp(e, "buckets"));
     ProbConst pc;
     pc.lambda = log((double)m / (double)(m - 1));
     pc.c1 = expm1(pc.lambda) / pc.lambda;
@@ -1609,26 +2212,67 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
     const size_t row = (size_t)m * (gs_value_bits(p) / 8);
     auto suits = [&](uint64_t g) { return hk[g] >= (uint64_t)64 * m && hk[g] <= (uint64_t)PB_NBMAX * PB_AVG; };
+    // tiered form: the in-bucket id must fit 4 bytes (>= vbits - 31 bucket bits), <= 2^PT_LGMAX buckets of PT_MINB .. 3 PT_AVG k-mers
+    const uint32_t vbits = p->data_t == GS_DATA_AA ? 5 * k : 2 * k;
+    std::vector<uint32_t> lgs(n_genomes, 0xFFFFFFFFu);
+    const uint64_t pt_avg = getenv("GS_PROB_PT_AVG") ? (uint64_t)std::max(256, atoi(getenv("GS_PROB_PT_AVG"))) : (uint64_t)PT_AVG;
+    if (tiers_on && vbits <= 31 + (uint32_t)PT_LGMAX)
+        for (uint64_t g = 0; g < n_genomes; g++) {
+            if (hk[g] < (uint64_t)64 * m) continue;
+            uint32_t lg = vbits > 31 ? vbits - 31 : 0;
+            while ((pt_avg << lg) < hk[g] && lg < (uint32_t)PT_LGMAX && lg + 1 < vbits) lg++;
+            if ((hk[g] >> lg) >= (uint64_t)PT_MINB && (hk[g] >> lg) <= 3 * pt_avg) lgs[g] = lg;
+        }
+    auto suits_tiers = [&](uint64_t g) { return lgs[g] != 0xFFFFFFFFu; };
     const uint64_t max_items = (uint64_t)3 << 29;                 // ~1.6e9 k-mers per chunk (12.9 GB of bucketed values)
+    // [a, b) through the bucketed form where it suits, else (and what it flags) through the sorted form
+    auto old_range = [&](uint64_t a, uint64_t b) -> int {
+        for (uint64_t g0 = a; g0 < b;) {
+            uint64_t g1 = g0 + 1;
+            if (!suits(g0)) {
+                while (g1 < b && !suits(g1)) g1++;
+                GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+                if ((rc = run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off + g0, g1 - g0, (uint8_t *)sig_out + row * g0))) return rc;
+                g0 = g1;
+                continue;
+            }
+            uint64_t T = hk[g0];
+            while (g1 < b && suits(g1) && g1 - g0 < 65535 && T + hk[g1] <= max_items) { T += hk[g1]; g1++; }
+            std::vector<uint8_t> redo;
+            if ((rc = run_prob_buckets(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, pc,
+                                       (uint8_t *)sig_out + row * g0, redo))) return rc;
+            for (uint64_t g = g0; g < g1;) {                          // flagged genomes, in runs
+                if (!redo[g - g0]) { g++; continue; }
+                uint64_t h = g + 1;
+                while (h < g1 && redo[h - g0]) h++;
+                GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+                if ((rc = run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off + g, h - g, (uint8_t *)sig_out + row * g))) return rc;
+                g = h;
+            }
+            g0 = g1;
+        }
+        return GS_OK;
+    };
     for (uint64_t g0 = 0; g0 < n_genomes;) {
         uint64_t g1 = g0 + 1;
-        if (!suits(g0)) {
-            while (g1 < n_genomes && !suits(g1)) g1++;
-            if ((rc = run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off + g0, g1 - g0, (uint8_t *)sig_out + row * g0))) return rc;
+        if (!suits_tiers(g0)) {
+            while (g1 < n_genomes && !suits_tiers(g1)) g1++;
+            if ((rc = old_range(g0, g1))) return rc;
             g0 = g1;
             continue;
         }
         uint64_t T = hk[g0];
-        while (g1 < n_genomes && suits(g1) && g1 - g0 < 65535 && T + hk[g1] <= max_items) { T += hk[g1]; g1++; }
+        while (g1 < n_genomes && suits_tiers(g1) && g1 - g0 < 65535 && T + hk[g1] <= max_items) { T += hk[g1]; g1++; }
         std::vector<uint8_t> redo;
-        if ((rc = run_prob_buckets(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, pc,
-                                   (uint8_t *)sig_out + row * g0, redo))) return rc;
-        for (uint64_t g = g0; g < g1;) {                          // flagged genomes, in runs
+        if ((rc = run_prob_tiers(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, lgs.data() + g0, pc,
+                                 (uint8_t *)sig_out + row * g0, redo))) return rc;
+        for (uint64_t g = g0; g < g1;) {                              // flagged genomes (slice / table overflow, cap not confirmed), in runs: the exact fallback
             if (!redo[g - g0]) { g++; continue; }
             uint64_t h = g + 1;
             while (h < g1 && redo[h - g0]) h++;
             GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-            if ((rc = run_prob_sorted(c, p, seq, seq_bytes, rec_start, rec_len, n_rec, genome_rec_off + g, h - g, (uint8_t *)sig_out + row * g))) return rc;
+            if (getenv("GS_PROB_VERBOSE")) fprintf(stderr, "[GS_PROB] tiered form flagged genomes [%llu, %llu): redone by the bucketed form\n", (unsigned long long)g, (unsigned long long)h);
+            if ((rc = old_range(g, h))) return rc;
             g = h;
         }
         g0 = g1;
