@@ -1380,16 +1380,20 @@ __global__ void k_prob_claim_list(const uint64_t *__restrict__ cand_v, const uin
                                   uint32_t seg, uint32_t nseg, uint32_t cand_cap, const uint32_t *__restrict__ n_ovf, uint32_t ovf_cap, const uint64_t *__restrict__ q,
                                   uint64_t *__restrict__ sigpass)
 {
-    // one workgroup per segment (the bucket kernel's workgroups each filled their own), then the shared overflow region
-    for (uint32_t sgm = blockIdx.x; sgm <= nseg; sgm += gridDim.x) {
-        const bool ov = sgm == nseg;
-        const uint32_t base = ov ? cand_cap : sgm * seg;
-        uint32_t n = ov ? *n_ovf : seg_n[sgm];
-        if (ov && n > ovf_cap) n = ovf_cap;
+    // one workgroup per segment (the bucket kernel's workgroups each filled their own), then the shared overflow region, dealt over all workgroups (it holds
+    // the first buckets' candidates - every point is one while a slot is empty: millions, 13 ms when one workgroup walked them)
+    for (uint32_t sgm = blockIdx.x; sgm < nseg; sgm += gridDim.x) {
+        const uint32_t base = sgm * seg, n = seg_n[sgm];
         for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
             const uint64_t gb = cand_gb[base + e];
             if (cand_h[base + e] == q[gb]) atomicMin((unsigned long long *)&sigpass[gb], (unsigned long long)cand_v[base + e]);
         }
+    }
+    uint32_t n = *n_ovf;
+    if (n > ovf_cap) n = ovf_cap;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint64_t gb = cand_gb[cand_cap + e];
+        if (cand_h[cand_cap + e] == q[gb]) atomicMin((unsigned long long *)&sigpass[gb], (unsigned long long)cand_v[cand_cap + e]);
     }
 }
 // passes >= 2 over the active list (generator state carried from point to point)
@@ -1830,36 +1834,39 @@ __global__ __launch_bounds__(PT_T) void k_prob_part1_dna(const uint8_t *__restri
     for (uint32_t b = threadIdx.x; b < NB; b += PT_T) cg[(uint64_t)b * parts + part] = s_cur[b];
 }
 
-__global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restrict__ vals32, const uint64_t *__restrict__ g_vbase, const uint32_t *__restrict__ g_cap,
-                                                         const uint32_t *__restrict__ cnt, uint32_t parts, uint32_t vbits, const uint32_t *__restrict__ g_sh,
-                                                         const uint32_t *__restrict__ g_boff, uint32_t ng, uint32_t lg_max, uint32_t m, uint64_t zone, ProbConst pc,
-                                                         uint64_t *__restrict__ q, uint64_t *__restrict__ thr, uint32_t *__restrict__ wmax, PbLists L, uint32_t *__restrict__ ovf)
+// ---- the bucket work of the tiered form, in two kernels (one kernel with both halves ran at three workgroups per CU - 52 kB of LDS, 80 VGPRs - and 0.66 of its
+//      VALU issue; the filter half is 9/10 of the instructions and needs neither the table nor the registers of the generator):
+// k_prob_tier_filter  workgroup per bucket: count-min of every id (pass A), first draw of every id against the bound its cell allows (pass B); what may matter
+//                     (~1 id in 12) is compacted to a list in global memory, (offset, count) per bucket in `desc`. 22 kB of LDS, <= 64 VGPRs: four workgroups per CU.
+// k_prob_tier_points  one WAVEFRONT per bucket (no barriers; T = 64, table of 1024) - or a workgroup for the few buckets with more than 512 kept ids (T = 512,
+//                     table of 4096, the ones the wavefront form lists in `big`): the kept ids enter the exact table, the owners of the entries run the
+//                     generator with the exact multiplicity and lower q[], exactly as k_prob_buckets does from its table.
+__global__ __launch_bounds__(PT2_T, 8) void k_prob_tier_filter(const uint32_t *__restrict__ vals32, const uint64_t *__restrict__ g_vbase, const uint32_t *__restrict__ g_cap,
+                                                               const uint32_t *__restrict__ cnt, uint32_t parts, uint32_t vbits, const uint32_t *__restrict__ g_sh,
+                                                               const uint32_t *__restrict__ g_boff, uint32_t ng, uint32_t lg_max, ProbConst pc, const uint64_t *__restrict__ thr,
+                                                               uint32_t *__restrict__ kept, uint32_t kept_cap, uint32_t *__restrict__ kept_n, uint2 *__restrict__ desc,
+                                                               uint32_t *__restrict__ ovf, unsigned long long *__restrict__ prof)
 {
-    // LDS per workgroup: 16 kB table + 8 kB duplicate counts + 16 kB count-min + 6 kB queue + 5 kB candidates = 51 kB (three workgroups per CU: <= 53 760 B)
-    __shared__ __attribute__((aligned(16))) uint32_t tab[PB_TAB];
-    __shared__ __attribute__((aligned(16))) uint32_t dup[PB_TAB / 2];
     __shared__ __attribute__((aligned(16))) uint32_t cm[PT_CM / 2];
-    __shared__ unsigned long long s_mx;
     __shared__ uint32_t s_q[PT_Q];
-    __shared__ uint64_t sc_v[PB_CST], sc_h[PB_CST]; __shared__ uint32_t sc_b[PB_CST];
-    __shared__ uint32_t s_nc, s_ns;
-    const uint32_t EMPTY = 0xFFFFFFFFu;
-    const uint32_t seg = L.cand_cap / gridDim.x;
-    uint32_t my_nc = 0;
+    __shared__ uint32_t s_ns;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr uint32_t NW = PT2_T / 64;
     constexpr int KPL = 8;                                        // ids per lane held in registers between the two passes (more: re-read from the slices)
     const uint64_t n_items = (uint64_t)ng << lg_max;              // bucket-major over the chunk, as k_prob_buckets
-    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint32_t jpos = (uint32_t)(item / ng), gl = (uint32_t)(item % ng);
+    const uint32_t region = kept_cap / gridDim.x; uint32_t my_kept = 0;
+    // (jpos, gl) of item = jpos ng + gl, stepped without a division per bucket (a 64-bit division is ~150 instructions: a fifth of a bucket's work)
+    const uint32_t dj = gridDim.x / ng, dg = gridDim.x % ng;
+    uint32_t jpos = blockIdx.x / ng, gl = blockIdx.x % ng;
+    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x, jpos += dj, gl += dg) {
+        if (gl >= ng) { gl -= ng; jpos++; }
         const uint32_t sh = g_sh[gl], lg = vbits - sh, rs = lg_max - lg;
         if (jpos & ((1u << rs) - 1u)) continue;                    // (workgroup-uniform) this genome has fewer buckets: it takes part at every 2^rs-th position
         const uint32_t bk = jpos >> rs;
         const uint64_t fb = (uint64_t)g_boff[gl] + bk;
-        uint64_t *qg = q + (uint64_t)gl * m;
-        const bool pf = L.prof && blockIdx.x == 0 && threadIdx.x == 0;
+        const bool pf = prof && blockIdx.x == 0 && threadIdx.x == 0;
         long long t0 = pf ? clock64() : 0, t1;
-#define GS_PSTAMP(i) do { if (pf) { t1 = clock64(); atomicAdd(&L.prof[i], (unsigned long long)(t1 - t0)); t0 = t1; } } while (0)
+#define GS_PSTAMP(i) do { if (pf) { t1 = clock64(); atomicAdd(&prof[i], (unsigned long long)(t1 - t0)); t0 = t1; } } while (0)
         const uint32_t capg = g_cap[gl];
         const uint32_t *base = vals32 + g_vbase[gl] + (uint64_t)bk * parts * capg;
         // ---- this wavefront's share of the bucket's slices: whole slices (parts >= 8) or an equal piece of one; the ids go to registers at once (every load
@@ -1872,9 +1879,9 @@ __global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restr
         uint32_t lo = 0, hi = 0, p_small = 0, NU;
         if (parts >= NW) NU = (parts / NW) * IT;
         else {
-            const uint32_t sub = NW / parts, piece = wv / parts; p_small = wv % parts;
+            const uint32_t lgp = 31u - (uint32_t)__builtin_clz(parts), lgs = 3u - lgp, piece = wv >> lgp; p_small = wv & (parts - 1u);      // parts is a power of two below NW = 8
             const uint32_t np = (uint32_t)__shfl((int)mycnt, (int)p_small);
-            lo = (uint32_t)((uint64_t)np * piece / sub); hi = (uint32_t)((uint64_t)np * (piece + 1) / sub);
+            lo = (np * piece) >> lgs; hi = (np * (piece + 1)) >> lgs;
             NU = (hi - lo + 63) >> 6;
         }
         auto key_at = [&](uint32_t u, uint32_t &id) -> bool {      // u-th trip of this wavefront: the lane's id, or false
@@ -1892,37 +1899,20 @@ __global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restr
         uint32_t kreg[KPL]; uint32_t kval = 0;                     // kval: bit u = kreg[u] holds an id
 #pragma unroll
         for (int u = 0; u < KPL; u++) { kreg[u] = 0; if ((uint32_t)u < NU && key_at(u, kreg[u])) kval |= 1u << u; }
+        // the genome's cap (q[] moves only in the second kernel), as thresholds on the 52 uniform bits K of the first draw x0 = c1 K 2^-52: x0 < 1 for K < k_one, and
+        // x0 > c thr for K > c t_one - both with a margin of 2^-40 relative on the safe side (a k-mer that is kept needlessly costs time, never the result)
+        const double thr_d = __longlong_as_double((long long)thr[gl]);
+        const uint64_t k_one = (uint64_t)(0x1.0p52 / pc.c1 * (1.0 - 0x1.0p-40));
+        const double t1d = thr_d / pc.c1 * 0x1.0p52 * (1.0 + 0x1.0p-40) + 4.0;      // (+ 4: the roundings of this line and the truncation below leave t_one >= the exact product + 1)
+        const uint64_t t_one = t1d < 0x1.0p52 ? (uint64_t)t1d : ((uint64_t)1 << 52);
         __syncthreads();                                           // the previous bucket's LDS is dead
-        for (uint32_t s = threadIdx.x; s < PB_TAB / 4; s += PT2_T) ((uint4 *)tab)[s] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-        for (uint32_t s = threadIdx.x; s < PB_TAB / 8; s += PT2_T) ((uint4 *)dup)[s] = make_uint4(0, 0, 0, 0);
         for (uint32_t s = threadIdx.x; s < PT_CM / 8; s += PT2_T) ((uint4 *)cm)[s] = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x == 0) { s_nc = 0; s_ns = 0; s_mx = 0; }
-        uint64_t thr_b = __hip_atomic_load(&thr[gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((jpos & ((1u << (lg_max > 5 ? lg_max - 5 : 0)) - 1u)) == 0 && jpos != 0) {      // 31 times per genome: rescan q[], publish the tighter bound
-            unsigned long long mx = 0;
-            for (uint32_t i0 = 0; i0 < m; i0 += 8 * PT2_T) {
-                unsigned long long x[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + u * PT2_T + threadIdx.x; x[u] = i < m ? __hip_atomic_load(&qg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; }
-#pragma unroll
-                for (int u = 0; u < 8; u++) mx = x[u] > mx ? x[u] : mx;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
-            __syncthreads();
-            if (lane == 0) atomicMax(&s_mx, mx);
-            __syncthreads();
-            const unsigned long long t = s_mx;
-            if (threadIdx.x == 0) atomicMin((unsigned long long *)&thr[gl], t);
-            if (t < thr_b) thr_b = t;
-        }
-        const double thr_d = __longlong_as_double((long long)thr_b);
-        const double thr_m = thr_d * (1.0 + 0x1.0p-40);
+        if (threadIdx.x == 0) s_ns = 0;
         __syncthreads();
-        if (n == 0) continue;                                      // (workgroup-uniform)
+        if (n == 0) { if (threadIdx.x == 0) desc[fb] = make_uint2(0u, 0u); continue; }      // (workgroup-uniform)
         GS_PSTAMP(0);
         auto cell_of = [&](uint32_t id) -> uint32_t { return (id * 0x9E3779B1u) >> 19; };      // 13 bits: PT_CM cells (the product pt_mix takes its lg bits from: one multiplication)
-        const bool wide = n > 65535u;                              // a 16-bit cell could wrap: everything counts as "many copies" (and overflows the table: redone)
+        const bool wide = n > 65535u;                              // a 16-bit cell could wrap: everything counts as "many copies" (the queue overflows: redone)
         // ---- pass A: every k-mer into its count-min cell (one non-returning LDS add)
         if (!wide) {
 #pragma unroll
@@ -1931,19 +1921,16 @@ __global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restr
         }
         __syncthreads();
         GS_PSTAMP(1);
-        // ---- pass B: first draw of every k-mer against the bound its cell allows. What may matter (~1 id in 12) is QUEUED, compacted across the wavefront:
-        //      a CAS insert with its probe loop inside the twelve unrolled trips was ~100 scalar mask instructions per trip for a handful of lanes
-        auto first_draw = [&](uint64_t v) -> double {
-            const uint64_t s0 = splitmix_mix(v + GS_GAMMA), s3 = splitmix_mix(v + 4 * GS_GAMMA);
-            return pc.c1 * ((double)((rotl64(s0 + s3, 23) + s0) >> 12) * 0x1.0p-52);
-        };
+        // ---- pass B: first draw of every k-mer against the bound its cell allows; what may matter is queued, compacted across the wavefront
         auto keep_b = [&](uint32_t id) -> bool {
             const uint32_t ce = cell_of(id);
             const uint32_t c = wide ? 0xFFFFu : ((cm[ce >> 1] >> ((ce & 1) * 16)) & 0xFFFFu);      // >= the multiplicity of this value
-            const double x0 = first_draw(pt_value(bk, id, sh, lg));
+            const uint64_t v = pt_value(bk, id, sh, lg);
+            const uint64_t s0 = splitmix_mix(v + GS_GAMMA), s3 = splitmix_mix(v + 4 * GS_GAMMA);
+            const uint64_t K = (rotl64(s0 + s3, 23) + s0) >> 12;     // x0 = c1 K 2^-52; when < 1 it IS the first truncated exponential (SPEC 3.3)
             // even c copies leave its first point above every slot minimum (x1 / w > thr), and it is dead in pass 2 (1 / w > thr), for every w <= c: tested without
-            // the division - x0 > c thr (1 + 2^-40) implies fl(fl(1 / w) x0) > thr (the margin covers the three roundings), and with x0 < 1 also 1 / w > thr
-            return !(x0 < 1.0 && x0 > (double)c * thr_m);
+            // the division and in integers - x0 > c thr (1 + 2^-40) implies fl(fl(1 / w) x0) > thr (the margin covers the roundings), and with x0 < 1 also 1 / w > thr
+            return !(c < 2048u && K < k_one && K > (uint64_t)c * t_one);
         };
         auto queue_b = [&](bool valid, uint32_t id) {
             const bool keep = valid && keep_b(id);
@@ -1961,11 +1948,99 @@ __global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restr
         for (uint32_t u = KPL; u < NU; u++) { uint32_t id = 0; const bool ok = key_at(u, id); queue_b(ok, id); }
         __syncthreads();
         GS_PSTAMP(2);
-        // ---- the queued ids enter the exact table on dense wavefronts: CAS + duplicate count as in k_prob_buckets; the lane whose CAS created an entry owns it
+        // ---- the kept ids to the global list (one returning atomic per bucket reserves their place)
+        // ---- the kept ids to this workgroup's own stretch of the global list (one cursor for all workgroups was a same-address returning atomic per bucket:
+        //      13 ns each, serialised - the whole kernel's time)
+        const uint32_t nk = s_ns;
+        uint32_t off = 0xFFFFFFFFu;
+        if (nk <= (uint32_t)PT_Q && my_kept + nk <= region) { off = blockIdx.x * region + my_kept; my_kept += nk; }
+        if (threadIdx.x == 0) {
+            if (off == 0xFFFFFFFFu) ovf[gl] = 1;                    // more than the queue holds (a loose cap over a large bucket) or the stretch is full: the genome is redone
+            desc[fb] = make_uint2(off, off == 0xFFFFFFFFu ? 0u : nk);
+        }
+        if (off != 0xFFFFFFFFu) for (uint32_t i = threadIdx.x; i < nk; i += PT2_T) kept[off + i] = s_q[i];
+        if (pf) { atomicAdd(&prof[6], (unsigned long long)nk); atomicAdd(&prof[7], 1ull); atomicAdd(&prof[8], (unsigned long long)n); }
+        GS_PSTAMP(3);
+#undef GS_PSTAMP
+    }
+    if (threadIdx.x == 0 && my_kept) atomicAdd(kept_n, my_kept);      // (statistics)
+}
+// T lanes per bucket (64: a wavefront, no other wavefront shares its LDS; 512: a workgroup), TAB table entries. BIG: the items come from the list `big`.
+template <int T, int TAB, bool BIG>
+__global__ __launch_bounds__(T) void k_prob_tier_points(const uint32_t *__restrict__ kept, const uint2 *__restrict__ desc, uint32_t vbits, const uint32_t *__restrict__ g_sh,
+                                                        const uint32_t *__restrict__ g_boff, uint32_t ng, uint32_t lg_max, uint32_t m, uint64_t zone, ProbConst pc,
+                                                        uint64_t *__restrict__ q, uint64_t *__restrict__ thr, uint32_t *__restrict__ wmax, PbLists L, uint32_t *__restrict__ ovf,
+                                                        uint32_t *__restrict__ big, uint32_t *__restrict__ n_big, uint32_t big_cap)
+{
+    constexpr int NT = T == 64 ? 8 : (PT_Q + T - 1) / T;        // trips over the kept ids: <= 512 for a wavefront, <= PT_Q for a workgroup
+    __shared__ __attribute__((aligned(16))) uint32_t tab[TAB];
+    __shared__ __attribute__((aligned(16))) uint32_t dup[TAB / 2];
+    __shared__ uint32_t s_nc; __shared__ unsigned long long s_mx;
+    const uint32_t EMPTY = 0xFFFFFFFFu;
+    const uint32_t seg = BIG ? 0u : L.cand_cap / gridDim.x;      // possible winners go straight to this block's segment of the candidate list (BIG: the shared region behind
+    uint32_t my_nc = 0;                                           // the segments - they belong to the wavefront form's blocks)
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t n_items = BIG ? (uint64_t)min(*n_big, big_cap) : ((uint64_t)ng << lg_max);
+    // A bucket's description and its kept ids are fetched ONE ITERATION AHEAD (a wavefront works alone on its bucket: nothing else hides the two dependent
+    // round trips - description, then ids - in front of the table insert).
+    struct Item { uint32_t jpos, gl, bk, sh, nk; uint32_t id[NT]; };
+    auto fetch = [&](uint64_t it0, Item &x) {
+        x.nk = 0; x.jpos = 0; x.gl = 0; x.bk = 0; x.sh = 1;
+        if (it0 >= n_items) return;
+        const uint32_t item = BIG ? big[it0] : (uint32_t)it0;      // (n_items < 2^32: <= 65 535 genomes x 2048 buckets)
+        x.jpos = item / ng; x.gl = item - x.jpos * ng;
+        x.sh = g_sh[x.gl];
+        const uint32_t rs = lg_max - (vbits - x.sh);
+        if (x.jpos & ((1u << rs) - 1u)) return;                     // (uniform) this genome has fewer buckets
+        x.bk = x.jpos >> rs;
+        const uint2 d = desc[(uint64_t)g_boff[x.gl] + x.bk];
+        x.nk = d.y;
+        if (!BIG && x.nk > (uint32_t)(TAB / 2)) return;            // (listed for the workgroup form below: no ids needed)
+#pragma unroll
+        for (int t = 0; t < NT; t++) { const uint32_t i = t * T + threadIdx.x; x.id[t] = i < x.nk ? kept[d.x + i] : 0u; }
+    };
+    Item nx;
+    fetch(blockIdx.x, nx);
+    for (uint64_t it0 = blockIdx.x; it0 < n_items; it0 += gridDim.x) {
+        const Item cu = nx;
+        fetch(it0 + gridDim.x, nx);
+        const uint32_t jpos = cu.jpos, gl = cu.gl, bk = cu.bk, sh = cu.sh, lg = vbits - sh, nk = cu.nk;
+        if (nk == 0) continue;
+        if (!BIG && nk > (uint32_t)(TAB / 2)) {                    // too many for a wavefront's table: listed for the workgroup form
+            if (threadIdx.x == 0) { const uint32_t at = atomicAdd(n_big, 1u); if (at < big_cap) big[at] = (uint32_t)it0; else ovf[gl] = 1; }
+            continue;
+        }
+        uint64_t *qg = q + (uint64_t)gl * m;
+        __syncthreads();                                           // the previous bucket's LDS is dead
+        for (uint32_t s = threadIdx.x; s < TAB / 4; s += T) ((uint4 *)tab)[s] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+        for (uint32_t s = threadIdx.x; s < TAB / 8; s += T) ((uint4 *)dup)[s] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) { s_nc = 0; s_mx = 0; }
+        uint64_t thr_b = __hip_atomic_load(&thr[gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((jpos & ((1u << (lg_max > 4 ? lg_max - 4 : 0)) - 1u)) == 0 && jpos != 0) {      // 15 times per genome: rescan q[], publish the tighter bound
+            unsigned long long mx = 0;
+            for (uint32_t i0 = 0; i0 < m; i0 += 8 * T) {
+                unsigned long long x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const uint32_t i = i0 + u * T + threadIdx.x; x[u] = i < m ? __hip_atomic_load(&qg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) mx = x[u] > mx ? x[u] : mx;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+            __syncthreads();
+            if (lane == 0) atomicMax(&s_mx, mx);
+            __syncthreads();
+            const unsigned long long t = s_mx;
+            if (threadIdx.x == 0) atomicMin((unsigned long long *)&thr[gl], t);
+            if (t < thr_b) thr_b = t;
+        }
+        const double thr_d = __longlong_as_double((long long)thr_b);
+        __syncthreads();
+        // ---- the kept ids enter the exact table: CAS + duplicate count as in k_prob_buckets; the lane whose CAS created an entry owns it
         bool over = false;
         auto insert_id = [&](uint32_t id) -> uint32_t {
-            uint32_t s = (id * 0x85EBCA6Bu) >> 20;                  // 12 bits: PB_TAB slots (the raw id is the k-mer's last bases)
-            for (uint32_t probe = 0; probe < PB_TAB; probe++) {
+            uint32_t s = ((id * 0x85EBCA6Bu) >> 16) & (uint32_t)(TAB - 1);      // (the raw id is the k-mer's last bases)
+            for (uint32_t probe = 0; probe < (uint32_t)TAB; probe++) {
                 const uint32_t old = atomicCAS(&tab[s], EMPTY, id);
                 if (old == EMPTY) return s;
                 if (old == id) {
@@ -1973,30 +2048,21 @@ __global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restr
                     if (((before >> ((s & 1) * 16)) & 0xFFFFu) == 0xFFFFu) over = true;
                     return 0xFFFFFFFFu;
                 }
-                s = (s + 1) & (PB_TAB - 1);
+                s = (s + 1) & (uint32_t)(TAB - 1);
             }
             over = true;
             return 0xFFFFFFFFu;
         };
-        const uint32_t nq = s_ns;
-        const bool queued = nq <= (uint32_t)PT_Q;
-        uint32_t own[PT_Q / PT2_T];
-        if (queued) {
+        uint32_t own[NT];
 #pragma unroll
-            for (int t = 0; t < PT_Q / PT2_T; t++) { const uint32_t i = t * PT2_T + threadIdx.x; own[t] = i < nq ? insert_id(s_q[i]) : 0xFFFFFFFFu; }
-        } else {
-            // more than the queue holds (a loose bound over a large bucket): every id straight into the table, one rolled loop; the entries come from a table sweep
-            for (uint32_t u = 0; u < NU; u++) { uint32_t id = 0; if (key_at(u, id) && keep_b(id)) (void)insert_id(id); }
-        }
+        for (int t = 0; t < NT; t++) { const uint32_t i = t * T + threadIdx.x; own[t] = 0xFFFFFFFFu; if ((uint32_t)(t * T) < nk && i < nk) own[t] = insert_id(cu.id[t]); }
         if (over) ovf[gl] = 1;
         __syncthreads();
-        GS_PSTAMP(3);
-        // ---- the exact (value, multiplicity) pairs, as in k_prob_buckets
+        // ---- the exact (value, multiplicity) pairs
         uint32_t wloc = 0;
-        auto count_of = [&](uint32_t s) -> uint32_t { return 1u + ((dup[s >> 1] >> ((s & 1) * 16)) & 0xFFFFu); };
         auto entry = [&](uint32_t s) {
             const uint64_t v = pt_value(bk, tab[s], sh, lg);
-            const uint32_t w = count_of(s);
+            const uint32_t w = 1u + ((dup[s >> 1] >> ((s & 1) * 16)) & 0xFFFFu);
             wloc = w > wloc ? w : wloc;
             const double winv = w == 1 ? 1.0 : 1.0 / (double)w;
             const bool alive2 = !(winv > thr_d);
@@ -2009,16 +2075,17 @@ __global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restr
                 const uint64_t hb = (uint64_t)__double_as_longlong(h);
                 uint64_t *slot = qg + b;
                 if (hb <= __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    // a possible winner: listed without waiting for the atomic's answer - the claim only takes candidates whose point equals the slot's final minimum
                     (void)__hip_atomic_fetch_min((unsigned long long *)slot, (unsigned long long)hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t sp = atomicAdd(&s_nc, 1u);
-                    if (sp < (uint32_t)PB_CST) { sc_v[sp] = v; sc_h[sp] = hb; sc_b[sp] = b; }
+                    const uint32_t sp = BIG ? seg : my_nc + atomicAdd(&s_nc, 1u);
+                    if (sp < seg) { const uint32_t o = blockIdx.x * seg + sp; L.cand_v[o] = v; L.cand_h[o] = hb; L.cand_gb[o] = (uint64_t)gl * m + b; }
                     else {
                         const uint32_t pos = atomicAdd(L.n_cand, 1u);
                         if (pos < L.ovf_cap) { const uint32_t o = L.cand_cap + pos; L.cand_v[o] = v; L.cand_h[o] = hb; L.cand_gb[o] = (uint64_t)gl * m + b; }
                     }
                 }
             }
-            if (alive2) {
+            if (alive2) {                                            // may still reach a slot in pass 2 (superset: thr >= the final max q)
                 const uint32_t pos = atomicAdd(L.n_act, 1u);
                 if (pos < L.act_cap) {
                     L.akey[pos] = v; L.agl[pos] = gl; L.acnt[pos] = w;
@@ -2026,30 +2093,15 @@ __global__ __launch_bounds__(PT2_T, 6) void k_prob_tiers(const uint32_t *__restr
                 }
             }
         };
-        if (pf) { atomicAdd(&L.prof[6], (unsigned long long)nq); atomicAdd(&L.prof[7], 1ull); atomicAdd(&L.prof[8], (unsigned long long)n); }
-        if (queued) {
 #pragma unroll
-            for (int t = 0; t < PT_Q / PT2_T; t++) if (own[t] != 0xFFFFFFFFu) entry(own[t]);
-        } else { for (uint32_t s = threadIdx.x; s < PB_TAB; s += PT2_T) if (tab[s] != EMPTY) entry(s); }
+        for (int t = 0; t < NT; t++) if ((uint32_t)(t * T) < nk && own[t] != 0xFFFFFFFFu) entry(own[t]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)wloc, o); wloc = y > wloc ? y : wloc; }
         if (lane == 0 && wloc > 1 && wloc > __hip_atomic_load(&wmax[gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&wmax[gl], wloc);
         __syncthreads();
-        GS_PSTAMP(4);
-        const uint32_t nst = s_nc < (uint32_t)PB_CST ? s_nc : (uint32_t)PB_CST;
-        if (pf) atomicAdd(&L.prof[9], (unsigned long long)s_nc);
-        if (nst) {
-            if (my_nc + nst > seg) { if (threadIdx.x == 0) atomicMax(L.n_cand, 0xFFFFFFFFu); }
-            else {
-                const uint32_t cb = blockIdx.x * seg + my_nc;
-                for (uint32_t i = threadIdx.x; i < nst; i += PT2_T) { L.cand_v[cb + i] = sc_v[i]; L.cand_h[cb + i] = sc_h[i]; L.cand_gb[cb + i] = (uint64_t)gl * m + sc_b[i]; }
-                my_nc += nst;
-            }
-        }
-        GS_PSTAMP(5);
-#undef GS_PSTAMP
+        if (!BIG) { const uint32_t room = seg - my_nc, got = s_nc; my_nc += got < room ? got : room; }      // (what did not fit went to the shared region)
     }
-    if (threadIdx.x == 0) L.seg_n[blockIdx.x] = my_nc;
+    if (!BIG && threadIdx.x == 0) L.seg_n[blockIdx.x] = my_nc;
 }
 
 // one chunk of genomes [g0, g0 + ng) through the tiered form; lgs = log2(buckets) per genome (host plan). redo as run_prob_buckets.
@@ -2088,12 +2140,19 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
     boff[ng] = nbt;
     PoolBuf dinfo(c, 0), dvb(c, 2), cnt(c, 3), vals(c, 8), q(c, 9), qprev(c, 10), sig(c, 11), sigpass(c, 12), thr(c, 13), wmax(c, 14), qmax(c, 15), ctr(c, 7);
     PoolBuf cv(c, 16), chh(c, 17), cgb(c, 18), akey(c, 19), agl(c, 24), acnt(c, 25), astate(c, 26), ph(c, 27), pb(c, 37), ovf(c, 38), segn(c, 28);
+    PoolBuf kept(c, 61), desc(c, 4), big(c, 5);
     const uint32_t cand_cap = (uint32_t)std::min<uint64_t>((uint64_t)ng * m * 16 + 65536, (uint64_t)1 << 30), ovf_cap = cand_cap / 4, act_cap = 1u << 24;
+    // the list of kept ids: what the caps let through (x1 < cap as singletons) plus the false alarms of shared cells and the real repeats, with room to spare
+    uint64_t kept_want = 1u << 20;
+    for (uint32_t i = 0; i < ng; i++) kept_want += (uint64_t)((double)hk[i] * std::min(1.0, 1.5 * capd[i] + 0.05));
+    const uint32_t kept_cap = (uint32_t)std::min<uint64_t>(kept_want, 0xFFFF0000u), big_cap = 1u << 16;
+    const uint32_t pts_max = (uint32_t)c->n_cu * 32;              // blocks of the wavefront-per-bucket kernel at most (segment counts)
     if ((rc = dinfo.alloc(4 * info.size())) || (rc = dvb.alloc(8 * (size_t)ng)) || (rc = cnt.alloc((size_t)4 * nbt * parts)) || (rc = vals.alloc(4 * (size_t)T32 + 64)) ||
         (rc = q.alloc((size_t)8 * ng * m)) || (rc = qprev.alloc((size_t)8 * ng * m)) || (rc = sig.alloc((size_t)8 * ng * m)) || (rc = sigpass.alloc((size_t)8 * ng * m)) ||
         (rc = thr.alloc(8 * (size_t)ng)) || (rc = wmax.alloc(4 * (size_t)ng)) || (rc = qmax.alloc(8 * (size_t)ng)) || (rc = ctr.alloc(64)) ||
         (rc = cv.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = chh.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = cgb.alloc((size_t)8 * (cand_cap + ovf_cap))) ||
-        (rc = ovf.alloc(4 * (size_t)ng)) || (rc = segn.alloc((size_t)4 * c->n_cu * 8)) ||
+        (rc = ovf.alloc(4 * (size_t)ng)) || (rc = segn.alloc((size_t)4 * pts_max)) || (rc = kept.alloc(4 * (size_t)kept_cap + 64)) || (rc = desc.alloc(8 * (size_t)nbt)) ||
+        (rc = big.alloc(4 * (size_t)big_cap)) ||
         (rc = akey.alloc((size_t)8 * act_cap)) || (rc = agl.alloc((size_t)4 * act_cap)) || (rc = acnt.alloc((size_t)4 * act_cap)) || (rc = astate.alloc((size_t)32 * act_cap)))
         return rc;
     const uint32_t *d_sh = dinfo.as<uint32_t>(), *d_boff = d_sh + ng, *d_cap = d_boff + ng + 1;
@@ -2107,7 +2166,7 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
         GS_HIP_CHECK(hipStreamSynchronize(c->stream));               // (the host vectors above go out of use here)
     }
     GS_HIP_CHECK(hipMemsetAsync(ovf.p, 0, 4 * (size_t)ng, c->stream));
-    GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));          // [2] n_cand, [3] n_act, [4] n_active genomes
+    GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));          // [2] n_cand, [3] n_act, [4] n_active genomes, [5] kept ids, [6] big buckets
     uint32_t *ctr32 = ctr.as<uint32_t>();
     {
         ProfScope ps(c, FAM_SKETCH);
@@ -2131,23 +2190,32 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
         GS_HIP_CHECK(hipGetLastError());
         PbLists L{cv.as<uint64_t>(), chh.as<uint64_t>(), cgb.as<uint64_t>(), cand_cap, ovf_cap, ctr32 + 2, segn.as<uint32_t>(), akey.as<uint64_t>(), agl.as<uint32_t>(), acnt.as<uint32_t>(),
                   astate.as<uint64_t>(), act_cap, ctr32 + 3, nullptr};
-        DevBuf profbuf;
-        if (getenv("GS_PROB_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); L.prof = profbuf.as<unsigned long long>(); }
-        int per_cu = 3;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_prob_tiers, PT2_T, 0);
+        DevBuf profbuf; unsigned long long *prof = nullptr;
+        if (getenv("GS_PROB_PROFILE")) { if ((rc = profbuf.alloc(128))) return rc; GS_HIP_CHECK(hipMemsetAsync(profbuf.p, 0, 128, c->stream)); prof = profbuf.as<unsigned long long>(); }
         uint32_t lg_max = 0; while ((1u << lg_max) < nbmax) lg_max++;
-        const uint32_t wgs = (uint32_t)std::min<uint64_t>((uint64_t)ng << lg_max, (uint64_t)c->n_cu * std::min(std::max(per_cu, 1), 8));
-        hipLaunchKernelGGL(k_prob_tiers, dim3(wgs), dim3(PT2_T), 0, c->stream, vals.as<uint32_t>(), dvb.as<uint64_t>(), d_cap, cnt.as<uint32_t>(), parts, vbits, d_sh, d_boff, ng, lg_max,
-                           m, zone, pc, q.as<uint64_t>(), thr.as<uint64_t>(), wmax.as<uint32_t>(), L, ovf.as<uint32_t>());
-        if (L.prof) {
-            unsigned long long h[16];
-            GS_HIP_CHECK(hipMemcpyAsync(h, L.prof, 128, hipMemcpyDeviceToHost, c->stream));
+        const uint64_t n_items = (uint64_t)ng << lg_max;
+        int f_cu = 4, w_cu = 16, b_cu = 2;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&f_cu, (const void *)k_prob_tier_filter, PT2_T, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&w_cu, (const void *)k_prob_tier_points<64, 1024, false>, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_cu, (const void *)k_prob_tier_points<512, 4096, true>, 512, 0);
+        const uint32_t fwgs = (uint32_t)std::min<uint64_t>(n_items, (uint64_t)c->n_cu * std::min(std::max(f_cu, 1), 8));
+        const uint32_t pwgs = (uint32_t)std::min<uint64_t>(n_items, std::min<uint64_t>((uint64_t)c->n_cu * std::min(std::max(w_cu, 1), 32), pts_max));
+        hipLaunchKernelGGL(k_prob_tier_filter, dim3(fwgs), dim3(PT2_T), 0, c->stream, vals.as<uint32_t>(), dvb.as<uint64_t>(), d_cap, cnt.as<uint32_t>(), parts, vbits, d_sh, d_boff, ng, lg_max,
+                           pc, thr.as<uint64_t>(), kept.as<uint32_t>(), kept_cap, ctr32 + 5, desc.as<uint2>(), ovf.as<uint32_t>(), prof);
+        hipLaunchKernelGGL((k_prob_tier_points<64, 1024, false>), dim3(pwgs), dim3(64), 0, c->stream, kept.as<uint32_t>(), desc.as<uint2>(), vbits, d_sh, d_boff, ng, lg_max, m, zone, pc,
+                           q.as<uint64_t>(), thr.as<uint64_t>(), wmax.as<uint32_t>(), L, ovf.as<uint32_t>(), big.as<uint32_t>(), ctr32 + 6, big_cap);
+        hipLaunchKernelGGL((k_prob_tier_points<512, 4096, true>), dim3((uint32_t)c->n_cu * std::min(std::max(b_cu, 1), 2)), dim3(512), 0, c->stream, kept.as<uint32_t>(), desc.as<uint2>(), vbits,
+                           d_sh, d_boff, ng, lg_max, m, zone, pc, q.as<uint64_t>(), thr.as<uint64_t>(), wmax.as<uint32_t>(), L, ovf.as<uint32_t>(), big.as<uint32_t>(), ctr32 + 6, big_cap);
+        if (prof) {
+            unsigned long long h[16]; uint32_t hcn[8];
+            GS_HIP_CHECK(hipMemcpyAsync(h, prof, 128, hipMemcpyDeviceToHost, c->stream));
+            GS_HIP_CHECK(hipMemcpyAsync(hcn, ctr.p, 32, hipMemcpyDeviceToHost, c->stream));
             GS_HIP_CHECK(hipStreamSynchronize(c->stream));
             const double it = (double)std::max<unsigned long long>(h[7], 1);
-            fprintf(stderr, "[GS_PROB_PROFILE] tiers: workgroup 0 of %u (%d per CU, %u parts): %llu buckets, keys/bucket %.0f, queued %.0f, candidates %.1f | cycles per bucket: load+zero+thr %.0f, count %.0f, draw+queue %.0f, insert %.0f, entries %.0f, flush %.0f\n",
-                    wgs, per_cu, parts, h[7], h[8] / it, h[6] / it, h[9] / it, h[0] / it, h[1] / it, h[2] / it, h[3] / it, h[4] / it, h[5] / it);
+            fprintf(stderr, "[GS_PROB_PROFILE] tiers: filter workgroup 0 of %u (%d per CU, %u parts; points: %u wavefronts, %d per CU): %llu buckets, keys/bucket %.0f, kept %.0f | cycles per bucket: load+zero %.0f, count %.0f, draw+queue %.0f, write %.0f | kept ids %u of %u, big buckets %u\n",
+                    fwgs, f_cu, parts, pwgs, w_cu, h[7], h[8] / it, h[6] / it, h[0] / it, h[1] / it, h[2] / it, h[3] / it, hcn[5], kept_cap, hcn[6]);
         }
-        hipLaunchKernelGGL(k_prob_claim_list, dim3(wgs + 1), dim3(256), 0, c->stream, cv.as<uint64_t>(), chh.as<uint64_t>(), cgb.as<uint64_t>(), segn.as<uint32_t>(), cand_cap / wgs, wgs,
+        hipLaunchKernelGGL(k_prob_claim_list, dim3(pwgs + 1), dim3(256), 0, c->stream, cv.as<uint64_t>(), chh.as<uint64_t>(), cgb.as<uint64_t>(), segn.as<uint32_t>(), cand_cap / pwgs, pwgs,
                            cand_cap, ctr32 + 2, ovf_cap, q.as<uint64_t>(), sigpass.as<uint64_t>());
         hipLaunchKernelGGL(k_prob_fold, dim3(ng), dim3(256), 0, c->stream, m, 1u, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), wmax.as<uint32_t>(),
                            qmax.as<double>(), ctr32 + 4);
