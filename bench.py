@@ -763,6 +763,87 @@ def c5_distance_leg(args, ctx, lib, chk, O):
             os.environ["GS_DIST_MODE"] = prev_mode
 
 
+def prob_request_leg(args, ctx, lib, chk, O, d_qseq, gbytes, d_rs, d_rl, d_goff):
+    """`tohnsw` + `request` with --algo prob (ProbMinHash3a, the first sketcher north_star names): k = 21, s = 18000 -> u64 signatures (the type dispatch of
+    /root/reference/src/dna/dnarequest.rs:417-455; sketcher /root/reference/src/dna/dnasketch.rs:499-518), 144 kB rows, 8-byte-key match-join. `--prob-db-genomes`
+    synthetic genomes of the headline's families are generated, sketched and inserted in the collector's chunks; the resident query genomes of the first set are
+    sketched and searched like a headline step (wall clock around sketch + search, inputs resident). A query sample is checked against the oracle: prob sketch of
+    two query genomes, ids / distances / evaluation counts of 16 queries on the exported graph."""
+    import ctypes as C
+    import gsearch_amd as G
+    k, m, L, qps, knbn, ef = args.kmer, args.sketch_size, args.genome_len, args.queries_per_step, args.knbn, args.ef_search
+    N = args.prob_db_genomes
+    n_roots = max(args.db_genomes // args.per_root, 1)            # the headline's families: the resident queries are their mutants
+    prm = G.SeqSketcherParams(k, m, "prob")
+    assert prm.sig_dtype() == np.uint64
+    chunk = min(args.build_chunk, N)
+    d_seq = ctx.alloc(chunk * gbytes + 64)
+    d_sig = ctx.alloc(max(chunk, qps) * m * 8)
+    hp = G.Hnsw.new(args.max_nb_conn, max(N, 1024), 16, args.ef_construction, G.DistHamming(ctx), dtype=np.uint64, seed=args.seed, insert_batch=256, ctx=ctx)
+    hp.modify_level_scale(args.scale_modify); hp.set_extend_candidates(True); hp.set_keeping_pruned(False)
+    hp._ensure(m)
+    try:
+        t_b = time.perf_counter(); sk_s = 0.0
+        for g0 in range(0, N, chunk):
+            n = min(chunk, N - g0)
+            chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, g0, n, L, n_roots, 0.001, 0.08, d_seq)); ctx.sync()
+            t0 = time.perf_counter()
+            chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, n * gbytes + 64, d_rs, d_rl, n, d_goff, n, d_sig)); ctx.sync()
+            sk_s += time.perf_counter() - t0
+            chk(lib.gs_index_parallel_insert_dev(hp.h, d_sig, n))
+        ctx.sync()
+        build_s = time.perf_counter() - t_b
+        ctx.free(d_seq); d_seq = None
+        d_ids, d_dist, d_cnt, d_ev = ctx.alloc(8 * qps * knbn), ctx.alloc(4 * qps * knbn), ctx.alloc(4 * qps), ctx.alloc(8 * qps)
+        steps = []
+        for rep in range(3):                                        # rep 0 warms up (scratch, count matrix)
+            ctx.profile(True)
+            for fam in range(4):
+                ctx.profile_read(fam, reset=True)
+            hp.search_stats(reset=True)
+            ctx.sync(); t0 = time.perf_counter()
+            chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_qseq, qps * gbytes + 64, d_rs, d_rl, qps, d_goff, qps, d_sig)); ctx.sync()
+            t1 = time.perf_counter()
+            chk(lib.gs_index_parallel_search_dev(hp.h, d_sig, qps, knbn, ef, d_ids, d_dist, d_cnt, d_ev)); ctx.sync()
+            t2 = time.perf_counter()
+            srch, prod, sk = ctx.profile_read(2, reset=True), ctx.profile_read(1, reset=True), ctx.profile_read(0, reset=True)
+            ctx.profile(False)
+            st = hp.search_stats(reset=True)
+            if rep:
+                steps.append({"ms": (t2 - t0) * 1e3, "sketch_ms": (t1 - t0) * 1e3, "search_ms": (t2 - t1) * 1e3, "count_matrix_kernels_ms": prod[0], "count_matrix_launches": prod[1],
+                              "traversal_kernel_ms": srch[0], "join_atomics": int(st.get("join_atomics", 0)), "pops_per_query": st.get("pops", 0) / qps})
+        best = min(steps, key=lambda x: x["ms"])
+        ns = 16
+        ids = ctx.download(d_ids, (qps, knbn), np.uint64); dist = ctx.download(d_dist, (qps, knbn), np.float32); ev = ctx.download(d_ev, (qps,), np.uint64)
+        qsig = ctx.download(d_sig, (qps, m), np.uint64)[:ns].copy()
+        for p_ in (d_ids, d_dist, d_cnt, d_ev):
+            ctx.free(p_)
+        # oracle: prob sketches of two query genomes, the search of 16 queries on the exported graph
+        qb = ctx.download(d_qseq, (2, gbytes), np.uint8)
+        op = O.params(k, m, "prob")
+        sk_ok = all(np.array_equal(O.sketch_batch(op, np.concatenate([qb[i].reshape(-1), np.zeros(16, np.uint8)]), np.zeros(1, np.uint64), np.array([L], np.uint64),
+                                                  np.array([0, 1], np.uint64))[0], qsig[i]) for i in range(2))
+        oix = O.Index(np.uint64, m, args.max_nb_conn, args.ef_construction, scale_modify=args.scale_modify, seed=args.seed)
+        oix.import_graph(hp.get_data(), hp.export_graph(), view=True)
+        oids, odist, _, oev = oix.parallel_search(qsig, knbn, ef, nthreads=min(host_cpu_budget()[1], ns))
+        same = bool(np.array_equal(oids, ids[:ns]) and np.array_equal(odist.view(np.uint32), dist[:ns].view(np.uint32)) and np.array_equal(oev, ev[:ns]))
+        del oix
+        return {"workload": "tohnsw + request with --algo prob: %d genomes x %.1f Mbp (k=%d s=%d ProbMinHash3a, u64 signatures, 144 kB rows) in an HNSW (M=%d efc=%d), then %d resident "
+                            "query genomes sketched (prob) and searched (n=%d ef=%d) per step" % (N, L / 1e6, k, m, args.max_nb_conn, args.ef_construction, qps, knbn, ef),
+                "db_genomes": N, "build_seconds": build_s, "db_sketch_seconds": sk_s, "db_sketch_kmers_per_sec": float(L - k + 1) * N / sk_s,
+                "ms_per_%d_queries" % qps: best["ms"], "genomes_per_sec": qps / (best["ms"] * 1e-3), "steps": steps,
+                "query_sketch_kmers_per_sec": float(L - k + 1) * qps / (best["sketch_ms"] * 1e-3),
+                "strategy": "dense: match-join (8-byte keys) + look-up traversal" if best["pops_per_query"] > 0 else "row gather",
+                "evals_per_query": float(ev.mean()), "median_nearest_distance": float(np.median(dist[:, 0])),
+                "prob_sketch_bit_exact_vs_oracle_2_query_genomes": bool(sk_ok), "ids_distances_evals_equal_oracle_%d_queries" % ns: same}
+    finally:
+        hp.close()
+        if d_seq:
+            ctx.free(d_seq)
+        ctx.free(d_sig)
+        chk(lib.gs_ctx_release_scratch(ctx.h))
+
+
 def extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff):
     """Driver-visible numbers for the rest of BASELINE's configs and of DESIGN 4's rate table, measured AFTER the timed region in the same
     run (rank 0, N = 1; each leg a few seconds): other sketchers at (k=21, s=18000) on the resident 5 Mbp query genomes, configs[4]
@@ -795,6 +876,12 @@ def extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff):
         ctx.free(d_sig)
         chk(lib.gs_ctx_release_scratch(ctx.h))                  # the sketchers' scratch (ProbMinHash: two copies of a chunk's k-mers) is not needed by the next leg
     out["other_sketchers_k21_s18000"] = rates
+    # ---- (1b) `request` on ProbMinHash3a signatures at size
+    if args.prob_db_genomes > 0:
+        try:
+            out["request_prob"] = prob_request_leg(args, ctx, lib, chk, O, d_qseq, gbytes, d_rs, d_rl, d_goff)
+        except Exception as e:                                      # noqa: BLE001 - the other legs must survive
+            out["request_prob"] = {"error": repr(e)}
     # ---- (2) BASELINE configs[4]: AA k=7 s=24000 super2 -> u64 signatures, all 50 000 proteomes (75 GB of residues generated in HBM, gs_synth_aa_dev)
     kaa, maa, Laa, NP = 7, 24000, 1_500_000, args.c5_proteomes
     pb = (Laa + 7) // 8 * 8
@@ -1005,6 +1092,7 @@ def main():
     ap.add_argument("--build-chunk", type=int, default=8192)
     ap.add_argument("--c5-proteomes", type=int, default=50000, help="proteomes of the configs[4] sketch leg (BASELINE: 50k)")
     ap.add_argument("--c5-rows", type=int, default=50000, help="index rows of the configs[4] distance leg")
+    ap.add_argument("--prob-db-genomes", type=int, default=100000, help="database genomes of the `request_prob` leg: tohnsw + request on ProbMinHash3a (u64) signatures (0 = skip)")
     ap.add_argument("--redundant-roots", type=int, default=30, help="families the queries of the `request_redundant` side leg are drawn from (0 = skip the leg)")
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     ap.add_argument("--verbose", action="store_true")

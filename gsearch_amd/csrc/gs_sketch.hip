@@ -1710,6 +1710,16 @@ __device__ __forceinline__ void pt_walk_dna(uint64_t w, uint64_t fwd, uint64_t r
         else pkr[j] = 0xFFFFFFFFu;
     }
 }
+// inclusive maximum over the lanes 0 .. l of a wavefront (DPP: shifts inside the rows of 16, then the row totals broadcast to the rows behind)
+__device__ __forceinline__ uint32_t wave_incl_max_scan(uint32_t v)
+{
+#define GS_DPP_MAX(ctrl, rows) do { const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false); v = y > v ? y : v; } while (0)
+    GS_DPP_MAX(0x111, 0xF); GS_DPP_MAX(0x112, 0xF); GS_DPP_MAX(0x114, 0xF); GS_DPP_MAX(0x118, 0xF);      // row_shr:1 / 2 / 4 / 8
+    GS_DPP_MAX(0x142, 0xA);                                                                            // row_bcast:15 -> rows 1 and 3
+    GS_DPP_MAX(0x143, 0xC);                                                                            // row_bcast:31 -> rows 2 and 3
+#undef GS_DPP_MAX
+    return v;
+}
 __global__ __launch_bounds__(PT_T) void k_prob_part1_dna(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len,
                                                          const uint64_t *__restrict__ rec_upre, const uint64_t *__restrict__ genome_rec_off, const uint64_t *__restrict__ gen_units,
                                                          uint64_t g0, uint32_t kq, uint32_t vbits, const uint32_t *__restrict__ g_sh, const uint32_t *__restrict__ g_boff,
@@ -1718,6 +1728,7 @@ __global__ __launch_bounds__(PT_T) void k_prob_part1_dna(const uint8_t *__restri
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_pt[];
     __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_mark[PT_T];                             // a 64-word mark row per wavefront (the copy-out below)
     const uint32_t gl = blockIdx.y, part = blockIdx.x;
     const uint64_t g = g0 + gl;
     const uint32_t sh = g_sh[gl], NB = 1u << (vbits - sh), cap = g_cap[gl];
@@ -1796,35 +1807,39 @@ __global__ __launch_bounds__(PT_T) void k_prob_part1_dna(const uint8_t *__restri
 #pragma unroll
         for (int j = 0; j < 32; j++) if (pkr[j] != 0xFFFFFFFFu) s_ids[s_start[pkr[j] >> 16] + (pkr[j] & 0xFFFFu)] = idr[j];
         __syncthreads();
-        // to this part's slices: a wavefront takes 64 buckets at a time - their ids are one contiguous stretch of s_ids - and every lane finds the bucket of its
-        // position by a 6-step search over the 64 starts (four positions per lane in flight: one run per trip of a half wavefront was a chain of three LDS round
-        // trips per ~16 ids, a quarter of the kernel). Lanes on consecutive positions of a bucket store to consecutive addresses.
-        for (uint32_t b0 = wv * 64; b0 < NB; b0 += (PT_T / 64) * 64) {
-            const uint32_t nbk = NB - b0 < 64u ? NB - b0 : 64u;
-            const uint32_t p0 = s_start[b0], p1 = s_start[b0 + nbk];
-            for (uint32_t pb = p0; pb < p1; pb += 256) {
-                uint32_t id4[4], bk4[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t pos = pb + q * 64 + lane;
-                    uint32_t lo = 0, hi = nbk;                      // last bucket of the 64 whose start is <= pos
-                    if (pos < p1) {
-                        id4[q] = s_ids[pos];
-#pragma unroll
-                        for (int st = 0; st < 6; st++) { const uint32_t mid = (lo + hi) >> 1; if (hi - lo > 1) { if (s_start[b0 + mid] <= pos) lo = mid; else hi = mid; } }
-                    }
-                    bk4[q] = b0 + lo;
+        // to this part's slices: a wavefront takes 64 buckets at a time - their ids are one contiguous stretch of s_ids, walked in windows of 64 positions. The
+        // buckets that START inside a window leave their number at their start position (a 64-word mark row per wavefront); an inclusive max-scan over the lanes
+        // (the marks increase along the window) tells every position its bucket, the bucket's destination comes from its lane by one permute. ~25 wave
+        // instructions per 64 ids (a 6-step search per id over the 64 starts was ~45, a half wavefront per run a chain of LDS round trips per ~16 ids).
+        {
+            uint32_t *mk = s_mark + wv * 64;
+            for (uint32_t b0 = wv * 64; b0 < NB; b0 += (PT_T / 64) * 64) {
+                const uint32_t nbk = NB - b0 < 64u ? NB - b0 : 64u;
+                const uint32_t st = lane < nbk ? s_start[b0 + lane] : 0u, en = lane < nbk ? s_start[b0 + lane + 1] : 0u, sc = lane < nbk ? s_cur[b0 + lane] : 0u;
+                const uint32_t nb = en - st;
+                const bool fits = sc + nb <= cap;
+                if (nb && !fits) over = true;
+                const uint64_t okb = __ballot(fits);
+                const uint32_t dbase = (uint32_t)(((uint64_t)(b0 + lane) * parts + part) * cap) + sc - st;      // destination of position pos = dbase + pos (mod 2^32)
+                const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st), p1 = s_start[b0 + nbk];
+                const uint64_t nz = __ballot(nb != 0);
+                uint32_t carry = nz ? (uint32_t)__builtin_ctzll(nz) : 0u;                                      // the bucket (lane) that holds position p0
+                for (uint32_t pw = p0; pw < p1; pw += 64) {
+                    mk[lane] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (nb && st >= pw && st - pw < 64u) mk[st - pw] = lane + 1;
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t v = mk[lane];
+                    __builtin_amdgcn_wave_barrier();
+                    v = wave_incl_max_scan(v);
+                    v = v ? v - 1 : carry;
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+                    const uint32_t pos = pw + lane;
+                    const uint32_t d = (uint32_t)__shfl((int)dbase, (int)v);
+                    if (pos < p1 && ((okb >> v) & 1ull)) out[d + pos] = s_ids[pos];
                 }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t pos = pb + q * 64 + lane;
-                    if (pos < p1) {
-                        const uint32_t b = bk4[q], at = s_cur[b] + (pos - s_start[b]);
-                        if (at < cap) out[((uint64_t)b * parts + part) * cap + at] = id4[q]; else over = true;
-                    }
-                }
+                if (lane < nbk) s_cur[b0 + lane] = fits ? sc + nb : cap;
             }
-            if (lane < nbk) { const uint32_t b = b0 + lane; s_cur[b] = std::min(s_cur[b] + s_cnt[b], cap); }
         }
         __syncthreads();
         cur = nxt;
@@ -2117,9 +2132,14 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
     const uint32_t vbits = aa ? 5 * k : 2 * k;
     uint64_t maxk = 0; uint32_t nbmax = 1, nbt = 0;
     for (uint32_t i = 0; i < ng; i++) maxk = std::max(maxk, hk[i]);
-    // parts per genome (one for the chunk): ~8 tiles of 32 768 k-mers each at least, a power of two (the bucket kernel deals slices to its eight wavefronts)
+    // parts per genome (one for the chunk), a power of two (the filter kernel deals slices to its eight wavefronts): four where the chunk has the genomes to fill the
+    // device with them (fewer, longer slices: 1.11e11 k-mers/s at 4 against 0.99e11 at 16 over 256 x 5 Mbp), more for a handful of genomes - down to 8 tiles per part
     uint32_t parts = 1;
-    { const uint64_t tiles = maxk / ((uint64_t)PT_T * 32) + 1; while (parts < 32 && (uint64_t)parts * 2 * 8 <= tiles) parts *= 2; }
+    {
+        const uint64_t tiles = maxk / ((uint64_t)PT_T * 32) + 1;
+        while (parts < 4 && (uint64_t)parts * 2 * 8 <= tiles) parts *= 2;
+        while (parts < 32 && (uint64_t)parts * 2 * 8 <= tiles && (uint64_t)ng * parts < 2 * (uint64_t)c->n_cu) parts *= 2;
+    }
     if (getenv("GS_PROB_PARTS")) { parts = 1; const uint32_t want = (uint32_t)atoi(getenv("GS_PROB_PARTS")); while (parts * 2 <= want && parts < 32) parts *= 2; }
     // per genome: shift, flat bucket offset, slice capacity (mean + 5 sigma of a slice's Poisson-like fill), offset of its slices (in 4-byte ids)
     std::vector<uint32_t> info(3 * (size_t)ng + 1); std::vector<uint64_t> vbase(ng); std::vector<uint64_t> capbits(ng); std::vector<double> capd(ng);

@@ -120,6 +120,74 @@ def test_config2_request_300k(gpu_ctx, monkeypatch):
     assert np.array_equal(od, bd[:4])
 
 
+def test_prob_tohnsw_then_request_100k(gpu_ctx):
+    """`tohnsw` + `request` with --algo prob at k = 21, s = 18000 (the first sketcher north_star names; u64 `Sig` - the type dispatch of
+    /root/reference/src/dna/dnarequest.rs:417-455, sketcher of dnasketch.rs:499-518): 100 000 synthetic genomes of 1.2 Mbp (1000 families) are
+    sketched by the tiered ProbMinHash3a form and inserted in the collector's chunks, 2000 fresh mutants are sketched and searched (n = 50,
+    ef = 5000, default strategy: 8-byte-key match-join + look-up traversal at this size). Signatures of a sample of database and query genomes
+    == oracle sketches; ids, distances, answer counts and evaluation counts of a query sample == the oracle searching the exported graph."""
+    import ctypes as C
+    import gsearch_amd as G
+    ctx, lib, chk = gpu_ctx, gpu_ctx.L, G._lib.check
+    n, L, k, m, M, efc, knbn, ef, nq, n_roots = 100_000, 1_200_000, 21, 18000, 128, 1600, 50, 5000, 2000, 1000
+    words = (L + 31) // 32
+    gbytes = words * 8
+    chunk = 8192
+    prm = G.SeqSketcherParams(k, m, "prob")
+    assert prm.sig_dtype() == np.uint64
+    nrec = max(chunk, nq)
+    d_seq = ctx.alloc(nrec * gbytes + 64)
+    d_sig = ctx.alloc(nrec * m * 8)
+    d_rs, d_rl, d_go = ctx.alloc(8 * nrec), ctx.alloc(8 * nrec), ctx.alloc(8 * (nrec + 1))
+    ctx.upload(d_rs, np.arange(nrec, dtype=np.uint64) * np.uint64(words * 32)); ctx.upload(d_rl, np.full(nrec, L, np.uint64)); ctx.upload(d_go, np.arange(nrec + 1, dtype=np.uint64))
+    hn = None
+    try:
+        hn = G.Hnsw.new(M, n, 16, efc, G.DistHamming(ctx), dtype=np.uint64, seed=17, insert_batch=256, ctx=ctx)
+        hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+        hn._ensure(m)
+        db_samples = {}
+        for g0 in range(0, n, chunk):
+            nb = min(chunk, n - g0)
+            chk(lib.gs_synth_dna_family_dev(ctx.h, 4321, g0, nb, L, n_roots, 0.001, 0.08, d_seq))
+            chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, nb * gbytes + 64, d_rs, d_rl, nb, d_go, nb, d_sig))
+            if g0 in (0, 49152):                                  # a database genome of the first and of a middle chunk, for the oracle
+                db_samples[g0] = (ctx.download(d_seq, (1, gbytes), np.uint8).copy(), ctx.download(d_sig, (1, m), np.uint64).copy())
+            chk(lib.gs_index_parallel_insert_dev(hn.h, d_sig, nb))
+        assert hn.get_nb_point() == n
+        chk(lib.gs_synth_dna_family_dev(ctx.h, 4321, 1_000_000_000, nq, L, n_roots, 0.001, 0.08, d_seq))
+        chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, nq * gbytes + 64, d_rs, d_rl, nq, d_go, nq, d_sig))
+        q = ctx.download(d_sig, (nq, m), np.uint64)
+        qseq = ctx.download(d_seq, (2, gbytes), np.uint8).copy()
+        ids, dist, cnt, ev = hn.search_arrays(q, knbn, ef)
+        st = hn.search_stats(reset=True)
+        g = hn.export_graph()
+        db = hn.get_data()
+    finally:
+        if hn is not None:
+            hn.close()
+        for p in (d_seq, d_sig, d_rs, d_rl, d_go):
+            ctx.free(p)
+        ctx.release_scratch()
+    # sketches: two database genomes and two query genomes against the oracle
+    op = O.params(k, m, "prob")
+    one = lambda b: O.sketch_batch(op, np.concatenate([b.reshape(-1), np.zeros(16, np.uint8)]), np.zeros(1, np.uint64), np.array([L], np.uint64), np.array([0, 1], np.uint64))[0]
+    for g0, (sq, sg) in db_samples.items():
+        assert np.array_equal(one(sq[0]), sg[0]), g0
+        assert np.array_equal(db[g0], sg[0])
+    for i in range(2):
+        assert np.array_equal(one(qseq[i]), q[i]), i
+    assert st["pops"] > 0                                       # the default strategy at this size is the dense one (8-byte-key join + look-up traversal)
+    ns = 24
+    oix = O.Index(np.uint64, m, M, efc, scale_modify=0.25, seed=17)
+    oix.import_graph(db, g, view=True)
+    want = oix.parallel_search(q[:ns], knbn, ef, nthreads=os.cpu_count())
+    for name, a, b in zip(("ids", "distances", "counts", "evaluations"), (ids, dist, cnt, ev), want):
+        assert np.array_equal(_bits(a[:ns]), _bits(b)), name
+    assert (cnt == knbn).all() and (ev >= ef).all()
+    # the queries are mutants of the database's families: their nearest neighbours are real relatives, not the chance level (d = 1 - J well below 0.99)
+    assert float(np.median(dist[:, 0])) < 0.9
+
+
 @pytest.mark.parametrize("n,placement", [(700_000, "lds bitmap, one workgroup per CU"), (1_250_000, "split bitmap"), (1_250_000, "global bitmap")])
 def test_dense_search_on_very_large_graphs(gpu_ctx, monkeypatch, n, placement):
     """the dense traversal's visited-bitmap placements beyond the sizes the other tests reach: up to ~1.08 M nodes the bitmap stays in LDS (one

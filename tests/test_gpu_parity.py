@@ -435,6 +435,49 @@ def test_sketch_prob_bucketed_form_hands_flagged_genomes_to_the_sorted_form(gpu_
     assert np.array_equal(got, ref), np.nonzero((got != ref).any(axis=1))[0].tolist()
 
 
+@pytest.mark.parametrize("mode", ["default", "cap_fails", "two_walk"])
+def test_sketch_prob_tiered_form_and_its_exact_fallback(gpu_ctx, monkeypatch, capfd, mode):
+    """ProbMinHash3a, tiered form (round 6: value-level first-draw filter under a speculative cap, count-min bounds of the multiplicity, one-pass
+    partition into per-part slices). Genomes large enough for it at k = 21 (2048 buckets of >= 256 k-mers), with what stresses each mechanism:
+    a 5 kb repeat in 50 copies (real multiplicities far above what the count-min cells of singletons hold: the repeats must enter the exact table
+    with w = 50, and survive into pass 2), a quarter of a genome twice (w = 2 everywhere in it), a poly-A run and four k-mers 40 000 times each
+    (one slice / one count-min cell / the table overflow: the genome is flagged on the device and redone by the bucketed, then the sorted form),
+    multi-record genomes and a small genome between them. `cap_fails`: GS_PROB_CAP_C = -6 makes the speculative cap ~400x too tight, the check
+    max_b q[b] <= cap fails for EVERY genome and all of them take the fallback (the stderr trace says so). `two_walk`: the amino-acid form of the
+    partition kernel on DNA. Bit-exact against the oracle in every mode."""
+    import gsearch_amd as G
+    if mode == "cap_fails":
+        monkeypatch.setenv("GS_PROB_CAP_C", "-6")
+    if mode == "two_walk":
+        monkeypatch.setenv("GS_PROB_TWOWALK", "1")
+    monkeypatch.setenv("GS_PROB_VERBOSE", "1")
+    rng = np.random.default_rng(606)
+    k, m = 21, 1000
+    base = [H.dna_ascii(H.rand_dna(rng, n)) for n in (760_000, 640_000, 700_000)]
+    rep = base[0][1000:6000]
+    genomes = [
+        [base[0]],
+        [base[1][:300_000] + rep * 50 + base[1][300_000:]],                       # the 50-copy 5 kb repeat
+        [base[2] + base[2][: len(base[2]) // 4]],                                 # a quarter of the k-mers twice
+        [base[0][:200_000], b"ACGTNN", base[1][1000:420_000], b"", base[2][5000:150_000].lower()],      # records, N, lower case
+        [base[1][:30_000]],                                                       # small: sorted form
+        [base[2][:350_000] + b"A" * 90_000 + base[2][350_000:]],                  # poly-A: one k-mer 89 980 times
+        [b"ACGT" * 40_000 + base[0][:600_000]],                                   # four k-mers 40 000 times each
+        [base[1]],
+    ]
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "prob", "dna"))
+    got = sk.sketch_genomes(genomes)
+    err = capfd.readouterr().err
+    ref = _oracle_sketch(k, m, "prob", genomes, "dna")
+    assert got.dtype == ref.dtype
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, (mode, bad.tolist())
+    flagged = "tiered form flagged genomes" in err
+    assert flagged, err[-500:]                                  # (default / two_walk: the poly-A and the 4-k-mer genome; cap_fails: every genome)
+    if mode == "cap_fails":
+        assert "[0," in err
+
+
 def test_index_dump_and_reload(gpu_ctx, tmp_path):
     """file_dump / load round trip (own format): identical graph, data and answers; `add` continues on the reloaded index"""
     import gsearch_amd as G
