@@ -518,6 +518,13 @@ def run_request(args, D):
                 out["extra_legs"] = extra_legs(args, ctx, lib, chk, d_qseq, gbytes, words, d_rs, d_rl, d_goff)
             except Exception as e:                              # the headline line must survive a failing side leg
                 out["extra_legs"] = {"error": repr(e)}
+            if args.skew_alpha > 0 and not args.no_cpu_baseline:
+                try:                                            # last: it needs the memory of the headline index
+                    hn.close(); ctx.free(d_qseq); ctx.free(d_qsig)
+                    chk(lib.gs_ctx_release_scratch(ctx.h))
+                    out["request_skewed"] = skewed_leg(args, ctx, lib, chk, d_rs, d_rl, d_goff, gbytes, out["ms_per_step"])
+                except Exception as e:                          # noqa: BLE001
+                    out["request_skewed"] = {"error": repr(e)}
         print(json.dumps(out))
 
 
@@ -1067,6 +1074,100 @@ def redundant_leg(args, ctx, hn, lib, chk, torch, sketch_dev, d_rs, d_rl, d_goff
         ctx.free(d_seq); ctx.free(d_sig)
 
 
+def skewed_leg(args, ctx, lib, chk, d_rs, d_rl, d_goff, gbytes, headline_ms):
+    """`request` against a database with SKEWED family sizes (the regime of NCBI / GTDB prokaryotes, /root/reference/README.md:134): the headline's
+    parameters, but genome g belongs to family floor(n_roots u^3.5) - the largest family holds ~10 % of the database (>= 30 000 of 300 000), the sizes fall off as a power
+    law - and the 10 000 queries of a step are fresh mutants drawn from the same law (~1000 of them isolates of the largest family). Runs LAST, after the headline index has
+    been closed (two 300 k indexes with their pair caches do not fit). Timed like a headline step (wall clock around sketch + search, inputs resident); a 16-query sample
+    against the oracle on the exported graph; the forced dense strategy and a row-streaming sub-batch beside `auto`."""
+    import ctypes as C
+    import gsearch_amd as G
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    k, m, L, qps, knbn, ef, N = args.kmer, args.sketch_size, args.genome_len, args.queries_per_step, args.knbn, args.ef_search, args.db_genomes
+    n_roots, alpha = max(N // args.per_root, 1), args.skew_alpha
+    prm = G.SeqSketcherParams(k, m, "optdens")
+    hs = G.Hnsw.new(args.max_nb_conn, 1_500_000, 16, args.ef_construction, G.DistHamming(ctx), dtype=np.float32, seed=args.seed, insert_batch=256, ctx=ctx)
+    hs.modify_level_scale(args.scale_modify); hs.set_extend_candidates(True); hs.set_keeping_pruned(False)
+    hs._ensure(m)
+    chunk = min(args.build_chunk, N)
+    d_seq = ctx.alloc(max(chunk, qps) * gbytes + 64)
+    d_sig = ctx.alloc(max(chunk, qps) * m * 4)
+    bufs = []
+    try:
+        t_b = time.perf_counter()
+        for g0 in range(0, N, chunk):
+            n = min(chunk, N - g0)
+            chk(lib.gs_synth_dna_family_skew_dev(ctx.h, args.seed + 1, g0, n, L, n_roots, 0.001, 0.08, alpha, d_seq))
+            chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, n * gbytes + 64, d_rs, d_rl, n, d_goff, n, d_sig))
+            chk(lib.gs_index_parallel_insert_dev(hs.h, d_sig, n))
+        ctx.sync()
+        build_s = time.perf_counter() - t_b
+        d_ids, d_dist, d_cnt, d_ev = ctx.alloc(8 * qps * knbn), ctx.alloc(4 * qps * knbn), ctx.alloc(4 * qps), ctx.alloc(8 * qps)
+        bufs = [d_ids, d_dist, d_cnt, d_ev]
+        res = {}
+        for mode in ("auto", "dense"):
+            prev = os.environ.get("GS_DIST_MODE")
+            if mode == "dense":
+                os.environ["GS_DIST_MODE"] = "dense"
+            steps = []
+            for i in range(3):                                          # step 0 warms up; every step has its own query genomes
+                chk(lib.gs_synth_dna_family_skew_dev(ctx.h, args.seed + 1, 3_000_000_000 + i * qps, qps, L, n_roots, 0.001, 0.08, alpha, d_seq)); ctx.sync()
+                ctx.profile(True)
+                for fam in range(4):
+                    ctx.profile_read(fam, reset=True)
+                hs.search_stats(reset=True)
+                t0 = time.perf_counter()
+                chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, qps * gbytes + 64, d_rs, d_rl, qps, d_goff, qps, d_sig))
+                chk(lib.gs_index_parallel_search_dev(hs.h, d_sig, qps, knbn, ef, d_ids, d_dist, d_cnt, d_ev)); ctx.sync()
+                dt = time.perf_counter() - t0
+                srch, prod, sk = ctx.profile_read(2, reset=True), ctx.profile_read(1, reset=True), ctx.profile_read(0, reset=True)
+                ctx.profile(False)
+                st = hs.search_stats(reset=True)
+                if i:
+                    steps.append({"ms": dt * 1e3, "sketch_ms": sk[0], "producer_ms": prod[0], "producer_launches": prod[1], "traversal_ms": srch[0],
+                                  "join_atomics": int(st.get("join_atomics", 0)), "pops_per_query": st.get("pops", 0) / qps})
+            if prev is None:
+                os.environ.pop("GS_DIST_MODE", None)
+            else:
+                os.environ["GS_DIST_MODE"] = prev
+            res[mode] = min(steps, key=lambda x: x["ms"])
+            if mode == "auto":
+                ids = ctx.download(d_ids, (qps, knbn), np.uint64); dist = ctx.download(d_dist, (qps, knbn), np.float32); ev = ctx.download(d_ev, (qps,), np.uint64)
+                qsig = ctx.download(d_sig, (qps, m), np.float32)[:16].copy()
+        # row streaming on the first 128 queries of the last step's batch (the whole batch would take minutes)
+        ng = min(128, qps)
+        os.environ["GS_DIST_MODE"] = "gather"
+        ctx.sync(); t0 = time.perf_counter()
+        chk(lib.gs_index_parallel_search_dev(hs.h, d_sig, ng, knbn, ef, d_ids, d_dist, d_cnt, d_ev)); ctx.sync()
+        g_dt = time.perf_counter() - t0
+        os.environ.pop("GS_DIST_MODE", None)
+        same_g = bool(np.array_equal(ctx.download(d_ids, (ng, knbn), np.uint64), ids[:ng]) and np.array_equal(ctx.download(d_ev, (ng,), np.uint64), ev[:ng]))
+        # family sizes as the generator deals them (host twin of synth_root)
+        with np.errstate(over="ignore"):
+            r = np.arange(N, dtype=np.uint64)
+            u = (splitmix_mix(np.uint64(((args.seed + 1) * 31) & MASK64) + r * np.uint64(0xA24BAED4963EE407) + np.uint64(3)) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        sizes = np.bincount(np.minimum((n_roots * u ** alpha).astype(np.int64), n_roots - 1), minlength=n_roots)
+        oix = O.Index(np.float32, m, args.max_nb_conn, args.ef_construction, scale_modify=args.scale_modify, seed=args.seed)
+        oix.import_graph(hs.get_data(), hs.export_graph(), view=True)
+        oids, odist, _, oev = oix.parallel_search(qsig, knbn, ef, nthreads=min(host_cpu_budget()[1], 16))
+        same = bool(np.array_equal(oids, ids[:16]) and np.array_equal(odist.view(np.uint32), dist[:16].view(np.uint32)) and np.array_equal(oev, ev[:16]))
+        del oix
+        best_forced = min(res["dense"]["ms"], g_dt * 1e3 / ng * qps)
+        return {"workload": "request, skewed database: %d genomes x %.1f Mbp in %d families of power-law sizes (family = floor(n u^%.1f): largest %d genomes, median %d), %d query genomes "
+                            "per step drawn from the same law" % (N, L / 1e6, n_roots, alpha, int(sizes.max()), int(np.median(sizes)), qps),
+                "largest_family": int(sizes.max()), "families_with_one_member_or_none": int((sizes <= 1).sum()), "build_seconds": build_s,
+                "ms_per_step": res["auto"]["ms"], "genomes_per_sec": qps / (res["auto"]["ms"] * 1e-3), "ms_per_step_over_headline": res["auto"]["ms"] / headline_ms,
+                "auto": res["auto"], "forced_dense": res["dense"], "row_streaming_first_%d_queries_ms" % ng: g_dt * 1e3, "row_streaming_ms_per_step_extrapolated": g_dt * 1e3 / ng * qps,
+                "auto_over_better_forced_strategy": res["auto"]["ms"] / best_forced, "row_streaming_same_ids_and_evals": same_g,
+                "evals_per_query": float(ev.mean()), "ids_distances_evals_equal_oracle_16_queries": same}
+    finally:
+        hs.close()
+        for p_ in [d_seq, d_sig] + bufs:
+            ctx.free(p_)
+        chk(lib.gs_ctx_release_scratch(ctx.h))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1093,6 +1194,7 @@ def main():
     ap.add_argument("--c5-proteomes", type=int, default=50000, help="proteomes of the configs[4] sketch leg (BASELINE: 50k)")
     ap.add_argument("--c5-rows", type=int, default=50000, help="index rows of the configs[4] distance leg")
     ap.add_argument("--prob-db-genomes", type=int, default=100000, help="database genomes of the `request_prob` leg: tohnsw + request on ProbMinHash3a (u64) signatures (0 = skip)")
+    ap.add_argument("--skew-alpha", type=float, default=3.5, help="`request_skewed` leg: family = floor(n_roots u^alpha); 3.5 puts ~10 %% of the database in the largest family (0 = skip)")
     ap.add_argument("--redundant-roots", type=int, default=30, help="families the queries of the `request_redundant` side leg are drawn from (0 = skip the leg)")
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     ap.add_argument("--verbose", action="store_true")

@@ -110,6 +110,9 @@ SYMBOLS = {
     "gs_comm_size": (_i, [_vp]),
     "gs_comm_allgather_topk_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "gs_comm_allgatherv_topk_dev": (_i, [_vp, _vp, _vp, _u64, _u64, _u32, _vp, _vp, _vp]),
+    "gs_comm_allgatherv_topk_async_dev": (_i, [_vp, _vp, _vp, _u64, _u64, _u32, _vp, _vp, _vp]),
+    "gs_comm_wait": (_i, [_vp, _vp]),
+    "gs_index_release_build_scratch": (_i, [_vp]),
     "gs_topk_block_bytes": (_u64, [_u64, _u32]),
     "gs_topk_pack": (_i, [_vp, _vp, _u64, _u64, _u32, _vp]),
     "gs_topk_unpack": (_i, [_vp, _i, _u64, _u32, _vp, _vp, _vp]),
@@ -118,6 +121,8 @@ SYMBOLS = {
     "gs_synth_aa_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _vp]),
     "gs_synth_dna_family_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _u64, C.c_double, C.c_double, _vp]),
     "gs_synth_sigs_dev": (_i, [_vp, _i, _u32, _u64, _u64, _u64, _u64, C.c_double, C.c_double, _vp]),
+    "gs_synth_sigs_skew_dev": (_i, [_vp, _i, _u32, _u64, _u64, _u64, _u64, C.c_double, C.c_double, C.c_double, _vp]),
+    "gs_synth_dna_family_skew_dev": (_i, [_vp, _u64, _u64, _u64, _u64, _u64, C.c_double, C.c_double, C.c_double, _vp]),
 }
 
 _lib = None

@@ -140,6 +140,16 @@ class Comm:
         check(self.L.gs_comm_allgatherv_topk_dev(self.h, ids_dev, dist_dev, int(nq_local), int(nq_max), int(knbn), all_ids_dev, all_dist_dev, _p(counts)))
         return counts
 
+    def allgatherv_topk_async_dev(self, ids_dev, dist_dev, nq_local, nq_max, knbn, all_ids_dev, all_dist_dev, counts_dev=None):
+        """the exchange queued on the context's stream, no host round trip (gs_comm_allgatherv_topk_async_dev); wait() is the synchronising half"""
+        check(self.L.gs_comm_allgatherv_topk_async_dev(self.h, ids_dev, dist_dev, int(nq_local), int(nq_max), int(knbn), all_ids_dev, all_dist_dev, counts_dev))
+
+    def wait(self):
+        """waits for the context's stream, checks the last exchange's block shapes, returns every rank's count (gs_comm_wait)"""
+        counts = np.zeros(self.n_ranks, dtype=np.uint64)
+        check(self.L.gs_comm_wait(self.h, _p(counts)))
+        return counts
+
     def size(self):
         return int(self.L.gs_comm_size(self.h))
 

@@ -60,6 +60,7 @@ static int rccl_load()
 struct gs_comm {
     gs_ctx *ctx = nullptr; void *comm = nullptr; int n_ranks = 1, rank = 0;
     gs::DevBuf send, recv;
+    uint64_t *pending_counts = nullptr;      // counts + bad-shape word of the last exchange (in recv), for gs_comm_wait
 };
 
 extern "C" {
@@ -199,21 +200,19 @@ extern "C" {
  * allowed), every rank passes the same nq_max >= all of them, and receives the compact concatenation in rank order - (sum of the counts) x knbn - plus
  * every rank's count (counts_out: HOST, n_ranks entries, optional). ONE ncclAllGather of the fixed-size packed blocks (gs_topk_block_bytes) on the
  * context's stream between a pack and an unpack kernel. all_*_dev must hold n_ranks * nq_max rows. */
-int gs_comm_allgatherv_topk_dev(gs_comm *m, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint64_t nq_max, uint32_t knbn, uint64_t *all_ids_dev,
-                                float *all_dist_dev, uint64_t *counts_out)
+static int allgatherv_launch(gs_comm *m, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint64_t nq_max, uint32_t knbn, uint64_t *all_ids_dev, float *all_dist_dev,
+                             uint64_t *counts_dev)
 {
-    GS_REQUIRE(m && all_ids_dev && all_dist_dev && nq_local <= nq_max && (nq_local == 0 || (ids_dev && dist_dev)), GS_ERR_INVALID, "gs_comm_allgatherv_topk_dev: bad argument");
     gs_ctx *c = m->ctx;
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
     GS_HIP_CHECK(hipSetDevice(c->device));
-    if (nq_max == 0 || knbn == 0) { if (counts_out) for (int r = 0; r < m->n_ranks; r++) counts_out[r] = 0; return GS_OK; }
     const uint64_t block = gs_topk_block_bytes(nq_max, knbn);
     int rc;
     if ((rc = m->send.ensure(block))) return rc;
     if ((rc = m->recv.ensure(block * (size_t)m->n_ranks + 8 * (size_t)m->n_ranks + 64))) return rc;
     uint64_t *d_counts = (uint64_t *)((uint8_t *)m->recv.p + block * (size_t)m->n_ranks);
     uint32_t *d_bad = (uint32_t *)(d_counts + m->n_ranks);
-    GS_HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, c->stream));
+    m->pending_counts = d_counts;
+    GS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 8 * (size_t)m->n_ranks + 8, c->stream));
     const uint64_t n = std::max<uint64_t>(nq_local * knbn, 1);
     hipLaunchKernelGGL(gs::k_topk_pack, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, ids_dev, dist_dev, nq_local, nq_max, knbn, (uint8_t *)m->send.p);
     GS_HIP_CHECK(hipGetLastError());
@@ -223,12 +222,42 @@ int gs_comm_allgatherv_topk_dev(gs_comm *m, const uint64_t *ids_dev, const float
     hipLaunchKernelGGL(gs::k_topk_unpack, dim3(std::max(gx, 1u), (uint32_t)m->n_ranks), dim3(256), 0, c->stream, (const uint8_t *)m->recv.p, block, m->n_ranks, nq_max, knbn, all_ids_dev, all_dist_dev,
                        d_counts, d_bad);
     GS_HIP_CHECK(hipGetLastError());
+    if (counts_dev) GS_HIP_CHECK(hipMemcpyAsync(counts_dev, d_counts, 8 * (size_t)m->n_ranks + 8, hipMemcpyDeviceToDevice, c->stream));
+    return GS_OK;
+}
+/* The exchange WITHOUT the host round trip (round 6): pack -> ncclAllGather -> unpack are queued on the context's stream and the call returns; what follows on that
+ * stream (the next step's sketch, a merge kernel) sees the gathered answers in order. counts_dev (DEVICE, optional): n_ranks counts + one word that is non-zero when
+ * a rank sent a block of another shape. gs_comm_wait() is the synchronising half: it waits for the stream, checks that word and hands the counts to the host. */
+int gs_comm_allgatherv_topk_async_dev(gs_comm *m, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint64_t nq_max, uint32_t knbn, uint64_t *all_ids_dev,
+                                      float *all_dist_dev, uint64_t *counts_dev)
+{
+    GS_REQUIRE(m && all_ids_dev && all_dist_dev && nq_local <= nq_max && nq_max > 0 && knbn > 0 && (nq_local == 0 || (ids_dev && dist_dev)), GS_ERR_INVALID,
+               "gs_comm_allgatherv_topk_async_dev: bad argument");
+    std::lock_guard<std::recursive_mutex> lk(m->ctx->mu);
+    return allgatherv_launch(m, ids_dev, dist_dev, nq_local, nq_max, knbn, all_ids_dev, all_dist_dev, counts_dev);
+}
+int gs_comm_wait(gs_comm *m, uint64_t *counts_out)
+{
+    GS_REQUIRE(m, GS_ERR_INVALID, "gs_comm_wait: null communicator");
+    gs_ctx *c = m->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    GS_HIP_CHECK(hipSetDevice(c->device));
+    if (!m->pending_counts) { GS_HIP_CHECK(hipStreamSynchronize(c->stream)); if (counts_out) for (int r = 0; r < m->n_ranks; r++) counts_out[r] = 0; return GS_OK; }
     std::vector<uint64_t> hc(m->n_ranks + 1, 0);
-    GS_HIP_CHECK(hipMemcpyAsync(hc.data(), d_counts, 8 * (size_t)m->n_ranks + 4, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(hc.data(), m->pending_counts, 8 * (size_t)m->n_ranks + 4, hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    GS_REQUIRE((uint32_t)hc[m->n_ranks] == 0, GS_ERR_INVALID, "gs_comm_allgatherv_topk_dev: a rank sent a block of another shape (nq_max / knbn must agree on every rank)");
+    GS_REQUIRE((uint32_t)hc[m->n_ranks] == 0, GS_ERR_INVALID, "gs_comm: a rank sent a block of another shape (nq_max / knbn must agree on every rank)");
     if (counts_out) for (int r = 0; r < m->n_ranks; r++) counts_out[r] = hc[r];
     return GS_OK;
+}
+int gs_comm_allgatherv_topk_dev(gs_comm *m, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint64_t nq_max, uint32_t knbn, uint64_t *all_ids_dev,
+                                float *all_dist_dev, uint64_t *counts_out)
+{
+    GS_REQUIRE(m && all_ids_dev && all_dist_dev && nq_local <= nq_max && (nq_local == 0 || (ids_dev && dist_dev)), GS_ERR_INVALID, "gs_comm_allgatherv_topk_dev: bad argument");
+    std::lock_guard<std::recursive_mutex> lk(m->ctx->mu);
+    if (nq_max == 0 || knbn == 0) { if (counts_out) for (int r = 0; r < m->n_ranks; r++) counts_out[r] = 0; return GS_OK; }
+    const int rc = allgatherv_launch(m, ids_dev, dist_dev, nq_local, nq_max, knbn, all_ids_dev, all_dist_dev, nullptr);
+    return rc ? rc : gs_comm_wait(m, counts_out);
 }
 /* the equal-shape form: same nq_local and knbn on every rank; all_*_dev: n_ranks x nq_local x knbn, rank order */
 int gs_comm_allgather_topk_dev(gs_comm *m, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint32_t knbn, uint64_t *all_ids_dev, float *all_dist_dev)

@@ -447,13 +447,21 @@ __global__ void k_synth_aa(uint64_t seed, uint64_t g0, uint64_t ng, uint64_t wor
 }
 // genome g = root genome (hash(seed,g) mod n_roots) with iid substitutions at rate mu(g) ~ U[mu_lo, mu_hi]:
 // 16 random bits per base (12 decide, 4 pick one of the three other bases); roots are never emitted themselves.
+// root of member x: uniform (alpha == 0: hash mod n_roots) or skewed (floor(n_roots u^alpha): power-law family sizes)
+__device__ __forceinline__ uint64_t synth_root(uint64_t seed, uint64_t x, uint64_t n_roots, double alpha)
+{
+    const uint64_t h = splitmix_mix(seed * 31 + x * 0xA24BAED4963EE407ULL + 3);
+    if (alpha == 0.0) return h % n_roots;
+    const uint64_t r = (uint64_t)((double)n_roots * pow((double)(h >> 11) * 0x1.0p-53, alpha));
+    return r < n_roots ? r : n_roots - 1;
+}
 __global__ void k_synth_family(uint64_t seed, uint64_t g0, uint64_t ng, uint64_t words_per, uint64_t len, uint64_t n_roots, double mu_lo,
-                               double mu_hi, uint64_t *out)
+                               double mu_hi, double alpha, uint64_t *out)
 {
     uint64_t total = ng * words_per;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t g = g0 + i / words_per, w = i % words_per;
-        uint64_t root = splitmix_mix(seed * 31 + g * 0xA24BAED4963EE407ULL + 3) % n_roots;
+        uint64_t root = synth_root(seed, g, n_roots, alpha);
         double mu = mu_lo + (mu_hi - mu_lo) * ((double)(splitmix_mix(seed + 0x1234567ULL * (g + 1)) >> 11) * 0x1.0p-53);
         uint32_t thr = (uint32_t)(mu * 4096.0 + 0.5);
         uint64_t be = __builtin_bswap64(synth_word(seed ^ 0x5DEECE66DULL, root, w));      // base j at bits 62-2j
@@ -479,12 +487,12 @@ __global__ void k_synth_family(uint64_t seed, uint64_t g0, uint64_t ng, uint64_t
 }
 // row r, slot s. root = hash(seed, r) mod n_roots. root value = f(seed, root, s); member keeps it with prob J(r).
 template <int KIND>
-__global__ void k_synth_sigs(uint32_t m, uint64_t seed, uint64_t r0, uint64_t nrows, uint64_t n_roots, double jlo, double jhi, void *out)
+__global__ void k_synth_sigs(uint32_t m, uint64_t seed, uint64_t r0, uint64_t nrows, uint64_t n_roots, double jlo, double jhi, double alpha, void *out)
 {
     uint64_t total = nrows * (uint64_t)m;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t r = r0 + i / m, s = i % m;
-        uint64_t root = splitmix_mix(seed * 31 + r * 0xA24BAED4963EE407ULL + 3) % n_roots;
+        uint64_t root = synth_root(seed, r, n_roots, alpha);
         double J = jlo + (jhi - jlo) * ((double)(splitmix_mix(seed + 0x1234567ULL * (r + 1)) >> 11) * 0x1.0p-53);
         uint64_t rootv = splitmix_mix(seed ^ (root * 0xD1342543DE82EF95ULL + s * 0x2545F4914F6CDD1DULL + 1));
         uint64_t coin = splitmix_mix(seed ^ (r * 0x9E3779B97F4A7C15ULL + s * 0xC2B2AE3D27D4EB4FULL + 7));
@@ -520,30 +528,40 @@ int gs_synth_aa_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_t
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
-int gs_synth_dna_family_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_t len, uint64_t n_roots, double mu_lo, double mu_hi,
-                            void *seq_dev)
+int gs_synth_dna_family_skew_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_t len, uint64_t n_roots, double mu_lo, double mu_hi, double alpha,
+                                 void *seq_dev)
 {
-    GS_REQUIRE(c && seq_dev && n_roots > 0 && mu_lo >= 0 && mu_hi >= mu_lo && mu_hi < 1.0, GS_ERR_INVALID, "bad argument");
+    GS_REQUIRE(c && seq_dev && n_roots > 0 && mu_lo >= 0 && mu_hi >= mu_lo && mu_hi < 1.0 && alpha >= 0.0, GS_ERR_INVALID, "bad argument");
     GS_CTX_LOCK(c);
     uint64_t wp = (len + 31) / 32;
     if (ng * wp == 0) return GS_OK;
-    hipLaunchKernelGGL(gs::k_synth_family, dim3(c->n_cu * 8), dim3(256), 0, c->stream, seed, g0, ng, wp, len, n_roots, mu_lo, mu_hi, (uint64_t *)seq_dev);
+    hipLaunchKernelGGL(gs::k_synth_family, dim3(c->n_cu * 8), dim3(256), 0, c->stream, seed, g0, ng, wp, len, n_roots, mu_lo, mu_hi, alpha, (uint64_t *)seq_dev);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+int gs_synth_dna_family_dev(gs_ctx *c, uint64_t seed, uint64_t g0, uint64_t ng, uint64_t len, uint64_t n_roots, double mu_lo, double mu_hi,
+                            void *seq_dev)
+{
+    return gs_synth_dna_family_skew_dev(c, seed, g0, ng, len, n_roots, mu_lo, mu_hi, 0.0, seq_dev);      // (alpha = 0: hash mod n_roots, the uniform assignment)
+}
+int gs_synth_sigs_skew_dev(gs_ctx *c, int kind, uint32_t m, uint64_t seed, uint64_t r0, uint64_t nrows, uint64_t n_roots,
+                           double jlo, double jhi, double alpha, void *out)
+{
+    GS_REQUIRE(c && out && n_roots > 0 && alpha >= 0.0, GS_ERR_INVALID, "bad argument");
+    GS_CTX_LOCK(c);
+    if (nrows == 0) return GS_OK;
+    dim3 g(c->n_cu * 8), b(256);
+    if (kind == GS_KIND_F32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_F32>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, alpha, out);
+    else if (kind == GS_KIND_U32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U32>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, alpha, out);
+    else if (kind == GS_KIND_U64) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U64>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, alpha, out);
+    else if (kind == GS_KIND_U16) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U16>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, alpha, out);
+    else GS_REQUIRE(false, GS_ERR_INVALID, "unsupported kind %d", kind);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
 int gs_synth_sigs_dev(gs_ctx *c, int kind, uint32_t m, uint64_t seed, uint64_t r0, uint64_t nrows, uint64_t n_roots,
                       double jlo, double jhi, void *out)
 {
-    GS_REQUIRE(c && out && n_roots > 0, GS_ERR_INVALID, "bad argument");
-    GS_CTX_LOCK(c);
-    if (nrows == 0) return GS_OK;
-    dim3 g(c->n_cu * 8), b(256);
-    if (kind == GS_KIND_F32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_F32>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
-    else if (kind == GS_KIND_U32) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U32>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
-    else if (kind == GS_KIND_U64) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U64>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
-    else if (kind == GS_KIND_U16) hipLaunchKernelGGL(gs::k_synth_sigs<GS_KIND_U16>, g, b, 0, c->stream, m, seed, r0, nrows, n_roots, jlo, jhi, out);
-    else GS_REQUIRE(false, GS_ERR_INVALID, "unsupported kind %d", kind);
-    GS_HIP_CHECK(hipGetLastError());
-    return GS_OK;
+    return gs_synth_sigs_skew_dev(c, kind, m, seed, r0, nrows, n_roots, jlo, jhi, 0.0, out);
 }
 }

@@ -2789,6 +2789,15 @@ int gs_index_search_stats(gs_index *ix, uint64_t out[8], int reset)
     out[3] = ix->stat_wg_in_flight; out[4] = ix->stat_adj_row_bytes;
     return GS_OK;
 }
+int gs_index_release_build_scratch(gs_index *ix)
+{
+    GS_REQUIRE(ix, GS_ERR_INVALID, "gs_index_release_build_scratch: null index");
+    GS_CTX_LOCK(ix->ctx);
+    const uint64_t budget = ix->pair_cache_budget;
+    gs::drop_pair_cache(ix);                                       // (waits for the streams that may still read the slabs)
+    ix->pair_cache_budget = budget;                                // later inserts may cache their own batches again
+    return GS_OK;
+}
 uint64_t gs_index_insert_evals(const gs_index *ix) { return ix ? ix->insert_evals : 0; }
 int gs_index_get_params(const gs_index *ix, gs_index_params *out)
 {

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(JT) void k_match_sample(const T *__restrict__ qkey,
 // Correctness does not depend on how the labels were found: a pair is either counted match by match (phase 0 + main) or its
 // counter is overwritten by the exact compare - "own cluster" in the main pass and "member of the block" in the last are the same test.
 constexpr uint32_t JS0 = 48, JHEAVY = 3;
-constexpr uint64_t JPAIR_CAP = (uint64_t)4 << 20;
+constexpr uint64_t JPAIR_CAP = (uint64_t)4 << 20, JPAIR_MAX = (uint64_t)256 << 20;      // heavy pairs listed by default (32 MB) / at most (2 GB)
 constexpr uint32_t JTILE_CAP = 24576;
 constexpr uint32_t JDEDUP_MINQ = 12;     // clusters of at least this many queries enter equal keys once (shared entries)
 
@@ -618,6 +618,11 @@ __global__ void k_label_prop(const uint2 *__restrict__ pairs, const unsigned lon
         if (l < a) atomicMin(&labq[q], l);
         if (l < b) atomicMin(&labe[p.x], l);
     }
+}
+// nodes per component label (labels are query numbers): what the host needs to size the components without the 1.2 MB of node labels
+__global__ void k_label_count(const uint32_t *__restrict__ labe, uint64_t n, uint32_t nq, uint32_t *__restrict__ cnt)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) { const uint32_t l = labe[e]; if (l < nq) atomicAdd(&cnt[l], 1u); }
 }
 // cluster-sorted copy of the keys of the clustered queries: qs[s * nh + pos] = row qlist[pos], slot s
 template <typename T>
@@ -759,34 +764,58 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     lap("query columns + memset");
     // ---- phase 0 + heavy pairs + labels
     DevBuf &pairs = scratch[2], &ctr = scratch[3], &labq = scratch[4], &labe = scratch[5];
-    if ((rc = pairs.ensure(JPAIR_CAP * 8)) || (rc = ctr.ensure(64)) || (rc = labq.ensure(4 * (size_t)nq)) || (rc = labe.ensure(4 * (size_t)n))) return rc;
-    GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));
+    uint64_t pair_cap = JPAIR_CAP;
+    DevBuf &lcnt = scratch[14];
+    if ((rc = pairs.ensure(pair_cap * 8)) || (rc = ctr.ensure(64)) || (rc = labq.ensure(4 * (size_t)nq)) || (rc = labe.ensure(4 * (size_t)n)) || (rc = lcnt.ensure(4 * (size_t)nq))) return rc;
+    pair_cap = std::max<uint64_t>(pair_cap, pairs.bytes / 8);       // (a list grown by an earlier batch stays)
     if ((rc = join_launch<KIND, T, false>(c, g, k0.as<T>(), nq, cols, colcap, n, 0, JS0, out16, ld, stats, 0, true, nullptr, nullptr, nullptr, 0, nullptr, nullptr))) return rc;
     lap("phase 0 (first slots)");
-    hipLaunchKernelGGL(k_heavy_scan, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, ld, nq, n, m, pairs.as<uint2>(), ctr.as<unsigned long long>(), JPAIR_CAP);
-    lap("heavy scan");
-    hipLaunchKernelGGL(k_label_init, dim3((uint32_t)((std::max<uint64_t>(n, nq) + 255) / 256)), dim3(256), 0, c->stream, labq.as<uint32_t>(), nq, labe.as<uint32_t>(), n);
-    for (int it = 0; it < 6; it++)
-        hipLaunchKernelGGL(k_label_prop, dim3(c->n_cu * 4), dim3(256), 0, c->stream, pairs.as<uint2>(), ctr.as<unsigned long long>(), JPAIR_CAP, labq.as<uint32_t>(), labe.as<uint32_t>());
-    GS_HIP_CHECK(hipGetLastError());
     // (pinned staging: a pageable destination makes the runtime bounce 1.2 MB through its own buffer, synchronously)
-    uint8_t *pin = (uint8_t *)pinned_pool(c)->ensure(34, 64 + 4 * ((size_t)nq + n) + 2 * ((size_t)nq + 8 + (size_t)g.chunks * JT * JN) + 64);
+    uint8_t *pin = (uint8_t *)pinned_pool(c)->ensure(34, 64 + 4 * (2 * (size_t)nq + n) + 2 * ((size_t)nq + 8 + (size_t)g.chunks * JT * JN) + 64);
     GS_REQUIRE(pin, GS_ERR_HIP, "match-join: pinned staging buffer");
     unsigned long long *hc = (unsigned long long *)pin;
-    uint32_t *hlq = (uint32_t *)(pin + 64), *hle = hlq + nq;
-    GS_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipMemcpyAsync(hlq, labq.p, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    lap("labels + query labels down");
+    uint32_t *hlq = (uint32_t *)(pin + 64), *hcn = hlq + nq, *hle = hcn + nq;
+    // The pair list holds (query, node) pairs with >= JHEAVY matches in the first slots. A database with a species of 30 000 genomes (skewed family sizes:
+    // NCBI / GTDB, /root/reference/README.md:134) puts queries-of-that-species x 30 000 pairs on it - 7.6 M per 2500-query batch at 10 % of 300 k nodes -
+    // where 100-member families leave ~0.3 M. A list that overflows is sized to what the scan counted and the scan repeated (once: the count is exact);
+    // round 5 gave such a batch to the compare tile kernel (3 s per 10 000 queries instead of 0.1).
+    for (int attempt = 0;; attempt++) {
+        GS_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, c->stream));
+        hipLaunchKernelGGL(k_heavy_scan, dim3(c->n_cu * 8), dim3(256), 0, c->stream, out16, ld, nq, n, m, pairs.as<uint2>(), ctr.as<unsigned long long>(), pair_cap);
+        lap("heavy scan");
+        hipLaunchKernelGGL(k_label_init, dim3((uint32_t)((std::max<uint64_t>(n, nq) + 255) / 256)), dim3(256), 0, c->stream, labq.as<uint32_t>(), nq, labe.as<uint32_t>(), n);
+        for (int it = 0; it < 6; it++)
+            hipLaunchKernelGGL(k_label_prop, dim3(c->n_cu * 4), dim3(256), 0, c->stream, pairs.as<uint2>(), ctr.as<unsigned long long>(), pair_cap, labq.as<uint32_t>(), labe.as<uint32_t>());
+        GS_HIP_CHECK(hipMemsetAsync(lcnt.p, 0, 4 * (size_t)nq, c->stream));
+        hipLaunchKernelGGL(k_label_count, dim3(c->n_cu * 2), dim3(256), 0, c->stream, labe.as<uint32_t>(), n, nq, lcnt.as<uint32_t>());
+        GS_HIP_CHECK(hipGetLastError());
+        GS_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipMemcpyAsync(hlq, labq.p, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipMemcpyAsync(hcn, lcnt.p, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+        GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        lap("labels + query labels down");
+        if (hc[0] <= pair_cap || attempt || hc[0] > JPAIR_MAX) break;
+        if (pairs.alloc((size_t)hc[0] * 8 + 4096) != GS_OK) { (void)hipGetLastError(); (void)pairs.alloc(JPAIR_CAP * 8); pair_cap = JPAIR_CAP; break; }      // no room: as before
+        pair_cap = hc[0] + 512;
+    }
     const uint64_t npairs = hc[0];
     // ---- clusters: labels with >= 2 queries and >= 1 node, largest blocks dropped while the tile budget is exceeded
     std::vector<uint32_t> cq(nq, 0), ce_(nq, 0), cid(nq, 0);
     uint32_t K = 0, ntiles = 0, nhq = 0, dedup_below = 1;
     uint64_t nhe = 0;
     const uint32_t minq = getenv("GS_JOIN_CLUSTER_MINQ") ? (uint32_t)std::max(2, atoi(getenv("GS_JOIN_CLUSTER_MINQ"))) : (ce && atoi(ce) == 2 ? 2u : 12u);
+    // A component becomes a cluster when it has enough QUERIES (the run of equal keys its isolates leave in the table is what costs) or enough PAIRS: a family of
+    // 2000 genomes with five isolates in the batch has 8000 related (query, node) pairs of thousands of matches each, of which a node's run-length accumulator
+    // absorbs one query's - the rest are atomics. Uniform 100-member families never reach the pair bar (5 x 100 = 400); a skewed database (tools/skew_probe.py)
+    // is full of such components. Where the bar sits: a component costs at least one 128 x 128 compare tile (~18 us), a related pair left to the atomics ~0.5 us
+    // (thousands of matches): ~40 pairs per tile break even; 128 leaves the uniform regime alone (the `min_saved` guard below still decides whether the
+    // cluster-aware pass runs at all). tools/skew_probe.py, 100 k rows: 32 -> 47.0 ms, 128 -> 50.2, 1024 -> 50.6 (first form), 4096 -> 57.9, none: 258.
+    const uint64_t minpairs = getenv("GS_JOIN_CLUSTER_MINPAIRS") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MINPAIRS")) : 128;
+    auto is_cluster = [&](uint32_t l) { return cq[l] >= minq || (cq[l] >= 2 && (uint64_t)(cq[l] - 1) * hcn[l] >= minpairs); };
     bool any = false;
-    if (npairs <= JPAIR_CAP) {
-        for (uint32_t q = 0; q < nq; q++) if (hlq[q] < nq) any |= ++cq[hlq[q]] >= minq;
+    if (npairs <= pair_cap) {
+        for (uint32_t q = 0; q < nq; q++) if (hlq[q] < nq) ++cq[hlq[q]];
+        for (uint32_t l = 0; l < nq && !any; l++) any = cq[l] && hcn[l] && is_cluster(l);
     }
     if (any) {
         // only now the node labels (1.2 MB for 300 k nodes, and a pass over them): a batch of unrelated isolates never gets here
@@ -799,7 +828,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         // 300 k genomes, 2500-query batches (profiles/r04_join_cluster_sweep.txt): 83 queries per family 4.1x faster, 8 per family even, 3 per
         // family 1.6x slower - components below GS_JOIN_CLUSTER_MINQ (12) queries stay with the run-length accumulator.
         std::vector<uint32_t> order;
-        for (uint32_t l = 0; l < nq; l++) if (cq[l] >= minq && ce_[l] >= 1) order.push_back(l);
+        for (uint32_t l = 0; l < nq; l++) if (ce_[l] >= 1 && is_cluster(l)) order.push_back(l);
         auto tiles_of = [&](uint32_t l) { return ((cq[l] + HTILE - 1) / HTILE) * ((ce_[l] + HTILE - 1) / HTILE); };
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { const uint32_t ta = tiles_of(a), tb = tiles_of(b); return ta != tb ? ta < tb : a < b; });
         std::vector<uint32_t> chosen;
@@ -830,7 +859,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
         // nothing to cluster (or too much: pair list overflow): the plain join over the remaining slots - unless the matches of phase 0, scaled to
         // all slots as if every one cost an atomic, say the tile kernel may be cheaper: then the sampled estimate (which knows about runs) decides
         const double t_tile = (double)((nq + 127) / 128 * 128) * (double)n * (double)m / (KIND == GS_KIND_U64 ? 1.4e13 : 1.6e13);
-        if (may_decline && (npairs > JPAIR_CAP || (double)hc[1] * ((double)m / JS0) / 1.6e10 > 0.5 * t_tile)) {
+        if (may_decline && (npairs > pair_cap || (double)hc[1] * ((double)m / JS0) / 1.6e10 > 0.5 * t_tile)) {
             int dec = 0;
             if ((rc = join_sample_declines<KIND, T>(c, g, m, k0.as<T>(), nq, cols, colcap, n, scratch, &dec))) return rc;
             if (dec) { *declined = 1; return GS_OK; }

@@ -96,11 +96,17 @@ class LibExchange:
         self.counts = None
 
     def exchange(self):
-        self.counts = self.comm.allgatherv_topk_dev(self.ids.data_ptr(), self.dist.data_ptr(), self.nq, self.nq_max, self.knbn,
-                                                    self.all_ids.data_ptr(), self.all_dist.data_ptr())
+        """queued on the library's stream, no host round trip per step (round 6): the next step's kernels follow it in stream order"""
+        self.comm.allgatherv_topk_async_dev(self.ids.data_ptr(), self.dist.data_ptr(), self.nq, self.nq_max, self.knbn, self.all_ids.data_ptr(), self.all_dist.data_ptr())
+        self.counts = None
+
+    def wait(self):
+        if self.counts is None:
+            self.counts = self.comm.wait()
+        return self.counts
 
     def gathered(self):
-        tot = int(self.counts.sum())
+        tot = int(self.wait().sum())
         return self.all_ids[:tot], self.all_dist[:tot]
 
     def ranks_seen(self):

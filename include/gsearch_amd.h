@@ -262,6 +262,10 @@ enum { GS_DUMP_TRUNCATE_255 = 1 };
 int      gs_index_dump_hnswrs_ex(gs_index *, const char *basename, uint32_t flags);
 int      gs_index_load_hnswrs(gs_ctx *, const char *basename, const gs_index_params *hint, gs_index **out);
 uint64_t gs_index_insert_evals(const gs_index *);      /* DistHamming evaluations spent by inserts so far */
+/* after the last parallel_insert of a build (the replicas of a multi-GPU request, a server that only answers): gives the insert-time pair cache back - up to 55 % of
+ * the device, 90 GB at 300 k nodes - and keeps everything a search needs. Later inserts still work (bit-identical graph): pairs among the nodes inserted before the
+ * call are evaluated from their rows instead of looked up. */
+int      gs_index_release_build_scratch(gs_index *);
 /* device-side work counters of the searches and dense-mode inserts since the last reset (bench.py prices kernels with them):
  * out[0] memory-side atomics sent by the match-join, out[1] candidates popped by the dense traversal, out[2] pops that accepted
  * at least one neighbour, out[3] traversal workgroups in flight (last launch), out[4] bytes of adjacency a pop loads, out[5] / out[6] pops before / after the traversal
@@ -288,6 +292,13 @@ int  gs_comm_allgather_topk_dev(gs_comm *, const uint64_t *ids_dev, const float 
  * counts_out (HOST, n_ranks, optional) every rank's count. Still ONE ncclAllGather - of fixed-size blocks, gs_topk_block_bytes() each. */
 int  gs_comm_allgatherv_topk_dev(gs_comm *, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint64_t nq_max, uint32_t knbn,
                                  uint64_t *all_ids_dev, float *all_dist_dev, uint64_t *counts_out);
+/* the same exchange WITHOUT the host round trip: the pack kernel, the ncclAllGather and the unpack kernel are queued on the context's stream and the call returns;
+ * work queued afterwards on that stream (the next step's sketch, gs_topk_merge_dev) sees the gathered answers in order. counts_dev (DEVICE, n_ranks + 1 words,
+ * optional): every rank's count, then a word that is non-zero when a rank sent a block of another shape. gs_comm_wait: waits for the stream, fails with
+ * GS_ERR_INVALID on such a block, hands the counts of the LAST exchange to the host (counts_out: HOST, n_ranks, optional). */
+int  gs_comm_allgatherv_topk_async_dev(gs_comm *, const uint64_t *ids_dev, const float *dist_dev, uint64_t nq_local, uint64_t nq_max, uint32_t knbn,
+                                       uint64_t *all_ids_dev, float *all_dist_dev, uint64_t *counts_dev);
+int  gs_comm_wait(gs_comm *, uint64_t *counts_out);
 /* the block layout itself, on the HOST (no device needed), for hosts that move the blocks by their own means (MPI, sockets): header {u64 nq_local, u32 knbn,
  * u32 magic}, nq_max x knbn ids, nq_max x knbn distances. unpack: n_ranks blocks back to back -> compact rows in rank order + counts. */
 uint64_t gs_topk_block_bytes(uint64_t nq_max, uint32_t knbn);
@@ -316,6 +327,13 @@ int gs_synth_dna_family_dev(gs_ctx *, uint64_t seed, uint64_t first_genome, uint
  * and keeps each root slot with probability J(r) ~ U[j_lo, j_hi], else draws its own value. */
 int gs_synth_sigs_dev(gs_ctx *, int kind, uint32_t m, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                       uint64_t n_roots, double j_lo, double j_hi, void *sigs_dev /* n_rows x m */);
+/* the same two generators with SKEWED family sizes (the regime of NCBI / GTDB prokaryotes, /root/reference/README.md:134: a few species with 10^4 genomes,
+ * a long tail of singletons): member g belongs to root floor(n_roots * u(g)^alpha), u uniform in [0,1) - root 0 holds a fraction n_roots^(-1/alpha) of
+ * everything (alpha = 3.5, n_roots = 3000: 10 %), the sizes fall off as a power law. alpha = 1 is uniform. */
+int gs_synth_dna_family_skew_dev(gs_ctx *, uint64_t seed, uint64_t first_genome, uint64_t n_genomes, uint64_t len_bases,
+                                 uint64_t n_roots, double mu_lo, double mu_hi, double alpha, void *seq_dev);
+int gs_synth_sigs_skew_dev(gs_ctx *, int kind, uint32_t m, uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                           uint64_t n_roots, double j_lo, double j_hi, double alpha, void *sigs_dev /* n_rows x m */);
 
 #ifdef __cplusplus
 }

@@ -102,3 +102,28 @@ def test_integration_md_binds_every_exported_symbol():
         decl = "pub fn %s(%s)%s;" % (name, ", ".join("%s: %s" % p for p in params), (" -> " + ret) if ret else "")
         assert " ".join(decl.split()) in md, decl
     assert sorted(names) == sorted(G.SYMBOLS), set(names) ^ set(G.SYMBOLS)
+
+
+def test_every_environment_knob_is_documented():
+    """every GS_* environment variable the library or its Python host reads appears in INTEGRATION.md section 5 with a class
+    (D diagnostic / S strategy override / A A-B switch / T tuning parameter)"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    knobs = set()
+    for fn in glob.glob(os.path.join(root, "gsearch_amd", "csrc", "*.h*")):
+        knobs |= set(re.findall(r'getenv\("(GS_[A-Z0-9_]+)"\)', open(fn).read()))
+    for fn in glob.glob(os.path.join(root, "gsearch_amd", "*.py")):
+        knobs |= set(re.findall(r'environ[^\n]*?"(GS_[A-Z0-9_]+)"', open(fn).read()))
+    assert len(knobs) > 50
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    table = md[md.index("## 5. Runtime knobs"):]
+    rows = {}
+    for line in table.split("\n"):
+        if line.startswith("| `GS_"):
+            cells = [c.strip() for c in line.strip().strip("|").split("|")]
+            for name in re.findall(r"`(GS_[A-Z0-9_]+)`", cells[0]):
+                rows[name] = cells[1]
+    missing = sorted(k for k in knobs if k not in rows)
+    assert not missing, missing
+    assert all(set(c.replace(" ", "").split("/")) <= {"D", "S", "A", "T"} for c in rows.values()), rows

@@ -65,6 +65,44 @@ def test_config1_sketch_5mbp_s18000(gpu_ctx, monkeypatch):
     assert np.array_equal(_bits(plain), _bits(ref))
 
 
+def test_config4_sketch_aa_super2_bench_shape(gpu_ctx):
+    """BASELINE configs[4] through the instantiation bench.py times: AA k = 7, s = 24000, super2 -> u64 signatures
+    (/root/reference/src/aa/aasketch.rs:508-517, src/aa/aarequest.rs:268,283). 24000 x u64 = 192 kB of slots do not fit the LDS: with >= 2 x CUs
+    proteomes in the batch every proteome gets ONE workgroup whose slot table lives in global memory behind the 2-byte LDS bound filter
+    (gs_sketch.hip MinEmit<.., LDS_TABLE = false>). Eight distinct proteomes of 1.5 M residues - iid and family members, one cut into 3750 records,
+    one with non-alphabet bytes - tiled 65 times (520 proteomes), bits == oracle; the same eight alone (each split over many workgroups) agree."""
+    import gsearch_amd as G
+    k, m, L = 7, 24000, 1_500_000
+    rng = np.random.default_rng(404)
+    fam = H.family(rng, L, [0.02, 0.1], alphabet=20)
+    asc = [H.aa_ascii(g) for g in fam] + [H.aa_ascii(rng.integers(0, 20, n)) for n in (L, L, L + 999, L - 4321)]
+    a7 = H.aa_ascii(rng.integers(0, 20, L))
+    genomes = [[a] for a in asc]
+    genomes.append([a7[i:i + 400] for i in range(0, L, 400)])                                     # 3750 records: k-mers never span them
+    genomes[3] = [asc[3][:700_000] + b"*XBZ-" + asc[3][700_000:].lower()]                            # bytes outside the alphabet are dropped, case folded
+    assert len(genomes) == 8
+    recs = [r for g in genomes for r in g]
+    goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
+    seq, rs, rl = O.filter_aa(recs)
+    ref = O.sketch_batch(O.params(k, m, "super2", "aa"), seq, rs, rl, goff, nthreads=os.cpu_count())
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "super2", "aa"))
+    assert sk.sig_dtype() == np.uint64
+    got = sk.sketch_packed(seq, rs, rl, goff)
+    info = sk.ctx.last_sketch_info()
+    assert not info["table_in_lds"] and info["workgroups_per_genome"] > 1, info
+    assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    reps = 65
+    seq_r = np.tile(seq, reps)
+    rs_r = np.concatenate([rs + np.uint64(r * len(seq)) for r in range(reps)])
+    rl_r = np.tile(rl, reps)
+    goff_r = np.concatenate([goff[:-1] + np.uint64(r * len(rs)) for r in range(reps)] + [np.array([reps * len(rs)], np.uint64)])
+    big = sk.sketch_packed(seq_r, rs_r, rl_r, goff_r)
+    info = sk.ctx.last_sketch_info()
+    assert not info["table_in_lds"] and info["workgroups_per_genome"] == 1, info       # the shape of the bench's 50 000-proteome launch
+    bad = np.nonzero((big != np.tile(ref, (reps, 1))).any(axis=1))[0]
+    assert bad.size == 0, bad[:10].tolist()
+
+
 def test_config2_request_300k(gpu_ctx, monkeypatch):
     import gsearch_amd as G
     ctx, lib, chk = gpu_ctx, gpu_ctx.L, G._lib.check
@@ -330,3 +368,80 @@ def test_cost_model_picks_a_strategy_close_to_the_better_one(gpu_ctx, monkeypatc
             if p:
                 ctx.free(p)
         ctx.release_scratch()
+
+
+def _synth_roots(seed, first, n, n_roots, alpha):
+    """host twin of gs_synth_*_skew_dev's family assignment (gs_ctx.hip synth_root)"""
+    M64 = (1 << 64) - 1
+    r = np.arange(first, first + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64((seed * 31) & M64) + r * np.uint64(0xA24BAED4963EE407) + np.uint64(3)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    return np.minimum((n_roots * u ** alpha).astype(np.int64), n_roots - 1)
+
+
+def test_request_on_a_skewed_database(gpu_ctx, monkeypatch):
+    """the database gsearch is run on (NCBI / GTDB prokaryotes, /root/reference/README.md:134) has a few species with 10^4
+    genomes and a long tail - every other test and bench database holds ~100 members per family. 120 000 rows of 1200 families whose sizes follow a
+    power law (the largest: 13 % of the rows), 4096 queries drawn from the same law (so ~540 of them hit the largest family: the match-join's heavy
+    blocks are 540 x 15 800 pairs, sized by the node side as much as by the query side). Forced row streaming, forced dense and `auto` give the same
+    ids / distances / evaluation counts, a 16-query sample equals the oracle on the exported graph, and `auto` costs at most 1.3x the better forced
+    strategy."""
+    import time
+    import gsearch_amd as G
+    ctx, lib, chk = gpu_ctx, gpu_ctx.L, G._lib.check
+    m, n, n_roots, nq, M, efc, ef, alpha, seed = 4096, 120_000, 1200, 4096, 48, 400, 1000, 3.5, 515
+    sizes = np.bincount(_synth_roots(seed, 0, n, n_roots, alpha), minlength=n_roots)
+    assert sizes.max() >= 0.1 * n and np.median(sizes) < 60, (sizes.max(), np.median(sizes))
+    d_db, d_q = ctx.alloc(n * m * 4), ctx.alloc(nq * m * 4)
+    hn = None
+    try:
+        chk(lib.gs_synth_sigs_skew_dev(ctx.h, G._lib.KIND_F32, m, seed, 0, n, n_roots, 0.3, 0.99, alpha, d_db))
+        chk(lib.gs_synth_sigs_skew_dev(ctx.h, G._lib.KIND_F32, m, seed, 7_000_000, nq, n_roots, 0.3, 0.99, alpha, d_q))
+        hn = G.Hnsw.new(M, n, 16, efc, G.DistHamming(ctx), dtype=np.float32, seed=5, insert_batch=256, ctx=ctx)
+        hn.modify_level_scale(0.25); hn.set_extend_candidates(True); hn.set_keeping_pruned(False)
+        hn._ensure(m)
+        t0 = time.perf_counter()
+        for g0 in range(0, n, 8192):
+            chk(lib.gs_index_parallel_insert_dev(hn.h, d_db + g0 * m * 4, min(8192, n - g0)))
+        ctx.sync()
+        build_s = time.perf_counter() - t0
+        ctx.free(d_db); d_db = None
+        outs = [ctx.alloc(8 * nq * 50), ctx.alloc(4 * nq * 50), ctx.alloc(4 * nq), ctx.alloc(8 * nq)]
+        times, answers = {}, {}
+        try:
+            for mode in ("gather", "dense", "auto", "gather", "dense", "auto"):         # second round = the timings
+                if mode == "auto":
+                    monkeypatch.delenv("GS_DIST_MODE", raising=False)
+                else:
+                    monkeypatch.setenv("GS_DIST_MODE", mode)
+                ctx.sync(); t0 = time.perf_counter()
+                chk(lib.gs_index_parallel_search_dev(hn.h, d_q, nq, 50, ef, *outs)); ctx.sync()
+                times[mode] = time.perf_counter() - t0
+                answers[mode] = (ctx.download(outs[0], (nq, 50), np.uint64), ctx.download(outs[1], (nq, 50), np.float32), ctx.download(outs[3], (nq,), np.uint64))
+        finally:
+            for p_ in outs:
+                ctx.free(p_)
+        print("skewed database m=%d n=%d (largest family %d) nq=%d: build %.1f s, gather %.1f ms, dense %.1f ms, auto %.1f ms"
+              % (m, n, sizes.max(), nq, build_s, times["gather"] * 1e3, times["dense"] * 1e3, times["auto"] * 1e3))
+        for mode in ("dense", "auto"):
+            for a, b in zip(answers[mode], answers["gather"]):
+                assert np.array_equal(a, b), mode
+        q = ctx.download(d_q, (16, m), np.float32)
+        g = hn.export_graph(); db = hn.get_data()
+    finally:
+        if hn is not None:
+            hn.close()
+        for p in (d_db, d_q):
+            if p:
+                ctx.free(p)
+        ctx.release_scratch()
+    oix = O.Index(np.float32, m, M, efc, scale_modify=0.25, seed=5)
+    oix.import_graph(db, g, view=True)
+    oids, odist, _, oev = oix.parallel_search(q, 50, ef, nthreads=os.cpu_count())
+    ids, dist, ev = answers["auto"]
+    assert np.array_equal(oids, ids[:16]) and np.array_equal(_bits(odist), _bits(dist[:16])) and np.array_equal(oev, ev[:16])
+    assert times["auto"] <= 1.3 * min(times["gather"], times["dense"]) + 2e-3, times
