@@ -132,9 +132,32 @@ def run_selftest_launch(args, D):
     allq = torch.arange(D.world * nq, dtype=torch.int64).view(-1, 1)
     ok = bool(torch.equal(ids, allq * 1000 + j) and torch.equal(dist, (allq * 8 + j).to(torch.float32) / 64.0))
     ranks = D.sum(float(1 << D.rank))
+    # --shard db: every rank answers ALL nq queries on its shard of a 1000-node database (stub: node g of query q lies at distance ((g * 37 + q * 11) % 1000) / 1000),
+    # ONE all-gather of the shard-major blocks, k-way merge under (distance, id) with the shards' id offsets: every rank must end with the global top-k
+    db_ok = None
+    if args.shard == "db":
+        import numpy as np
+        NDB = 1000
+        lo, hi = S.shard_bounds(NDB, D.rank, D.world)
+        q = np.arange(nq).reshape(nq, 1)
+        g = np.arange(lo, hi).reshape(1, -1)
+        dl = ((g * 37 + q * 11) % 1000).astype(np.float32) / np.float32(1000.0)
+        order = np.lexsort((np.broadcast_to(g, dl.shape), dl), axis=1)[:, :knbn]
+        ex.ids.copy_(torch.from_numpy(order.astype(np.int64)))                                   # LOCAL ids, as a shard's index returns them
+        ex.dist.copy_(torch.from_numpy(np.take_along_axis(dl, order, axis=1)))
+        ex.exchange()
+        ids_g, dist_g = ex.gathered()
+        offs = [S.shard_bounds(NDB, r, D.world)[0] for r in range(D.world)]
+        ids_s = [ids_g[r * nq:(r + 1) * nq].cpu().numpy().astype(np.uint64) + np.uint64(offs[r]) for r in range(D.world)]
+        dist_s = [dist_g[r * nq:(r + 1) * nq].cpu().numpy() for r in range(D.world)]
+        mi, md = S.merge_topk_shards(ids_s, dist_s, knbn)
+        ga = np.arange(NDB).reshape(1, -1)
+        da = ((ga * 37 + q * 11) % 1000).astype(np.float32) / np.float32(1000.0)
+        oa = np.lexsort((np.broadcast_to(ga, da.shape), da), axis=1)[:, :knbn]
+        db_ok = D.sum_i64(1 if (np.array_equal(mi, oa.astype(np.uint64)) and np.array_equal(md, np.take_along_axis(da, oa, axis=1))) else 0) == D.world
     if D.rank == 0:
         print(json.dumps({"selftest": "launch", "n_gpus": D.world, "backend": D.backend, "rank_mask": int(ranks), "collectives_per_step": 1,
-                          "gathered_equals_expected": ok, "seconds": dt}))
+                          "gathered_equals_expected": ok, "db_sharded_merge_equals_global_topk_on_every_rank": db_ok, "seconds": dt}))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -235,6 +258,17 @@ def join_valu_model(elements_per_launch, batch_ms):
                           "is the survivor queue's push / pop (eight ballot + mbcnt sequences each, executed by every lane of a wavefront that has ONE survivor)",
             "valu_issue_ms_per_launch_at_4.2_cycles": issue_ms, "valu_issue_frac_of_batch_time": issue_ms / batch_ms if batch_ms else None,
             "note": "VALU issue is about half busy: the binding resource is the memory-side atomic unit (frac_of_atomics_ceiling); halving the queue's instructions would not shorten the launch"}
+
+
+def join_class_string():
+    """what binds k_match_join, with the NEWEST committed evidence named (the string used to cite round-4 files whatever the round)"""
+    import glob
+    def newest(pattern):
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return os.path.basename(f[-1]) if f else None
+    sq, ub, wo = newest("r0*_step_sq_counters.txt"), newest("r0*_ubench_atomic.txt"), newest("r0*_join_without_atomics.log")
+    return ("atomics + valu: memory-side atomics at `frac_of_atomics_ceiling` of the scattered no-return rate of profiles/%s; VALU issue about half busy (`valu_model`, SQ counters of "
+            "profiles/%s); with the atomics compiled out the launch keeps ~0.8 of its time (profiles/%s) - two walls, the atomic unit first" % (ub, sq, wo))
 
 
 def run_sketch(args, D):
@@ -389,8 +423,14 @@ def run_request(args, D):
     def sketch_dev(d_seq, n, d_sig, d_rs, d_rl, d_goff):
         chk(lib.gs_sketch_batch_dev(ctx.h, C.byref(prm.c), d_seq, n * gbytes + 64, d_rs, d_rl, n, d_goff, n, d_sig))
 
+    # --shard db (the other decomposition of SURVEY 8e, the per-shard loop + merge of /root/reference/scripts/multiple_search.sh:71-107): the DATABASE is split over the
+    # ranks (contiguous genome ranges), every rank sketches and answers ALL queries of a step on its shard, the gathered answers (one all-gather of world x qps blocks) are
+    # merged on the device under (distance, id) with the shards' id offsets (gs_topk_merge_dev). Total work per step is fixed: "strong" scaling.
+    db_shard = args.shard == "db"
+    g_lo, g_hi = S.shard_bounds(N, D.rank, D.world) if db_shard else (0, N)
+    N_loc = g_hi - g_lo
     # ---- tohnsw (untimed setup): generate -> sketch -> parallel_insert, in chunks
-    chunk = min(args.build_chunk, N)
+    chunk = min(args.build_chunk, max(N_loc, 1))
     d_seq = ctx.alloc(chunk * gbytes + 64)
     d_sig = ctx.alloc(chunk * m * 4)
     nrec = max(chunk, qps)                                  # record tables serve the build chunks and the query batches
@@ -398,20 +438,21 @@ def run_request(args, D):
     d_rs, d_rl, d_goff = ctx.alloc(rs.nbytes), ctx.alloc(rs.nbytes), ctx.alloc(8 * (nrec + 1))
     ctx.upload(d_rs, rs); ctx.upload(d_rl, np.full(nrec, L, np.uint64)); ctx.upload(d_goff, np.arange(nrec + 1, dtype=np.uint64))
     t_b = time.perf_counter()
-    for g0 in range(0, N, chunk):
-        n = min(chunk, N - g0)
+    for g0 in range(g_lo, g_hi, chunk):
+        n = min(chunk, g_hi - g0)
         chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, g0, n, L, n_roots, mu_lo, mu_hi, d_seq))
         sketch_dev(d_seq, n, d_sig, d_rs, d_rl, d_goff)
         chk(lib.gs_index_parallel_insert_dev(hn.h, d_sig, n))
         if D.rank == 0 and args.verbose:
-            print("# built %d / %d in %.1fs" % (g0 + n, N, time.perf_counter() - t_b), file=sys.stderr, flush=True)
+            print("# built %d / %d in %.1fs" % (g0 - g_lo + n, N_loc, time.perf_counter() - t_b), file=sys.stderr, flush=True)
     ctx.sync()
     build_s = time.perf_counter() - t_b
     ctx.free(d_seq); ctx.free(d_sig)
+    chk(lib.gs_index_release_build_scratch(hn.h))              # the build is over: the insert-time pair cache (up to 55 % of the device) goes back before the request
 
     # ---- query genomes resident in HBM before the timed region: fresh mutants of the DB's roots
     d_qseq = ctx.alloc(nq_rank * gbytes + 64)
-    q_first = 1_000_000_000 + D.rank * nq_rank
+    q_first = 1_000_000_000 + (0 if db_shard else D.rank * nq_rank)     # (db sharding: every rank answers the SAME queries)
     chk(lib.gs_synth_dna_family_dev(ctx.h, args.seed, q_first, nq_rank, L, n_roots, mu_lo, mu_hi, d_qseq))
     d_qsig = ctx.alloc(qps * m * 4)
     # the exchange: ONE all-gather of the per-rank top-k blocks per step, through the LIBRARY's communicator (gs_comm_*: its own RCCL communicator, pack kernel ->
@@ -438,12 +479,24 @@ def run_request(args, D):
     nsteps_q = max(nq_rank // qps, 1)
     evals_steps = []
 
+    merged_ids = torch.empty((qps, knbn), dtype=torch.int64, device=D.device) if db_shard else None
+    merged_dist = torch.empty((qps, knbn), dtype=torch.float32, device=D.device) if db_shard else None
+    shard_off = np.array([S.shard_bounds(N, r, D.world)[0] for r in range(D.world)], dtype=np.uint64)
+
     def step(i):
         b = i % nsteps_q
         sketch_dev(d_qseq + b * qps * gbytes, qps, d_qsig, d_rs, d_rl, d_goff)
         chk(lib.gs_index_parallel_search_dev(hn.h, d_qsig, qps, knbn, ef, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), ev_t.data_ptr()))
         if D.on:           # RCCL all-gather of the per-rank top-k blocks
             ex.exchange()
+        if db_shard:       # every rank merges the shards' answers for the step's queries (shard-major blocks, as gathered)
+            if D.on and D.world > 1:
+                a_ids, a_dist = (ex.all_ids, ex.all_dist) if isinstance(ex, S.LibExchange) else ex.gathered()
+                if not isinstance(ex, S.LibExchange):
+                    torch.cuda.current_stream().synchronize()      # (the torch collective ran on torch's stream, the merge runs on the library's)
+            else:
+                a_ids, a_dist = ids_t, dist_t
+            G.topk_merge_dev(ctx, a_ids.data_ptr(), a_dist.data_ptr(), D.world, qps, knbn, knbn, merged_ids.data_ptr(), merged_dist.data_ptr(), id_offset=shard_off)
 
     for i in range(args.warmup):
         step(args.steps + i)
@@ -482,10 +535,10 @@ def run_request(args, D):
     n_ok = D.sum_i64(1 if (exchange_ok and all_sum == sum_of_own) else 0)
     rank_mask = D.sum_i64(1 << D.rank)
     ranks_seen = ex.ranks_seen() if isinstance(ex, S.LibExchange) else bin(rank_mask).count("1")     # gs_comm_size of the library's communicator
-    value = D.world * qps * args.steps / dt
+    value = (1 if db_shard else D.world) * qps * args.steps / dt
     out = {
         "metric": "query genomes/sec", "value": value, "unit": "genomes/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if db_shard else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "request: %d query genomes x %.1f Mbp per GPU per step (k=%d s=%d optdens sketch + HNSW search n=%d ef=%d) against a %d-genome "
                                "OptDens HNSW (M=%d efc=%d scale %.2f) built on the GPU, DB replicated per GPU, queries sharded (BASELINE configs[2]/[3]); query genomes "
                                "HBM-resident before the timed region, %d distinct sets rotated over the steps; queries are fresh mutants of the DB's %d families (~%.1f per "
@@ -496,8 +549,13 @@ def run_request(args, D):
                    "distinct_query_sets": max(nq_rank // qps, 1), "queries_per_db_family_per_step": qps / n_roots},
         "step_ms": [round(x, 2) for x in step_ms], "build_seconds": build_s, "build_genomes_per_sec": N / build_s, "dist_evals_per_query": evals_total / (qps * args.steps),
         "sketch_kmers_per_sec": (L - k + 1) * qps * sk_n / (sk_ms * 1e-3) if sk_ms > 0 else None,
-        "multi_gpu_check": {"rccl_ranks_seen": ranks_seen, "ranks_whose_block_and_checksum_verified": n_ok, "world": D.world, "collective": ex_kind},
+        "multi_gpu_check": {"rccl_ranks_seen": ranks_seen, "ranks_whose_block_and_checksum_verified": n_ok, "world": D.world, "collective": ex_kind,
+                            "sharding": "database split over the ranks, every rank answers all queries, gathered answers merged by gs_topk_merge_dev" if db_shard
+                                        else "database replicated, queries split over the ranks"},
+        "build_scratch_released": True,
     }
+    if db_shard:
+        out["db_shard"] = {"genomes_of_this_rank": int(N_loc), "first_genome": int(g_lo), "merged_best_distance_sum": float(merged_dist[:, 0].sum().item())}
     if D.rank == 0:
         out.update(request_accounting(args, ctx, hn, lib, chk, torch, D, dict(
             srch=(srch_ms, srch_n), tile=(tile_ms, tile_n), sk=(sk_ms, sk_n), stats=st, evals_total=evals_total, d_qsig=d_qsig, ids_t=ids_t,
@@ -550,7 +608,7 @@ def request_accounting(args, ctx, hn, lib, chk, torch, D, r):
         if join:
             col_bytes = float(N) * row_bytes                                   # the column store is streamed once per launch
             atom = st.get("join_atomics", 0)
-            kd.update({"class": "valu + atomics (SQ counters: VALU issue 0.67 busy; without the atomics the kernel runs 0.8 of its time - profiles/r04_join_dense_pmc.txt, r04_join_without_atomics.log)",
+            kd.update({"class": join_class_string(),
                        "algorithmic_bytes_per_launch": col_bytes + 2.0 * pairs_total / tile_n,
                        "column_stream_GBps": col_bytes * tile_n / (tile_ms * 1e-3) / 1e9, "atomics_per_launch": atom / tile_n,
                        "atomics_per_sec": atom / (tile_ms * 1e-3), "atomics_peak_per_sec": ATOMICS_PEAK, "frac_of_atomics_ceiling": atom / (tile_ms * 1e-3) / ATOMICS_PEAK,
@@ -1173,6 +1231,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shard", default="query", choices=["query", "db"], help="multi-GPU decomposition: `query` (north star: database replicated, queries split, one all-gather) or `db` "
+                                                                                 "(database split, every rank answers all queries, all-gather + device merge)")
     ap.add_argument("--workload", default="request", choices=["sketch", "request", "c5dist"], help="c5dist: only the configs[4] u64 distance leg (the PMC passes of tools/pmc_bench.sh run it)")
     ap.add_argument("--genomes", type=int, default=10000)
     ap.add_argument("--genome-len", type=int, default=5_000_000)

@@ -812,10 +812,17 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     // cluster-aware pass runs at all). tools/skew_probe.py, 100 k rows: 32 -> 47.0 ms, 128 -> 50.2, 1024 -> 50.6 (first form), 4096 -> 57.9, none: 258.
     const uint64_t minpairs = getenv("GS_JOIN_CLUSTER_MINPAIRS") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MINPAIRS")) : 128;
     auto is_cluster = [&](uint32_t l) { return cq[l] >= minq || (cq[l] >= 2 && (uint64_t)(cq[l] - 1) * hcn[l] >= minpairs); };
+    // (query, node) pairs the would-be clusters take off the match-by-match path, from the per-label counts alone: below the bar of the cluster-aware pass (min_saved, further
+    // down) the batch takes the plain join without the node labels ever leaving the device (1.2 MB + a host pass over 300 k nodes per batch: 3 ms per request when every
+    // batch of unrelated isolates paid it for its handful of three-query components)
+    const uint64_t min_scaled0 = (uint64_t)((double)nq * 32.0 * (double)n / 3.0e5);
+    const uint64_t min_saved0 = getenv("GS_JOIN_CLUSTER_MIN") ? (uint64_t)atoll(getenv("GS_JOIN_CLUSTER_MIN")) : (ce && atoi(ce) == 2 ? 0 : std::max<uint64_t>((uint64_t)nq * 8, min_scaled0));
     bool any = false;
     if (npairs <= pair_cap) {
         for (uint32_t q = 0; q < nq; q++) if (hlq[q] < nq) ++cq[hlq[q]];
-        for (uint32_t l = 0; l < nq && !any; l++) any = cq[l] && hcn[l] && is_cluster(l);
+        uint64_t est = 0;
+        for (uint32_t l = 0; l < nq; l++) if (cq[l] && hcn[l] && is_cluster(l)) { any = true; est += (uint64_t)(cq[l] - 1) * hcn[l]; }
+        if (est < min_saved0) any = false;
     }
     if (any) {
         // only now the node labels (1.2 MB for 300 k nodes, and a pass over them): a batch of unrelated isolates never gets here

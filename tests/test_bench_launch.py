@@ -23,6 +23,19 @@ def test_bench_gpus_n_self_launches_n_ranks(n):
     assert r["n_gpus"] == n and r["rank_mask"] == (1 << n) - 1 and r["collectives_per_step"] == 1 and r["gathered_equals_expected"]
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_db_sharded_launch_merges_to_the_global_topk(n):
+    """`bench.py --gpus N --shard db` (the per-shard loop + merge of /root/reference/scripts/multiple_search.sh:71-107): the database split
+    over the ranks, every rank answers all queries on its shard with local ids, one all-gather of the shard-major blocks, merge under (distance, id) with
+    the shards' offsets - every rank ends with the global top-k (gloo, stub searcher; the GPU run uses gs_topk_merge_dev for the same merge)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--selftest-launch", "--shard", "db"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == n and r["gathered_equals_expected"] and r["db_sharded_merge_equals_global_topk_on_every_rank"] is True
+
+
 def test_single_rank_needs_no_launcher():
     from gsearch_amd import sharding as S
     env = dict(os.environ)

@@ -1324,6 +1324,37 @@ def test_worker_table_of_one_under_many_threads(gpu_ctx):
     assert "genomes/s" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
 
 
+def test_release_build_scratch_then_search_and_insert_more(gpu_ctx):
+    """gs_index_release_build_scratch (round 6: what a replica of a multi-GPU request, or a server that only answers, calls after its last insert) gives
+    the insert-time pair cache back. Searches are unchanged, and inserting MORE points afterwards still builds the graph an index that never
+    released anything builds (pairs among the older nodes are then evaluated from their rows instead of looked up) - both equal the oracle's."""
+    import gsearch_amd as G
+    db = H.synth_sig_db(40, 60, 256, 77, jlo=0.05, jhi=0.95)                 # 2400 rows
+    q = H.queries_from(db, 48, 78, frac=0.2)
+    cut = 2048                                                               # a multiple of the insert batch: the graph depends on the batch boundaries
+    hs = []
+    for release in (False, True):
+        hn = G.Hnsw.new(12, 10000, 16, 60, G.DistHamming(), seed=9, insert_batch=64)
+        hn.set_extend_candidates(True)
+        hn.parallel_insert(db[:cut])
+        before = hn.search_arrays(q, 10, 120)
+        if release:
+            G._lib.check(hn.ctx.L.gs_index_release_build_scratch(hn.h))
+            after = hn.search_arrays(q, 10, 120)
+            assert all(np.array_equal(a, b) for a, b in zip(before, after))
+        hn.parallel_insert(db[cut:], ids=np.arange(cut, len(db), dtype=np.uint64))
+        hs.append(hn)
+    g0, g1 = hs[0].export_graph(), hs[1].export_graph()
+    for key in ("levels", "deg0", "nbr0", "cnt0", "upidx"):
+        assert np.array_equal(g0[key], g1[key]), key
+    oix = O.Index(np.float32, db.shape[1], 12, 60, seed=9)
+    oix.parallel_insert(db[:cut], batch=64); oix.parallel_insert(db[cut:], batch=64)
+    og = oix.export()
+    assert np.array_equal(og["deg0"], g1["deg0"]) and np.array_equal(og["nbr0"], g1["nbr0"])
+    a, b = hs[0].search_arrays(q, 10, 120), hs[1].search_arrays(q, 10, 120)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_comm_allgather_single_rank(gpu_ctx):
     """C-level multi-GPU helper (gs_comm_*, RCCL): a one-rank communicator gathers the rank's own top-k block; the N > 1 exchange is the
     same call (covered for layout by the gloo world-size-2 test of the packed Python exchange)"""
@@ -1347,6 +1378,16 @@ def test_comm_allgather_single_rank(gpu_ctx):
             assert list(counts) == [nq]
             assert np.array_equal(ctx.download(d_bi, ids.shape, np.uint64), ids) and np.array_equal(ctx.download(d_bd, dist.shape, np.float32), dist)
             assert list(comm.allgatherv_topk_dev(None, None, 0, 50, knbn, d_bi, d_bd)) == [0]
+            # the same exchange without the host round trip (round 6): queued on the stream, counts on the device, gs_comm_wait is the synchronising half
+            d_cn = ctx.alloc(16)
+            try:
+                ctx.upload(d_bi, np.zeros(50 * knbn, np.uint64))
+                comm.allgatherv_topk_async_dev(d_i, d_d, nq, 50, knbn, d_bi, d_bd, d_cn)
+                assert list(comm.wait()) == [nq]
+                assert list(ctx.download(d_cn, (2,), np.uint64)) == [nq, 0]
+                assert np.array_equal(ctx.download(d_bi, ids.shape, np.uint64), ids) and np.array_equal(ctx.download(d_bd, dist.shape, np.float32), dist)
+            finally:
+                ctx.free(d_cn)
         finally:
             ctx.free(d_bi); ctx.free(d_bd)
     finally:
