@@ -3,6 +3,7 @@
    rand_xoshiro crate tests against), fxhash constants;
  * the distance -> ANI table of the reference README (README.md:231-242) against reformat.rs:80-86.
 """
+import pytest
 import ctypes as C
 
 import numpy as np
@@ -104,3 +105,27 @@ def test_spec_ln_against_libm():
         assert abs(got - ref) <= 4e-16 * max(1.0, abs(ref)), (x, got, ref)
     # log_b steps of the register formula: 1/LN(1.001) and one register value by hand: x = 1e-8 -> 1 - ln(1e-8)/ln(1.001) = 18430.9...
     assert int(1.0 - L.go_test_ln(1e-8) / L.go_test_ln(1.001)) == 18430
+
+
+@pytest.mark.parametrize("k,m,data", [(12, 64, "dna_fwd"), (14, 96, "dna_fwd"), (7, 50, "dna_fwd"), (12, 64, "dna"), (21, 80, "dna"), (16, 64, "dna")])
+def test_oracle_sketch_equals_an_independent_python_restatement(k, m, data):
+    """golden_v3_fwd.npz is generated by the oracle itself, so it cannot catch a forward-only closure that the oracle and the kernels share
+    but that differs from bindash.rs:346-354. tests/pyref.py restates SPEC.md 1.1 / 2 / 3.1 in pure Python without sharing a line with the oracle: the
+    optdens signatures of small multi-record genomes (N runs, lower case, a record shorter than k, few enough k-mers that densification runs) must agree
+    bit for bit - for the forward-only closure, for the canonical one, and the two closures must differ on the same genome."""
+    import numpy as np
+    import helpers as H
+    import oracle_lib as O
+    import pyref
+    rng = np.random.default_rng(k * 7 + m)
+    a = H.dna_ascii(H.rand_dna(rng, 900))
+    genomes = [[a[:400] + b"NNnn" + a[400:600].lower(), b"ACGT", a[600:]], [a[100:160]], [H.revcomp_ascii(a[:400])]]
+    recs = [r for g in genomes for r in g]
+    goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
+    seq, rs, rl = O.pack_dna(recs)
+    got = O.sketch_batch(O.params(k, m, "optdens", data), seq, rs, rl, goff).view(np.uint32)
+    for gi, g in enumerate(genomes):
+        want = np.array(pyref.optdens(g, k, m, forward_only=(data == "dna_fwd")), dtype=np.uint32)
+        assert np.array_equal(got[gi], want), gi
+    other = O.sketch_batch(O.params(k, m, "optdens", "dna" if data == "dna_fwd" else "dna_fwd"), seq, rs, rl, goff).view(np.uint32)
+    assert not np.array_equal(other[0], got[0])
