@@ -25,10 +25,10 @@ for r in seg:
     k = r["Kernel_Name"].split("(")[0][:70]
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 busy = sum(v[1] for v in agg.values())
-with open("gpurun_out/r05_request_step_trace.txt", "w") as f:
+with open("gpurun_out/r06_request_step_trace.txt", "w") as f:
     f.write("one 10 000-query request (bench.py step), rocprofv3 --kernel-trace: %d launches, %.2f ms from first start to last end, %.2f ms inside kernels\n" % (len(seg), (t1 - t0) / 1e6, busy))
     for k, (n, ms) in sorted(agg.items(), key=lambda x: -x[1][1]):
         f.write("%8.3f ms  %4d x  %s\n" % (ms, n, k))
-print(open("gpurun_out/r05_request_step_trace.txt").read())
+print(open("gpurun_out/r06_request_step_trace.txt").read())
 P
 rm -rf gpurun_out/steptrace
