@@ -464,6 +464,7 @@ def test_sketch_prob_tiered_form_and_its_exact_fallback(gpu_ctx, monkeypatch, ca
         [base[2][:350_000] + b"A" * 90_000 + base[2][350_000:]],                  # poly-A: one k-mer 89 980 times
         [b"ACGT" * 40_000 + base[0][:600_000]],                                   # four k-mers 40 000 times each
         [base[1]],
+        [base[2][i:i + 997] for i in range(0, 700_000, 997)],                     # a draft assembly: 703 contigs of 997 bases (every unit of the walk touches a record boundary)
     ]
     sk = G.sketcher_for(G.SeqSketcherParams(k, m, "prob", "dna"))
     got = sk.sketch_genomes(genomes)
