@@ -143,7 +143,7 @@ constexpr int JTAG_CL_SHIFT = 13;
 constexpr uint32_t JCL_MAX = 2047;      // cluster ids 1..2047
 
 template <int KIND, typename T, int SR, bool CL>
-__global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
+__global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
                                                     uint32_t slot_lo, uint32_t slot_hi, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
                                                     unsigned long long *__restrict__ stats, int chunk_major, uint64_t col0, const uint16_t *__restrict__ qcl,
                                                     const uint16_t *__restrict__ nodelab, const T *__restrict__ qs, uint32_t nh, const uint32_t *__restrict__ cl_lo,
@@ -155,7 +155,11 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                                                                  // insert sees complete entries, so it can flag the entries behind which ANOTHER entry holds the same key:
                                                                  // a hit on an entry without JTAG_MORE ends the probe instead of walking on to the next empty slot)
     constexpr bool DEDUP = CL && E8;                             // ... and a cluster's equal keys can share one entry
-    constexpr bool DENSE = E8;                                   // survivors of the bitmap are compacted per wavefront and probed one per lane (below)
+    constexpr bool D64 = sizeof(T) == 8 && SR == 1 && !CL;      // 8-byte keys (round 6): the same survivor queue; key and tag stay in separate LDS arrays (a CAS holds 8 bytes), so no
+                                                                 // JTAG_MORE - a probe chain ends at the first empty entry - and a queue entry is two 8-byte words {value}, {owner | accumulator}.
+                                                                 // The round-3 form it replaces for request batches ran 312 VALU lane-instructions per (slot, node) element against 64 for 4-byte
+                                                                 // keys (profiles/r06_join_u64_pmc.txt): every lane of a wavefront walked the flattened state machine for one lane's survivor
+    constexpr bool DENSE = E8 || D64;                            // survivors of the bitmap are compacted per wavefront and probed one per lane (below)
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     const uint32_t P = 1u << log2p, mask = P - 1, sh = 32 - log2p;
     constexpr uint32_t BMW = (1u << JB_LOG2) / 32;                // bitmap words per slot
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
             labmask |= ((uint32_t)((l4.x & 0xFFFFu) != 0u) | (uint32_t)((l4.x >> 16) != 0u) << 1 | (uint32_t)((l4.y & 0xFFFFu) != 0u) << 2 | (uint32_t)((l4.y >> 16) != 0u) << 3) << (it * JU);
         }
     }
-    uint2 *wq = (uint2 *)(s_raw + 8 * (size_t)P + (size_t)BMW * 4) + (threadIdx.x >> 6) * 64;
+    uint2 *wq = (uint2 *)(s_raw + (D64 ? 12 : 8) * (size_t)P + (size_t)BMW * 4) + (threadIdx.x >> 6) * (D64 ? 128 : 64);      // D64: entry i = words 2i (value), 2i + 1 (owner | accumulator)
     T vn[DENSE ? JN : JU];
 #pragma unroll
     for (int u = 0; u < (DENSE ? JN : JU); u++) { const uint64_t e = e0 + (uint64_t)u * JT; vn[u] = (e < n && s0 < s1) ? cols[(uint64_t)s0 * colcap + e] : (T)0; }
@@ -286,8 +290,12 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                         const unsigned long long mw = __ballot(want);
                         const uint32_t cw = (uint32_t)__popcll(mw);
                         if (cw != 0u && qn + cw <= 64u) {
-                            if (want) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u))] =
-                                          make_uint2((uint32_t)vn[u], lane | ((uint32_t)u << 6) | (sticky[u] << 9) | (CL ? ((labmask >> u) & 1u) << 29 : 0u));
+                            if (want) {
+                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
+                                const uint32_t who = lane | ((uint32_t)u << 6) | (sticky[u] << 9) | (CL ? ((labmask >> u) & 1u) << 29 : 0u);
+                                if constexpr (D64) { wq[2 * at] = make_uint2((uint32_t)vn[u], (uint32_t)((uint64_t)vn[u] >> 32)); wq[2 * at + 1].x = who; }
+                                else wq[at] = make_uint2((uint32_t)vn[u], who);
+                            }
                             qn += cw; pend &= ~(1u << u);
                         }
                     }
@@ -359,6 +367,32 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                             if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom++; }
                             wq[lane].x = st;
                         }
+                    } else if constexpr (D64) {
+                        if (lane < qn) {
+                            const uint2 q0 = wq[2 * lane];
+                            const uint32_t who = wq[2 * lane + 1].x;
+                            const T val = (T)((uint64_t)q0.x | ((uint64_t)q0.y << 32));
+                            uint32_t st = who >> 9, flp = 0;
+                            const uint32_t eo = (who & 63u) + ((who >> 6) & 7u) * JT - lane;
+                            uint32_t hh = join_hash(val) >> sh;
+                            for (;;) {
+                                const uint32_t t = tag[hh];
+                                if (t == 0u) break;
+                                if (key[hh] == val) {
+                                    const uint32_t tg = t & JTAG_MASK, one = tg | 0x1000u;
+                                    const bool same = (st & 0xFFFu) == tg, weak = st < 0x2000u, full = st >= 0xFF000u;
+                                    const uint32_t fl = same ? (full ? st : 0u) : (weak ? st : one);
+                                    st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
+                                    if (fl) {
+                                        if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                                        flp = fl;
+                                    }
+                                }
+                                hh = (hh + 1) & mask;
+                            }
+                            if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                            wq[2 * lane + 1].x = st;
+                        }
                     } else
                     if (lane < qn) {
                         const uint2 qe = wq[lane];
@@ -396,7 +430,7 @@ __global__ __launch_bounds__(JT, 8) void k_match_join(const T *__restrict__ qkey
                         const bool mine = (queued >> u) & 1u;
                         const unsigned long long mw = __ballot(mine);
                         if (mw != 0ull) {
-                            if (mine) sticky[u] = wq[qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u))].x;
+                            if (mine) { const uint32_t at = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u)); sticky[u] = D64 ? wq[2 * at + 1].x : wq[at].x; }
                             qb += (uint32_t)__popcll(mw);
                         }
                     }
@@ -736,7 +770,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     while (g.log2p < (uint32_t)JP_MAX_LOG2 && (double)(1u << g.log2p) * 0.4 < (double)nq) g.log2p++;
     g.chunks = (uint32_t)((n + (uint64_t)JT * JN - 1) / ((uint64_t)JT * JN));
     g.lds1 = (sizeof(T) + 4) * ((size_t)1 << g.log2p) + ((size_t)1 << JB_LOG2) / 8;
-    g.ldsq = sizeof(T) == 4 ? (size_t)(JT / 64) * 64 * 8 : 0;            // the wavefronts' survivor queues (one-slot rounds of 4-byte keys without clusters)
+    g.ldsq = (size_t)(JT / 64) * 64 * (sizeof(T) == 4 ? 8 : 16);         // the wavefronts' survivor queues (one-slot rounds; 8-byte keys: two words per entry; their cluster variant does not use it)
     const bool may_decline = declined && m >= 64 && n >= 4096;
     const char *ce = getenv("GS_JOIN_CLUSTER");
     // heavy blocks: request batches (the insert path passes no `declined`) large enough for phase 0 to be a small part of the work
