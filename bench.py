@@ -349,7 +349,13 @@ def run_sketch(args, D):
 
 
 _PMC = None
-PMC_DEFAULTS = ("profiles/r05_pmc_sidecar.json", "profiles/r04_pmc_sidecar.json", "profiles/r03_pmc_sidecar.json", "profiles/r02_pmc_sidecar.json")
+def _pmc_defaults():
+    """the committed sidecars, newest round first (profiles/r06_... sorts after r05_...)"""
+    import glob
+    return [os.path.relpath(f, ROOT) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_sidecar.json")), reverse=True)]
+
+
+PMC_DEFAULTS = tuple(_pmc_defaults())
 
 
 def _pmc_load():

@@ -2,7 +2,7 @@
 # final round-6 session: the whole GPU suite, smoke(), the default bench with the committed sidecar
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-( time timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -4 ) > gpurun_out/r06_gpu_suite.txt 2>&1
+( time timeout 3000 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 ) > gpurun_out/r06_gpu_suite.txt 2>&1
 cat gpurun_out/r06_gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 ( time python bench.py > gpurun_out/r06_bench_default.log 2> gpurun_out/r06_bench_default.err ) 2>&1 | tail -3
