@@ -444,7 +444,10 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                     typedef const T __attribute__((address_space(1))) *gptr;       // (an integer cast alone would leave a flat pointer)
                     const gptr cn = (gptr)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cb >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cb));      // (the builtin returns int)
 #pragma unroll
-                    for (int u = 0; u < JN; u++) { const gptr cu = cn + u * JT; vn[u] = ((vmask >> u) & 1u) ? cu[threadIdx.x] : (T)0; }
+                    // (nontemporal: the column store - 21.6 GB per batch at 300 k nodes - is read once; as ordinary loads it flushes the count-matrix window the
+                    // atomics work on out of the 256 MB Infinity Cache. With the chunk-major launch order below, whose live window is a few node chunks' counters,
+                    // 19.3 -> 18.6 ms per 2500-query batch; either alone 19.1 / 19.2: profiles/r06_join_nt_chunk_major.txt)
+                    for (int u = 0; u < JN; u++) { const gptr cu = cn + u * JT; vn[u] = ((vmask >> u) & 1u) ? __builtin_nontemporal_load(cu + threadIdx.x) : (T)0; }
                 }
             } else {
 #pragma unroll
@@ -690,7 +693,9 @@ static int join_launch(gs_ctx *c, const JoinGeom &g, const T *qkey, uint32_t nq,
     if (getenv("GS_JOIN_BLOCKS") && !few_blocks) blocks = (uint32_t)atoi(getenv("GS_JOIN_BLOCKS"));
     blocks = std::min<uint32_t>(std::max<uint32_t>(blocks, 1), ms);
     const uint32_t slots_per_wg = (ms + blocks - 1) / blocks;
-    const int chunk_major = getenv("GS_JOIN_CHUNK_MAJOR") ? atoi(getenv("GS_JOIN_CHUNK_MAJOR")) : 0;
+    // chunk-major: consecutive workgroups sweep the slot blocks of ONE node chunk, so the counters under update at any time are those of a few chunks - with the
+    // nontemporal column loads of the kernel that window stays in the Infinity Cache (request batches; an insert batch's matrix is small either way)
+    const int chunk_major = getenv("GS_JOIN_CHUNK_MAJOR") ? atoi(getenv("GS_JOIN_CHUNK_MAJOR")) : (nq >= 1024 ? 1 : 0);
     const uint32_t nblk = (ms + slots_per_wg - 1) / slots_per_wg;
     dim3 jg(chunk_major ? nblk : chunks, chunk_major ? chunks : nblk);
     // small tables (an insert batch): several slots per barrier round while two workgroups still fit a CU

@@ -386,7 +386,7 @@ def test_sketch_prob_matches_oracle(gpu_ctx, k, m, data):
 
 
 @pytest.mark.parametrize("k,m,data,length", [(21, 1000, "dna", 200000), (16, 512, "dna", 90000), (32, 700, "dna", 120000), (7, 600, "aa", 100000), (21, 18000, "dna", 1600000)])
-@pytest.mark.parametrize("impl", ["buckets", "buckets_one_level", "sort"])
+@pytest.mark.parametrize("impl", ["tiers", "buckets", "buckets_one_level", "sort"])
 def test_sketch_prob_bucketed_form_matches_oracle(gpu_ctx, monkeypatch, k, m, data, length, impl):
     """ProbMinHash3a on genomes with >= 64 k-mers per slot, which take the bucketed form (partition by hash bits -> LDS hash -> (value,
     multiplicity) -> first points under a running rejection threshold; the partition in two levels - coarse scatter + LDS-sorted refinement that
@@ -394,8 +394,12 @@ def test_sketch_prob_bucketed_form_matches_oracle(gpu_ctx, monkeypatch, k, m, da
     list), a genome in two parts workgroups split, multi-record genomes, and small genomes in the same batch (sorted form) - bit-exact
     against the oracle, and the sorted form (GS_PROB_IMPL=sort) gives the same signatures"""
     import gsearch_amd as G
+    # "tiers": the default since round 6 (the tiered form where it suits - here the k = 16, k = 21 / 1.6 Mbp and amino-acid cases - with the bucketed form as its fallback);
+    # "buckets" / "buckets_one_level": GS_PROB_IMPL=buckets keeps the round-4 / round-3 forms under test for every genome they suit (they are the exact fallback)
     if impl == "sort":
         monkeypatch.setenv("GS_PROB_IMPL", "sort")
+    if impl in ("buckets", "buckets_one_level"):
+        monkeypatch.setenv("GS_PROB_IMPL", "buckets")
     if impl == "buckets_one_level":                               # the round-3 partition (one scatter over all buckets, 8-byte values): kept for A/B
         monkeypatch.setenv("GS_PROB_ONELEVEL", "1")
     rng = np.random.default_rng(k * 131 + m)
