@@ -665,7 +665,9 @@ __device__ __forceinline__ void dense_phase2(const IndexDev &ix, const DenseLds 
         deg = ix.deg0[node];
         const uint32_t *row = ix.nbr0 + (uint64_t)node * maxdeg;
 #pragma unroll
-        for (int j = 0; j < NR; j++) { const uint32_t idx = lane + 64 * j; rid[j] = idx < maxdeg ? row[idx] : 0u; }
+        // (nontemporal, like every adjacency row of this kernel: a row is read once per query and only competes with the queries' count rows for the Infinity Cache;
+        // 38.8 -> 38.4 ms per 10 000 queries, two A/B pairs on one box)
+        for (int j = 0; j < NR; j++) { const uint32_t idx = lane + 64 * j; rid[j] = idx < maxdeg ? __builtin_nontemporal_load(row + idx) : 0u; }
     };
     constexpr uint32_t WS = DT / 64;
     for (;;) {
@@ -985,13 +987,14 @@ __global__ __launch_bounds__(DT, OCC) void k_hnsw_search_dense(IndexDev ix, uint
     DenseLds S = carve_dense(s_raw, ix.m, knbn, maxdeg, SPLIT ? (uint64_t)vis_w : ix.n, VLDS, CN);
     // adjacency row of a (wave-uniform) candidate: the node id is pinned to an SGPR so that the row base is scalar and the load takes a
     // 32-bit lane offset instead of a 64-bit per-lane pointer
+#define GS_TRAV_LOAD(p) __builtin_nontemporal_load(p)
 #define GS_DROWX(K, PD, PI)                                                                                                \
     do {                                                                                                                   \
         const uint32_t rid_ = uni32(KID(K));                                                                               \
         uint32_t ho_ = hl4;                                                                                                \
         asm volatile("" : "+v"(ho_));               /* opaque lane offset: keeps the 64-bit row base scalar */            \
         PD = ix.deg0[rid_];                                                                                                \
-        PI = hl < maxdeg ? *(const uint32_t *)((const uint8_t *)(ix.nbr0 + (uint64_t)rid_ * maxdeg) + ho_) : 0;           \
+        PI = hl < maxdeg ? GS_TRAV_LOAD((const uint32_t *)((const uint8_t *)(ix.nbr0 + (uint64_t)rid_ * maxdeg) + ho_)) : 0; \
     } while (0)
 #define GS_DROW(K) GS_DROWX(K, pdeg, pid)
     // per-workgroup global scratch: the visited bitmap (VLDS = false) or the fine histogram bins (VLDS = true)
