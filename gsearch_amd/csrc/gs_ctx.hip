@@ -162,6 +162,14 @@ int gs_ctx_create(gs_ctx **out, int device_id, void *stream)
     GS_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount;
     c->hbm_bytes = prop.totalGlobalMem;
+    {
+        // clockRate / memoryClockRate are kHz, memoryBusWidth bits. The reference is what an MI355X REPORTS (256 CUs, 2 400 000 kHz, 2 000 000 kHz x 8192 bits - its
+        // 8 TB/s are four transfers per reported memory clock; only the ratio matters here). Unreported or implausible values leave 1.0.
+        const double compute = (double)prop.multiProcessorCount * (double)prop.clockRate * 1e3, ref_compute = 256.0 * 2.4e9;
+        const double bw = (double)prop.memoryClockRate * 1e3 * (double)prop.memoryBusWidth / 8.0, ref_bw = 2.0e9 * 1024.0;
+        if (compute > 0.05 * ref_compute && compute < 20.0 * ref_compute) c->rel_compute = compute / ref_compute;
+        if (bw > 0.05 * ref_bw && bw < 20.0 * ref_bw) c->rel_hbm = bw / ref_bw;
+    }
     snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { GS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }

@@ -2399,12 +2399,16 @@ static bool use_join(const gs_index *ix);
 //            n*m element compares at ~1.6e13/s per query - then latency-bound traversals: ~75 ns per evaluation, 768 in flight
 static bool dense_pays(const gs_index *ix, double frac, uint64_t nq)
 {
+    // The six rates below were measured on an MI355X (profiles/). They are scaled by what THIS device reports against that one - streaming rates by the
+    // memory system (rel_hbm), the join's, the tile kernel's and the traversal's by CUs x clock (rel_compute) - instead of being taken as they are;
+    // on the device they were measured on both factors are within a few percent of 1 and the decisions are the measured ones (test_cost_model_picks_..., 5 operating points).
+    const double rc = ix->ctx->rel_compute, rh = ix->ctx->rel_hbm;
     const double n = (double)ix->n, q = (double)std::max<uint64_t>(nq, 1), evals = frac * n;
-    const double gather = evals * (double)ix->rowbytes * std::max(q / 5.5e12, 1.0 / 8.0e10);
+    const double gather = evals * (double)ix->rowbytes * std::max(q / (5.5e12 * rh), 1.0 / (8.0e10 * rh));
     double dense;
-    if (use_join(ix)) dense = n * (double)ix->rowbytes / (nq <= 512 ? 3.5e12 : 1.0e12) * std::ceil(q / (double)match_join_max_queries()) + 3e-3;
-    else dense = std::ceil(q / 128.0) * 128.0 * n * (double)ix->prm.m / (ix->ikind == GS_KIND_U64 ? 1.4e13 : 1.6e13);       // 128-query tiles
-    dense += evals * 75e-9 * std::max(1.0, q / 768.0);
+    if (use_join(ix)) dense = n * (double)ix->rowbytes / ((nq <= 512 ? 3.5e12 : 1.0e12) * rc) * std::ceil(q / (double)match_join_max_queries()) + 3e-3;
+    else dense = std::ceil(q / 128.0) * 128.0 * n * (double)ix->prm.m / ((ix->ikind == GS_KIND_U64 ? 1.4e13 : 1.6e13) * rc);       // 128-query tiles
+    dense += evals * 75e-9 / rc * std::max(1.0, q / 768.0);
     return dense < gather;
 }
 static bool use_join(const gs_index *ix)

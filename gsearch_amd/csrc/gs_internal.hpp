@@ -48,6 +48,9 @@ struct gs_ctx {
     bool own_stream = false;
     int n_cu = 0;
     uint64_t hbm_bytes = 0;
+    // this device against the one the cost model's rates were measured on (MI355X: 256 CUs at 2.4 GHz, 8 TB/s): dense_pays() scales its compute-side rates by
+    // `rel_compute` and its streaming rates by `rel_hbm` instead of assuming that device (1.0 / 1.0 there; gs_ctx_create fills them from hipDeviceProp_t)
+    double rel_compute = 1.0, rel_hbm = 1.0;
     char name[128] = {0};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profile = false;
