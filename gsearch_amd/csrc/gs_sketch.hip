@@ -1433,6 +1433,28 @@ __global__ void k_prob_claim_act(const uint64_t *__restrict__ akey, const uint32
 static int run_prob_sorted(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, uint64_t seq_bytes, const uint64_t *rec_start, const uint64_t *rec_len,
                            uint64_t n_rec, const uint64_t *genome_rec_off, uint64_t n_genomes, void *sig_out);
 
+// Genomes that will be redone anyway must not keep the pass loop alive (round 6, found by tools/prob_fuzz.py): a flagged genome can be left with an EMPTY slot - its largest slot
+// minimum is then +inf, no element of it ever falls out of "w^-1 (pass - 1) <= max q", and the loop over passes >= 2 never ended. Their multiplicity bound is zeroed on
+// the device (k_prob_fold skips a genome with wmax == 0) and the count of active genomes recomputed from the survivors.
+static int prob_retire_flagged(gs_ctx *c, const std::vector<uint8_t> &redo, uint32_t ng, uint32_t *wmax_dev, const double *qmax_dev, uint32_t &na)
+{
+    bool any = false;
+    for (uint32_t i = 0; i < ng; i++) any |= redo[i] != 0;
+    if (!any) return GS_OK;
+    std::vector<uint32_t> hw(ng); std::vector<double> hq(ng);
+    GS_HIP_CHECK(hipMemcpyAsync(hw.data(), wmax_dev, 4 * (size_t)ng, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(hq.data(), qmax_dev, 8 * (size_t)ng, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    na = 0;
+    for (uint32_t i = 0; i < ng; i++) {
+        if (redo[i]) hw[i] = 0;
+        else if (hw[i] > 0 && !((1.0 / (double)hw[i]) * 1.0 > hq[i])) na++;       // (k_prob_fold's rule after pass 1)
+    }
+    GS_HIP_CHECK(hipMemcpyAsync(wmax_dev, hw.data(), 4 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
 // one chunk of genomes [g0, g0 + ng) through the bucketed form; hk = k-mers per genome (host). *redo (ng flags, host) marks genomes that
 // must be redone by the sorted form; returns GS_OK with every flag set when a list overflowed.
 static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *upre,
@@ -1566,6 +1588,7 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
     if (hc[2] > ovf_cap || hc[3] > act_cap) { redo.assign(ng, 1); return GS_OK; }      // a list overflowed: the whole chunk goes the sorted way
     for (uint32_t i = 0; i < ng; i++) redo[i] = hovf[i] ? 1 : 0;
     uint32_t na = hc[4];
+    if ((rc = prob_retire_flagged(c, redo, ng, wmax.as<uint32_t>(), qmax.as<double>(), na))) return rc;
     const uint32_t n_list = hc[3];
     if (na && n_list) {
         if ((rc = ph.alloc((size_t)8 * n_list)) || (rc = pb.alloc((size_t)4 * n_list))) return rc;
@@ -1581,6 +1604,7 @@ static int run_prob_buckets(gs_ctx *c, const gs_sketch_params *p, const uint8_t 
             GS_HIP_CHECK(hipGetLastError());
             GS_HIP_CHECK(hipMemcpyAsync(&na, ctr32 + 4, 4, hipMemcpyDeviceToHost, c->stream));
             GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (getenv("GS_PROB_VERBOSE") && (it < 8 || (it & (it - 1)) == 0)) fprintf(stderr, "[GS_PROB] pass %u done: %u genomes still active, %u elements on the active list\n", it, na, n_list);
         }
     }
     if (sigbits == 32) hipLaunchKernelGGL(k_prob_write<uint32_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint32_t *)sig_rows);
@@ -2250,7 +2274,11 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
     if (hc[2] > ovf_cap || hc[3] > act_cap) { redo.assign(ng, 1); return GS_OK; }
     // the speculation is checked here: q only decreases in later passes, so a maximum under the cap after pass 1 stays there
     for (uint32_t i = 0; i < ng; i++) redo[i] = (hovf[i] || !(hq[i] <= capd[i])) ? 1 : 0;
+    if (getenv("GS_PROB_VERBOSE"))
+        for (uint32_t i = 0; i < ng; i++) if (redo[i]) fprintf(stderr, "[GS_PROB] tiered form: genome %llu flagged (%s; max slot minimum %g, cap %g)\n", (unsigned long long)(g0 + i),
+                                                               hovf[i] ? "a slice, the kept-id queue or a table overflowed" : "cap not confirmed", hq[i], capd[i]);
     uint32_t na = hc[4];
+    if ((rc = prob_retire_flagged(c, redo, ng, wmax.as<uint32_t>(), qmax.as<double>(), na))) return rc;
     const uint32_t n_list = hc[3];
     if (na && n_list) {
         if ((rc = ph.alloc((size_t)8 * n_list)) || (rc = pb.alloc((size_t)4 * n_list))) return rc;
@@ -2266,6 +2294,7 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
             GS_HIP_CHECK(hipGetLastError());
             GS_HIP_CHECK(hipMemcpyAsync(&na, ctr32 + 4, 4, hipMemcpyDeviceToHost, c->stream));
             GS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (getenv("GS_PROB_VERBOSE") && (it < 8 || (it & (it - 1)) == 0)) fprintf(stderr, "[GS_PROB] pass %u done: %u genomes still active, %u elements on the active list\n", it, na, n_list);
         }
     }
     if (sigbits == 32) hipLaunchKernelGGL(k_prob_write<uint32_t>, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), sig.as<uint64_t>(), ng * (uint64_t)m, (uint32_t *)sig_rows);

@@ -483,6 +483,18 @@ def test_sketch_prob_tiered_form_and_its_exact_fallback(gpu_ctx, monkeypatch, ca
         assert "[0," in err
 
 
+def test_prob_differential_run_over_random_shapes():
+    """tools/prob_fuzz.py (round 6): the ProbMinHash3a sketcher against the oracle over random k / sketch sizes / genome sizes around the thresholds of its forms / records /
+    repeats / poly-A runs. Its third case (seed 1) is the one that hung the round-6 code for good: a genome flagged by the tiered form (slice overflow) was left with an
+    EMPTY slot - largest slot minimum +inf - while another genome's repeats sat on the active list, and the loop over passes >= 2 waited for the flagged genome to fall
+    out of "w^-1 (pass - 1) <= max q". Twelve cases, bounded time, zero mismatches."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "prob_fuzz.py"), "12", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "12 cases, 0 mismatches" in out.stdout, out.stdout[-1500:]
+
+
 def test_index_dump_and_reload(gpu_ctx, tmp_path):
     """file_dump / load round trip (own format): identical graph, data and answers; `add` continues on the reloaded index"""
     import gsearch_amd as G
