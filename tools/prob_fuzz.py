@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Differential run of the ProbMinHash3a sketcher (tiered form and its fallbacks) against the oracle over random shapes: k, sketch size, genome sizes around the
-thresholds of the tiered form, records, N runs, repeats of random multiplicity, poly-A runs. usage: prob_fuzz.py [cases] [seed]   (GS_PROB_VERBOSE=1 to see the fallbacks)"""
+"""Differential run of a sketcher (default ProbMinHash3a: the tiered form and its fallbacks) against the oracle over random shapes: k, sketch size, genome sizes around the
+thresholds of the kernels' forms, records, N runs, repeats of random multiplicity, poly-A runs. usage: prob_fuzz.py [cases] [seed] [algo: prob|optdens|revoptdens|super|super2|hll|any]
+(GS_PROB_VERBOSE=1 to see the fallbacks of prob)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,8 +12,10 @@ import oracle_lib as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ALGO = sys.argv[3] if len(sys.argv) > 3 else "prob"
 bad = 0
 for case in range(cases):
+    algo = ALGO if ALGO != "any" else str(rng.choice(["prob", "optdens", "revoptdens", "super", "super2", "hll"]))
     data = "aa" if rng.random() < 0.2 else "dna"
     if data == "dna":
         k = int(rng.choice([8, 11, 12, 14, 16, 17, 19, 21, 21, 21, 24, 32]))
@@ -46,16 +49,16 @@ for case in range(cases):
         genomes.append(recs)
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != case:
         continue
-    sk = G.sketcher_for(G.SeqSketcherParams(k, m, "prob", data))
+    sk = G.sketcher_for(G.SeqSketcherParams(k, m, algo, data))
     t0 = time.perf_counter()
     got = sk.sketch_genomes(genomes)
     t1 = time.perf_counter()
     flat = [r for g in genomes for r in g]
     goff = np.cumsum([0] + [len(g) for g in genomes]).astype(np.uint64)
     seq, rs, rl = (O.pack_dna(flat) if data == "dna" else O.filter_aa(flat))
-    ref = O.sketch_batch(O.params(k, m, "prob", data), seq, rs, rl, goff, nthreads=os.cpu_count())
-    ok = got.dtype == ref.dtype and np.array_equal(got, ref)
+    ref = O.sketch_batch(O.params(k, m, algo, data), seq, rs, rl, goff, nthreads=os.cpu_count())
+    ok = got.dtype == ref.dtype and np.array_equal(got.view(np.uint8), ref.view(np.uint8))
     bad += not ok
-    print("case %2d %s k=%d m=%d genomes=%s: %s (device %.0f ms)" % (case, data, k, m, [sum(len(r) for r in g) for g in genomes], "ok" if ok else "MISMATCH rows %s" % np.nonzero((got != ref).any(axis=1))[0].tolist(), (t1 - t0) * 1e3), flush=True)
+    print("case %2d %s %s k=%d m=%d genomes=%s: %s (device %.0f ms)" % (case, algo, data, k, m, [sum(len(r) for r in g) for g in genomes], "ok" if ok else "MISMATCH rows %s" % np.nonzero((got.view(np.uint8).reshape(len(got), -1) != ref.view(np.uint8).reshape(len(ref), -1)).any(axis=1))[0].tolist(), (t1 - t0) * 1e3), flush=True)
 print("%d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)
