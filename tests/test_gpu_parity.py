@@ -495,6 +495,18 @@ def test_prob_differential_run_over_random_shapes():
     assert "12 cases, 0 mismatches" in out.stdout, out.stdout[-1500:]
 
 
+def test_sketchers_and_hnsw_differential_runs():
+    """the same differential idea over every sketcher (`prob_fuzz.py .. any`: optdens / revoptdens / super / super2 / hll / prob on random k, sizes, records, repeats) and over the
+    HNSW build + search (`hnsw_fuzz.py`: random element type, sketch size, M, ef_construction, level scale, family structure with duplicates, insert batch and calls, knbn / ef,
+    every distance strategy - device-built graph == oracle graph, answers and evaluation counts == oracle search). Bounded: 12 + 10 cases."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "prob_fuzz.py"), "12", "23", "any"], capture_output=True, text=True, timeout=900)
+    assert a.returncode == 0 and "12 cases, 0 mismatches" in a.stdout, (a.stdout[-1500:], a.stderr[-800:])
+    b = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "hnsw_fuzz.py"), "10", "4"], capture_output=True, text=True, timeout=1200)
+    assert b.returncode == 0 and "10 cases, 0 mismatches" in b.stdout, (b.stdout[-1500:], b.stderr[-800:])
+
+
 def test_index_dump_and_reload(gpu_ctx, tmp_path):
     """file_dump / load round trip (own format): identical graph, data and answers; `add` continues on the reloaded index"""
     import gsearch_amd as G
