@@ -213,3 +213,15 @@ def test_sketch_files_bgzf_members_on_the_device(gpu_ctx, tmp_path):
     assert st["gz_members_handed_back_to_host"] == 4             # the four ordinary multi-member files; every bgzip file stayed on the device
     bl = sk.sketch_files(comp, block=True)[0]
     assert np.array_equal(bl.view(np.uint32), sk.sketch_files(plain, block=True)[0].view(np.uint32))
+
+
+def test_inflate_and_ingest_differential_runs():
+    """round 6: random members against zlib through every form of the device decoder, with bit flips that must never come back as "status 0, other bytes"
+    (tools/inflate_fuzz.py), and random FASTA files - headers with `capsid`, empty / short records, CRLF, blank lines, no final newline, plain / gzip / multi-member /
+    bgzip-like, by-sequence and --block, DNA and amino acids - through gs_sketch_files against an independent Python reading of the files + the oracle (tools/ingest_fuzz.py)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "inflate_fuzz.py"), "2", "3"], capture_output=True, text=True, timeout=900)
+    assert a.returncode == 0 and "2 rounds, 0 failures" in a.stdout, (a.stdout[-1500:], a.stderr[-800:])
+    b = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "ingest_fuzz.py"), "5", "3"], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0 and "5 rounds, 0 wrong files" in b.stdout, (b.stdout[-1500:], b.stderr[-800:])
