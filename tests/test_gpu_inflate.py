@@ -1,6 +1,7 @@
 """Device-side gzip (gs_inflate.hip, the .gz path of gs_sketch_files) against zlib: the text a member inflates to must be byte-identical
 for every block type and table shape the encoders in this image can produce, and damaged members must be reported, not decoded."""
 import gzip
+import os
 import io
 import zlib
 
