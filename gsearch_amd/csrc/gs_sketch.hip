@@ -2342,6 +2342,15 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
         }
     auto suits_tiers = [&](uint64_t g) { return lgs[g] != 0xFFFFFFFFu; };
     const uint64_t max_items = (uint64_t)3 << 29;                 // ~1.6e9 k-mers per chunk (12.9 GB of bucketed values)
+    // the tiered form's chunks: ~8 bytes of scratch per k-mer (slices of 4-byte ids with their slack, kept ids, lists), so twice the k-mers of a bucketed chunk where a quarter of
+    // the free device memory holds them (2048 x 5 Mbp: 1.07e11 k-mers/s at 1.6e9 per chunk, 1.11e11 at 3.2e9, 1.13e11 at 6.4e9 - a chunk ends in a host round trip)
+    uint64_t tier_items = 2 * max_items;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) tier_items = std::min<uint64_t>(tier_items, std::max<uint64_t>(max_items / 4, (uint64_t)fr / 4 / 8));
+        else (void)hipGetLastError();
+        if (getenv("GS_PROB_CHUNK_KMERS")) tier_items = std::max<uint64_t>(1, (uint64_t)atoll(getenv("GS_PROB_CHUNK_KMERS")));
+    }
     // [a, b) through the bucketed form where it suits, else (and what it flags) through the sorted form
     auto old_range = [&](uint64_t a, uint64_t b) -> int {
         for (uint64_t g0 = a; g0 < b;) {
@@ -2379,7 +2388,7 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
             continue;
         }
         uint64_t T = hk[g0];
-        while (g1 < n_genomes && suits_tiers(g1) && g1 - g0 < 65535 && T + hk[g1] <= max_items) { T += hk[g1]; g1++; }
+        while (g1 < n_genomes && suits_tiers(g1) && g1 - g0 < 65535 && T + hk[g1] <= tier_items) { T += hk[g1]; g1++; }
         std::vector<uint8_t> redo;
         if ((rc = run_prob_tiers(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, lgs.data() + g0, pc,
                                  (uint8_t *)sig_out + row * g0, redo))) return rc;
