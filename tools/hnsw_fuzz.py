@@ -40,6 +40,21 @@ for case in range(cases):
     q[mq] = rnd(q.shape)[mq]
     knbn = int(rng.choice([1, 5, 10, 50])); ef = int(rng.choice([knbn, 2 * knbn + 3, 100, 500]))
     ext = bool(rng.random() < 0.8)
+    # FUZZ_KNOBS=1: the paths larger indexes take, forced on small ones - no dense pair cache (sparse rows, short lists, no level bitmaps), insert batches joined one by one /
+    # in small groups, the split / global visited bitmap, the sorted-array layer-0 search of inserts, the sequential traversal without the order-free phase
+    knobs = {}
+    if os.environ.get("FUZZ_KNOBS"):
+        if rng.random() < 0.5: knobs["GS_PAIR_CACHE_GB"] = "0"
+        if rng.random() < 0.3: knobs["GS_SPARSE_L"] = str(int(rng.choice([8, 64, 512])))
+        if rng.random() < 0.2: knobs["GS_SPARSE_BITMAP_GB"] = "0"
+        if rng.random() < 0.3: knobs["GS_INSERT_GROUP"] = str(int(rng.choice([1, 2, 5])))
+        if rng.random() < 0.3: knobs["GS_DENSE_VIS"] = str(rng.choice(["split", "global"])); knobs["GS_SPLIT_W"] = "1024"
+        if rng.random() < 0.2: knobs["GS_PLAN_PREPASS"] = "0"
+        if rng.random() < 0.2: knobs["GS_DENSE_PHASE2"] = "0"
+        if rng.random() < 0.2: knobs["GS_JOIN_CLUSTER"] = "2"
+        if rng.random() < 0.5: knobs["GS_DIST_MODE"] = "dense"        # (for the INSERTS: the searches below set their own)
+    for kk, vv in knobs.items():
+        os.environ[kk] = vv
     t0 = time.perf_counter()
     oix = O.Index(dtype, m, M, efc, scale_modify=scale, extend_candidates=ext, seed=case + 3)
     hn = G.Hnsw.new(M, max(n, 1024), 16, efc, G.DistHamming(), dtype=dtype, seed=case + 3, insert_batch=ib)
@@ -69,9 +84,12 @@ for case in range(cases):
             if not np.array_equal(xv, yv):
                 why.append("%s search %s" % (mode, name))
     os.environ.pop("GS_DIST_MODE", None)
+    for kk in knobs:
+        os.environ.pop(kk, None)
     hn.close()
     bad += bool(why)
     print("case %2d %s m=%d M=%d efc=%d scale=%.2f ib=%d n=%d roots=%d universe=%d ext=%d nq=%d knbn=%d ef=%d calls=%d: %s (%.1f s)"
-          % (case, np.dtype(dtype).name, m, M, efc, scale, ib, n, n_roots, universe, ext, nq, knbn, ef, len(cuts) - 1, "ok" if not why else "MISMATCH " + "; ".join(why), time.perf_counter() - t0), flush=True)
+          % (case, np.dtype(dtype).name, m, M, efc, scale, ib, n, n_roots, universe, ext, nq, knbn, ef, len(cuts) - 1, "ok" if not why else "MISMATCH " + "; ".join(why), time.perf_counter() - t0)
+          + (" knobs " + " ".join("%s=%s" % kv for kv in sorted(knobs.items())) if knobs else ""), flush=True)
 print("%d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)
