@@ -2390,8 +2390,17 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
         uint64_t T = hk[g0];
         while (g1 < n_genomes && suits_tiers(g1) && g1 - g0 < 65535 && T + hk[g1] <= tier_items) { T += hk[g1]; g1++; }
         std::vector<uint8_t> redo;
-        if ((rc = run_prob_tiers(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, lgs.data() + g0, pc,
-                                 (uint8_t *)sig_out + row * g0, redo))) return rc;
+        rc = run_prob_tiers(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, lgs.data() + g0, pc,
+                            (uint8_t *)sig_out + row * g0, redo);
+        if (rc == GS_ERR_HIP) {                                      // its scratch did not fit (an index with its pair cache beside the sketcher): the chunk takes the older forms, which
+            (void)hipGetLastError();                                  // work in smaller chunks and have their own ways down
+            (void)hipStreamSynchronize(c->stream);
+            if (getenv("GS_PROB_VERBOSE")) fprintf(stderr, "[GS_PROB] tiered form: no room for the scratch of genomes [%llu, %llu) (%s): the bucketed form takes them\n", (unsigned long long)g0,
+                                                   (unsigned long long)g1, gs_last_error());
+            redo.assign(g1 - g0, 1);
+            rc = GS_OK;
+        }
+        if (rc) return rc;
         for (uint64_t g = g0; g < g1;) {                              // flagged genomes (slice / table overflow, cap not confirmed), in runs: the exact fallback
             if (!redo[g - g0]) { g++; continue; }
             uint64_t h = g + 1;
