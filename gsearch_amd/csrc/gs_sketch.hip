@@ -1897,6 +1897,7 @@ __global__ __launch_bounds__(PT2_T, 8) void k_prob_tier_filter(const uint32_t *_
     // (jpos, gl) of item = jpos ng + gl, stepped without a division per bucket (a 64-bit division is ~150 instructions: a fifth of a bucket's work)
     const uint32_t dj = gridDim.x / ng, dg = gridDim.x % ng;
     uint32_t jpos = blockIdx.x / ng, gl = blockIdx.x % ng;
+    const uint64_t k_one = (uint64_t)(0x1.0p52 / pc.c1 * (1.0 - 0x1.0p-40));
     for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x, jpos += dj, gl += dg) {
         if (gl >= ng) { gl -= ng; jpos++; }
         const uint32_t sh = g_sh[gl], lg = vbits - sh, rs = lg_max - lg;
@@ -1940,10 +1941,7 @@ __global__ __launch_bounds__(PT2_T, 8) void k_prob_tier_filter(const uint32_t *_
         for (int u = 0; u < KPL; u++) { kreg[u] = 0; if ((uint32_t)u < NU && key_at(u, kreg[u])) kval |= 1u << u; }
         // the genome's cap (q[] moves only in the second kernel), as thresholds on the 52 uniform bits K of the first draw x0 = c1 K 2^-52: x0 < 1 for K < k_one, and
         // x0 > c thr for K > c t_one - both with a margin of 2^-40 relative on the safe side (a k-mer that is kept needlessly costs time, never the result)
-        const double thr_d = __longlong_as_double((long long)thr[gl]);
-        const uint64_t k_one = (uint64_t)(0x1.0p52 / pc.c1 * (1.0 - 0x1.0p-40));
-        const double t1d = thr_d / pc.c1 * 0x1.0p52 * (1.0 + 0x1.0p-40) + 4.0;      // (+ 4: the roundings of this line and the truncation below leave t_one >= the exact product + 1)
-        const uint64_t t_one = t1d < 0x1.0p52 ? (uint64_t)t1d : ((uint64_t)1 << 52);
+        const uint64_t t_one = thr[ng + gl];                       // (the host's: run_prob_tiers)
         __syncthreads();                                           // the previous bucket's LDS is dead
         for (uint32_t s = threadIdx.x; s < PT_CM / 8; s += PT2_T) ((uint4 *)cm)[s] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) s_ns = 0;
@@ -2146,9 +2144,10 @@ __global__ __launch_bounds__(T) void k_prob_tier_points(const uint32_t *__restri
 // one chunk of genomes [g0, g0 + ng) through the tiered form; lgs = log2(buckets) per genome (host plan). redo as run_prob_buckets.
 static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *upre,
                           const uint64_t *genome_rec_off, const uint64_t *gunits, uint64_t g0, uint32_t ng, const uint64_t *hk, const uint32_t *lgs, const ProbConst &pc,
-                          void *sig_rows, std::vector<uint8_t> &redo)
+                          void *sig_rows, std::vector<uint8_t> &redo, bool &no_room)
 {
     const uint32_t m = p->sketch_size, k = p->k;
+    no_room = false;
     const bool aa = p->data_t == GS_DATA_AA;
     const int sigbits = gs_value_bits(p);
     const uint64_t zone = uint_zone(m);
@@ -2166,7 +2165,7 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
     }
     if (getenv("GS_PROB_PARTS")) { parts = 1; const uint32_t want = (uint32_t)atoi(getenv("GS_PROB_PARTS")); while (parts * 2 <= want && parts < 32) parts *= 2; }
     // per genome: shift, flat bucket offset, slice capacity (mean + 5 sigma of a slice's Poisson-like fill), offset of its slices (in 4-byte ids)
-    std::vector<uint32_t> info(3 * (size_t)ng + 1); std::vector<uint64_t> vbase(ng); std::vector<uint64_t> capbits(ng); std::vector<double> capd(ng);
+    std::vector<uint32_t> info(3 * (size_t)ng + 1); std::vector<uint64_t> vbase(ng); std::vector<uint64_t> capbits(2 * (size_t)ng); std::vector<double> capd(ng);      // capbits: [ng] caps, then [ng] t_one (below)
     uint32_t *sh = info.data(), *boff = sh + ng, *cap = boff + ng + 1;
     uint64_t T32 = 0;
     const double cap_c = getenv("GS_PROB_CAP_C") ? atof(getenv("GS_PROB_CAP_C")) : 10.0;     // P(a genome fails the check) = e^-c
@@ -2180,6 +2179,10 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
         const double t = (double)m / (double)hk[i] * (log((double)m) + cap_c);
         capd[i] = t > 0.0 ? t : 0x1.0p-1000;
         memcpy(&capbits[i], &capd[i], 8);
+        // the cap as a threshold on the 52 uniform bits K of a first draw x0 = c1 K 2^-52 (k_prob_tier_filter): x0 > c cap for K > c t_one, with a margin of 2^-40 relative
+        // on the safe side (+ 4: the roundings of this line and the truncation leave t_one >= the exact product + 1) - once per genome here, not per bucket and lane there
+        const double t1d = capd[i] / pc.c1 * 0x1.0p52 * (1.0 + 0x1.0p-40) + 4.0;
+        capbits[ng + i] = t1d < 0x1.0p52 ? (uint64_t)t1d : ((uint64_t)1 << 52);
     }
     boff[ng] = nbt;
     PoolBuf dinfo(c, 0), dvb(c, 2), cnt(c, 3), vals(c, 8), q(c, 9), qprev(c, 10), sig(c, 11), sigpass(c, 12), thr(c, 13), wmax(c, 14), qmax(c, 15), ctr(c, 7);
@@ -2193,16 +2196,18 @@ static int run_prob_tiers(gs_ctx *c, const gs_sketch_params *p, const uint8_t *s
     const uint32_t pts_max = (uint32_t)c->n_cu * 32;              // blocks of the wavefront-per-bucket kernel at most (segment counts)
     if ((rc = dinfo.alloc(4 * info.size())) || (rc = dvb.alloc(8 * (size_t)ng)) || (rc = cnt.alloc((size_t)4 * nbt * parts)) || (rc = vals.alloc(4 * (size_t)T32 + 64)) ||
         (rc = q.alloc((size_t)8 * ng * m)) || (rc = qprev.alloc((size_t)8 * ng * m)) || (rc = sig.alloc((size_t)8 * ng * m)) || (rc = sigpass.alloc((size_t)8 * ng * m)) ||
-        (rc = thr.alloc(8 * (size_t)ng)) || (rc = wmax.alloc(4 * (size_t)ng)) || (rc = qmax.alloc(8 * (size_t)ng)) || (rc = ctr.alloc(64)) ||
+        (rc = thr.alloc(16 * (size_t)ng)) || (rc = wmax.alloc(4 * (size_t)ng)) || (rc = qmax.alloc(8 * (size_t)ng)) || (rc = ctr.alloc(64)) ||
         (rc = cv.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = chh.alloc((size_t)8 * (cand_cap + ovf_cap))) || (rc = cgb.alloc((size_t)8 * (cand_cap + ovf_cap))) ||
         (rc = ovf.alloc(4 * (size_t)ng)) || (rc = segn.alloc((size_t)4 * pts_max)) || (rc = kept.alloc(4 * (size_t)kept_cap + 64)) || (rc = desc.alloc(8 * (size_t)nbt)) ||
         (rc = big.alloc(4 * (size_t)big_cap)) ||
-        (rc = akey.alloc((size_t)8 * act_cap)) || (rc = agl.alloc((size_t)4 * act_cap)) || (rc = acnt.alloc((size_t)4 * act_cap)) || (rc = astate.alloc((size_t)32 * act_cap)))
+        (rc = akey.alloc((size_t)8 * act_cap)) || (rc = agl.alloc((size_t)4 * act_cap)) || (rc = acnt.alloc((size_t)4 * act_cap)) || (rc = astate.alloc((size_t)32 * act_cap))) {
+        no_room = true;                                               // (the one failure the caller answers with the older forms; anything later is an error)
         return rc;
+    }
     const uint32_t *d_sh = dinfo.as<uint32_t>(), *d_boff = d_sh + ng, *d_cap = d_boff + ng + 1;
     GS_HIP_CHECK(hipMemcpyAsync(dinfo.p, info.data(), 4 * info.size(), hipMemcpyHostToDevice, c->stream));
     GS_HIP_CHECK(hipMemcpyAsync(dvb.p, vbase.data(), 8 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
-    GS_HIP_CHECK(hipMemcpyAsync(thr.p, capbits.data(), 8 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+    GS_HIP_CHECK(hipMemcpyAsync(thr.p, capbits.data(), 16 * (size_t)ng, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_prob_init, dim3(c->n_cu * 4), dim3(256), 0, c->stream, q.as<uint64_t>(), qprev.as<uint64_t>(), sig.as<uint64_t>(), sigpass.as<uint64_t>(), ng * (uint64_t)m);
     {
         std::vector<uint32_t> ones(ng, 1u);
@@ -2389,10 +2394,10 @@ static int run_prob(gs_ctx *c, const gs_sketch_params *p, const uint8_t *seq, ui
         }
         uint64_t T = hk[g0];
         while (g1 < n_genomes && suits_tiers(g1) && g1 - g0 < 65535 && T + hk[g1] <= tier_items) { T += hk[g1]; g1++; }
-        std::vector<uint8_t> redo;
+        std::vector<uint8_t> redo; bool no_room = false;
         rc = run_prob_tiers(c, p, seq, rec_start, rec_len, upre.as<uint64_t>(), genome_rec_off, gunits.as<uint64_t>(), g0, (uint32_t)(g1 - g0), hk.data() + g0, lgs.data() + g0, pc,
-                            (uint8_t *)sig_out + row * g0, redo);
-        if (rc == GS_ERR_HIP) {                                      // its scratch did not fit (an index with its pair cache beside the sketcher): the chunk takes the older forms, which
+                            (uint8_t *)sig_out + row * g0, redo, no_room);
+        if (rc && no_room) {                                      // its scratch did not fit (an index with its pair cache beside the sketcher): the chunk takes the older forms, which
             (void)hipGetLastError();                                  // work in smaller chunks and have their own ways down
             (void)hipStreamSynchronize(c->stream);
             if (getenv("GS_PROB_VERBOSE")) fprintf(stderr, "[GS_PROB] tiered form: no room for the scratch of genomes [%llu, %llu) (%s): the bucketed form takes them\n", (unsigned long long)g0,
