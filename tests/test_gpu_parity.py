@@ -481,6 +481,8 @@ def test_sketch_prob_tiered_form_and_its_exact_fallback(gpu_ctx, monkeypatch, ca
     assert flagged, err[-500:]                                  # (default / two_walk: the poly-A and the 4-k-mer genome; cap_fails: every genome)
     if mode == "cap_fails":
         assert "[0," in err
+    else:                                                       # the tiered form itself must have run: a plain random genome is never flagged, and its scratch fits
+        assert "no room for the scratch" not in err and "flagged genomes [0," not in err, err[-800:]
 
 
 def test_prob_differential_run_over_random_shapes():
