@@ -82,6 +82,9 @@ __device__ __forceinline__ uint32_t join_hash(uint32_t k) { return k * 0x9E3779B
 __device__ __forceinline__ uint32_t join_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }
 #define GS_SEL4(a, i) (((i) & 2) ? (((i) & 1) ? a[3] : a[2]) : (((i) & 1) ? a[1] : a[0]))
 
+#ifndef GS_JOIN_COUNT_KIND
+#define GS_JOIN_COUNT_KIND 0      // what `natom` counts: 0 the memory-side atomics (the product); 1..6: tools/join_atomics_kinds.sh
+#endif
 constexpr int JN = 8;             // nodes per lane: a workgroup owns JT * JN nodes for a whole block of slots
 // Barrier that only orders LDS traffic (the hash table of a slot): a __syncthreads() also waits for vmcnt(0), i.e. for every count atomic
 // and column prefetch the wave has in flight - three times per slot
@@ -409,16 +412,20 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                 const uint32_t tg = t & JTAG_MASK, one = tg | 0x1000u;
                                 const bool same = (st & 0xFFFu) == tg, weak = st < 0x2000u, full = st >= 0xFF000u;
                                 const uint32_t fl = same ? (full ? st : 0u) : (weak ? st : one);
+                                if (GS_JOIN_COUNT_KIND == 1 && !same && !weak) natom++;       // (instrumented builds only: what the atomics are made of)
+                                if (GS_JOIN_COUNT_KIND == 2 && !same && weak && st) natom++;
+                                if (GS_JOIN_COUNT_KIND == 5) natom++;
+                                if (GS_JOIN_COUNT_KIND == 6 && same) natom++;
                                 st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
                                 if (fl) {
-                                    if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                                    if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom += GS_JOIN_COUNT_KIND == 0; }
                                     flp = fl;
                                 }
                                 if (!(t & JTAG_MORE)) break;                                // the last entry with this key
                             }
                             hh = (hh + 1) & mask;
                         }
-                        if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                        if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom += GS_JOIN_COUNT_KIND == 0; }
                         wq[lane].x = st;
                     }
                     join_wave_sync();
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
         }
     }
 #pragma unroll
-    for (int i = 0; i < JN; i++) if (sticky[i]) { join_flush(mm32, ld, sticky[i], col0 + e0 + (uint64_t)i * JT); natom++; }
+    for (int i = 0; i < JN; i++) if (sticky[i]) { join_flush(mm32, ld, sticky[i], col0 + e0 + (uint64_t)i * JT); natom += GS_JOIN_COUNT_KIND == 0 || (GS_JOIN_COUNT_KIND == 3 && sticky[i] >= 0x2000u) || (GS_JOIN_COUNT_KIND == 4 && sticky[i] < 0x2000u); }
     if (stats) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) natom += __shfl_down(natom, o);
