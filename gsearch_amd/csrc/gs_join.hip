@@ -144,14 +144,16 @@ __device__ __forceinline__ void join_flush(uint32_t *mm32, uint64_t ld, uint32_t
 constexpr uint32_t JTAG_MASK = 0xFFFu, JTAG_MULTI = 0x1000u, JTAG_MORE = 0x80000000u;
 constexpr int JTAG_CL_SHIFT = 13;
 constexpr uint32_t JCL_MAX = 2047;      // cluster ids 1..2047
+constexpr int JWALK = 4;                // table entries the in-place own-cluster test of a node's value looks at (k_match_join, CL)
 
 template <int KIND, typename T, int SR, bool CL>
 __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_match_join(const T *__restrict__ qkey, uint32_t nq, uint32_t log2p, const T *__restrict__ cols, uint64_t colcap, uint64_t n,
                                                     uint32_t slot_lo, uint32_t slot_hi, uint32_t slots_per_wg, uint32_t *__restrict__ mm32, uint64_t ld,
                                                     unsigned long long *__restrict__ stats, int chunk_major, uint64_t col0, const uint16_t *__restrict__ qcl,
                                                     const uint16_t *__restrict__ nodelab, const T *__restrict__ qs, uint32_t nh, const uint32_t *__restrict__ cl_lo,
-                                                    const uint32_t *__restrict__ qlist, uint32_t dedup_below)
+                                                    const uint32_t *__restrict__ qlist, uint32_t dedup_flags)
 {
+    const uint32_t dedup_below = dedup_flags & 0x7FFFFFFFu;      // bit 31: the in-place own-cluster test (below) is on for this launch
     static_assert(JU == 4 && JN % JU == 0, "GS_SEL4 / pending mask are written for JU = 4");
     static_assert(!CL || SR == 1, "clusters: request batches only");
     constexpr bool E8 = sizeof(T) == 4 && SR == 1;               // 4-byte keys, one slot per round: key + tag word in ONE 8-byte entry (a probe step is one LDS read; an
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
             labmask |= ((uint32_t)((l4.x & 0xFFFFu) != 0u) | (uint32_t)((l4.x >> 16) != 0u) << 1 | (uint32_t)((l4.y & 0xFFFFu) != 0u) << 2 | (uint32_t)((l4.y >> 16) != 0u) << 3) << (it * JU);
         }
     }
+    const bool wave_lab = CL && DENSE && (dedup_flags >> 31) && __any(labmask != 0u);   // (wavefront-uniform) some node of this wavefront belongs to a cluster
     uint2 *wq = (uint2 *)(s_raw + (D64 ? 12 : 8) * (size_t)P + (size_t)BMW * 4) + (threadIdx.x >> 6) * (D64 ? 128 : 64);      // D64: entry i = words 2i (value), 2i + 1 (owner | accumulator)
     T vn[DENSE ? JN : JU];
 #pragma unroll
@@ -237,8 +240,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                     const unsigned long long old = atomicCAS(&ent[h], 0ull, nw);
                     if (old == 0ull) break;
                     // same key already entered by a query of the same cluster: that entry stands for this query too
-                    // (only clusters numbered below dedup_below - the large ones - share entries: a run of two or three equal keys is cheaper to walk
-                    // than a chance match on a shared entry is to expand)
+                    // (only clusters numbered below dedup_below share entries - all of them by default, JDEDUP_MINQ)
                     if (DEDUP && (tw >> JTAG_CL_SHIFT) - 1u < dedup_below - 1u && (uint32_t)old == (uint32_t)k &&
                         (((uint32_t)(old >> 32) >> JTAG_CL_SHIFT) & JCL_MAX) == (tw >> JTAG_CL_SHIFT)) {
                         atomicOr((uint32_t *)&ent[h] + 1, JTAG_MULTI);
@@ -258,6 +260,12 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
             for (int j = 0; j < JQ; j++) { const uint32_t i = threadIdx.x + (uint32_t)j * JT; if (i < nq) insert_key(0u, i, kq[j]); }
         } else {
             for (uint32_t i = threadIdx.x; i < nq * nr; i += JT) { const uint32_t r = i / nq, q = i - r * nq; insert_key(r, q, qkey[(uint64_t)(sr + r) * nq + q]); }
+        }
+        // CL: the cluster ids of the lane's eight nodes, fetched again for every slot (16 kB per workgroup: L2) so that they occupy registers only between the
+        // inserts and the push - the request is in flight across the barrier (opaque offsets: hoisted out of the slot loop they would live, and spill, through it)
+        uint2 lb0 = make_uint2(0u, 0u), lb1 = make_uint2(0u, 0u);
+        if constexpr (CL && DENSE) {
+            if (wave_lab) { uint32_t o0 = 0, o1 = JT; asm volatile("" : "+v"(o0), "+v"(o1)); lb0 = labT[o0]; lb1 = labT[o1]; }
         }
         join_lds_barrier();
 #pragma unroll 1
@@ -284,6 +292,35 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                         pend |= pass << (u0 + u);
                     }
                 }
+                if constexpr (CL) {
+                    // Own-cluster hits end HERE when the table says so in one read (round 6, skewed databases: 72 % of the nodes belong to a cluster and two thirds of their
+                    // values pass the bitmap - their own cluster's queries hold them - so the survivor path ran for 47 % of all values instead of 7 %): the entry at the
+                    // value's home position holds this key, belongs to the node's cluster and is the ONLY entry with the key (no JTAG_MORE; a cluster's equal keys share
+                    // one entry) - every hit of this value is one the block compare writes, exactly what the probe below would find and drop.
+                    if (wave_lab) {
+#pragma unroll
+                        for (int u = 0; u < JN; u++) {
+                            const uint32_t l2 = u < 4 ? ((u & 2) ? lb0.y : lb0.x) : ((u & 2) ? lb1.y : lb1.x);
+                            const uint32_t lab = (l2 >> ((u & 1) * 16)) & 0xFFFFu;
+                            if (((pend >> u) & 1u) && lab != 0u) {
+                                // (up to JWALK entries: the key may sit behind its home position - a collision - and clusters below GS_JOIN_DEDUP_MINQ queries, if that is
+                                // raised, enter their equal keys one by one; a foreign entry with the key, or a longer walk, leaves the value to the probe)
+                                uint32_t hh = join_hash(vn[u]) >> sh;
+#pragma unroll
+                                for (int j = 0; j < JWALK; j++) {
+                                    const unsigned long long en = ent[hh];
+                                    const uint32_t t = (uint32_t)(en >> 32);
+                                    if (t == 0u) { pend &= ~(1u << u); natom += GS_JOIN_COUNT_KIND == 8; break; }      // the end of the run: nobody else holds this value
+                                    if ((uint32_t)en == (uint32_t)vn[u]) {
+                                        if (((t >> JTAG_CL_SHIFT) & JCL_MAX) != lab) break;                            // a foreign (or unclustered) query holds it too
+                                        if (!(t & JTAG_MORE)) { pend &= ~(1u << u); natom += GS_JOIN_COUNT_KIND == 8; break; }
+                                    }
+                                    hh = (hh + 1) & mask;
+                                }
+                            }
+                        }
+                    }
+                }
                 while (__any(pend != 0u)) {
                     uint32_t qn = 0;
                     const uint32_t pend0 = pend;
@@ -304,6 +341,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                     }
                     join_wave_sync();
                     if constexpr (CL) {
+                        if (GS_JOIN_COUNT_KIND == 7 && lane < qn) natom++;                              // (instrumented builds: survivors that reach the probe)
                         // clusters: the same probe, but the wavefront stays together until its last lane is done, so that all 64 lanes can expand a
                         // chance match on a shared entry. The node's own cluster is looked up (L2) only when the node has one AND the entry hit
                         // belongs to a cluster: a percent of the nodes.
@@ -328,9 +366,13 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                             uint32_t nl = 0;
                                             if ((qe.y >> 29) & 1u) {
                                                 const uint32_t uo = (qe.y >> 6) & 7u, to = threadIdx.x - lane + (qe.y & 63u);
+#ifdef GS_JOIN_FAKE_LABEL                                              /* timing experiment only (wrong counts): what the look-up at hit time costs */
+                                                nl = cl + (uo & 0u) + (to & 0u);
+#else
                                                 nl = nodelab[(((uint64_t)bchunk * (JN / JU) + (uo >> 2)) * JT + to) * JU + (uo & 3u)];
+#endif
                                             }
-                                            if (nl == cl) count_it = false;                             // own cluster: the block compare writes this pair's counter
+                                            if (nl == cl) { count_it = false; natom += GS_JOIN_COUNT_KIND == 9; }      // own cluster: the block compare writes this pair's counter
                                             else if (t & JTAG_MULTI) { mitem = cl; count_it = false; }
                                         }
                                         if (count_it) {
@@ -339,7 +381,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                             const uint32_t fl = same ? (full ? st : 0u) : (weak ? st : one);
                                             st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
                                             if (fl) {
-                                                if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom++; }
+                                                if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom += GS_JOIN_COUNT_KIND == 0; }
                                                 flp = fl;
                                             }
                                         }
@@ -360,14 +402,14 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                     if (!never_equal<KIND, T>(k2) && (uint32_t)canon<KIND, T>(k2) == vsrc) {
                                         const uint64_t idx = (uint64_t)qlist[pos] * ld + e;
                                         atomicSub(&mm32[idx >> 1], 1u << ((idx & 1) * 16));
-                                        natom++;
+                                        natom += GS_JOIN_COUNT_KIND == 0;
                                     }
                                 }
                             }
                             if (!__any(have)) break;
                         }
                         if (lane < qn) {
-                            if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom++; }
+                            if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom += GS_JOIN_COUNT_KIND == 0; }
                             wq[lane].x = st;
                         }
                     } else if constexpr (D64) {
@@ -597,7 +639,11 @@ __global__ __launch_bounds__(JT) void k_match_sample(const T *__restrict__ qkey,
 constexpr uint32_t JS0 = 48, JHEAVY = 3;
 constexpr uint64_t JPAIR_CAP = (uint64_t)4 << 20, JPAIR_MAX = (uint64_t)256 << 20;      // heavy pairs listed by default (32 MB) / at most (2 GB)
 constexpr uint32_t JTILE_CAP = 24576;
-constexpr uint32_t JDEDUP_MINQ = 12;     // clusters of at least this many queries enter equal keys once (shared entries)
+constexpr uint32_t JDEDUP_MINQ = 2;      // clusters of at least this many queries enter equal keys once (shared entries): all of them since round 6 (GS_JOIN_DEDUP_MINQ).
+                                         // Round 4 kept the small ones apart (12): a chance match on a shared entry is expanded by the whole wavefront. Measured on a skewed
+                                         // database (tools/skew_probe.py, 2500 x 100 k, 197 clusters of 8.8 queries on average): such expansions are rare - 35 189 per batch at
+                                         // 2 against 3 471 at 12 - while the runs of equal keys the small clusters left behind were walked by every own-cluster survivor:
+                                         // cluster-aware join 19.3 ms at 12, 16.5 at 8, 11.4 at 4, 9.4 at 2 (with the in-place own-cluster test of k_match_join)
 
 // tiles of 8 consecutive counters per lane x 256 lanes; a workgroup walks many tiles, stages the heavy pairs it finds in LDS and sends them to
 // the list in blocks (a first version paid one same-address global atomic per wavefront and tile: 1.1e6 of them, 10 ms per batch)
@@ -891,8 +937,9 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
             chosen.push_back(l); ntiles += tiles_of(l); nhq += cq[l]; nhe += ce_[l];
         }
         // cluster ids: the large clusters (>= JDEDUP_MINQ queries) first - only they share table entries
-        std::stable_sort(chosen.begin(), chosen.end(), [&](uint32_t a, uint32_t b) { return (cq[a] >= JDEDUP_MINQ) > (cq[b] >= JDEDUP_MINQ); });
-        for (uint32_t l : chosen) { cid[l] = ++K; if (cq[l] >= JDEDUP_MINQ) dedup_below = K + 1; }
+        const uint32_t dq = getenv("GS_JOIN_DEDUP_MINQ") ? (uint32_t)std::max(2, atoi(getenv("GS_JOIN_DEDUP_MINQ"))) : JDEDUP_MINQ;
+        std::stable_sort(chosen.begin(), chosen.end(), [&](uint32_t a, uint32_t b) { return (cq[a] >= dq) > (cq[b] >= dq); });
+        for (uint32_t l : chosen) { cid[l] = ++K; if (cq[l] >= dq) dedup_below = K + 1; }
     }
     // (query, node) pairs the blocks take off the match-by-match path; a handful is not worth a second kernel variant and the tile launch
     uint64_t saved_pairs = 0;
@@ -958,8 +1005,11 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     hipLaunchKernelGGL((k_query_cols_list<T>), dim3((nhq + 31) / 32, (m + 31) / 32), dim3(256), 0, c->stream, qrows, qstride, dql.as<uint32_t>(), nhq, m, dqs.as<T>());
     GS_HIP_CHECK(hipGetLastError());
     lap("uploads + sorted key copy");
+    // the in-place own-cluster test of k_match_join pays where a good part of the NODES belongs to clusters (a skewed database: 72 %); with a percent of them (isolates of a few
+    // species against a uniform database) nearly every wavefront still holds one such node and pays the test's fixed part for nothing: +6 ms per request_redundant step
+    const bool inplace = getenv("GS_JOIN_INPLACE") ? atoi(getenv("GS_JOIN_INPLACE")) != 0 : nhe * 10 >= n;
     if ((rc = join_launch<KIND, T, true>(c, g, k0.as<T>(), nq, cols, colcap, n, JS0, m, out16, ld, stats, 0, false, dqcl.as<uint16_t>(), dnl.as<uint16_t>(), dqs.as<T>(), nhq,
-                                         dcl.as<uint32_t>(), dql.as<uint32_t>(), dedup_below))) return rc;
+                                         dcl.as<uint32_t>(), dql.as<uint32_t>(), dedup_below | (inplace ? 0x80000000u : 0u)))) return rc;
     {
         ProfScope ps(c, FAM_HAMMING);
         lap("cluster-aware join");
