@@ -175,6 +175,89 @@ __global__ __launch_bounds__(256) void k_hamming_qxc(const uint32_t *__restrict_
     }
 }
 
+// ---- thin blocks --------------------------------------------------------------------------------------
+// Work-list items with at most HTQ query rows (a cluster of a few isolates against the hundreds or thousands of genomes of its family: most blocks of a skewed
+// database, bench leg request_skewed). The tile kernel above spends a 128 x 128 tile's LDS traffic on them whatever their height (its THIN path: 9 LDS reads per 16
+// VALU instructions); here nothing goes through LDS: a wavefront takes HTR candidate rows, lane l the words 4 l .. 4 l + 3 of every 256-word step of
+// those rows (one 16-byte load each, coalesced) and of each query row (the cluster's <= 16 rows: re-read by every pass, L2-resident), 2 VALU instructions per
+// (query, candidate) word pair into per-lane counters, one wavefront reduction at the end. 4-byte elements with 16-byte aligned rows only (hamming_blocks).
+constexpr int HTQ = 16;     // query rows of a thin item at most
+constexpr int HTR = 4;      // candidate rows per wavefront
+constexpr int HTS = HT / (4 * HTR);     // workgroups per item
+#define GS_CMP4(OP)                                                                                                   \
+    asm volatile(OP " vcc, %4, %5\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"                                           \
+                 OP " vcc, %4, %6\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"                                           \
+                 OP " vcc, %4, %7\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"                                           \
+                 OP " vcc, %4, %8\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc"                                               \
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)                                                              \
+                 : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3)                                                          \
+                 : "vcc")
+template <int KIND>
+__device__ __forceinline__ void cmp_acc4(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t a, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    if (KIND == GS_KIND_F32) GS_CMP4("v_cmp_neq_f32");
+    else GS_CMP4("v_cmp_ne_u32");
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void k_hamming_thin(const uint32_t *__restrict__ Q, uint64_t strideQ, const uint32_t *__restrict__ C, uint64_t strideC, uint32_t m,
+                                                       uint16_t *__restrict__ out_cnt16, uint64_t ld_out, const uint4 *__restrict__ items, const uint32_t *__restrict__ qlist,
+                                                       const uint32_t *__restrict__ clist)
+{
+    // grid: HTS workgroups per item, each with 4 x HTR = 16 of its candidate rows - a few hundred items of 128 rows would leave the chip at one or two workgroups per CU,
+    // and the kernel has nothing but other wavefronts to hide its load latency behind
+    const uint4 it = items[blockIdx.x / HTS];                     // {first entry of qlist, query rows (<= HTQ), first entry of clist, candidate rows (<= 128)}
+    const uint32_t nqr = it.y, ncr = it.w, lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t steps = (m + 255) / 256;
+    {
+        const uint32_t r0 = (blockIdx.x % HTS) * 4 * HTR + wv * HTR;   // (wavefront-uniform) this wavefront's candidate rows of the item
+        if (r0 >= ncr) return;
+        uint32_t cnt[HTR][HTQ];
+#pragma unroll
+        for (int r = 0; r < HTR; r++)
+#pragma unroll
+            for (int q = 0; q < HTQ; q++) cnt[r][q] = 0;
+        const uint32_t *cp[HTR];
+#pragma unroll
+        for (int r = 0; r < HTR; r++) cp[r] = C + (uint64_t)clist[it.z + (r0 + r < ncr ? r0 + r : ncr - 1)] * strideC;      // (clamped rows: results discarded)
+        for (uint32_t s = 0; s < steps; s++) {
+            const uint32_t w = s * 256 + lane * 4;
+            const bool in = w + 4 <= m;                            // (m is a multiple of 4 here or the last lanes fall back to word loads below)
+            uint4 cb[HTR];
+#pragma unroll
+            for (int r = 0; r < HTR; r++) {
+                if (in) cb[r] = *(const uint4 *)(cp[r] + w);
+                else { cb[r].x = w < m ? cp[r][w] : 0u; cb[r].y = w + 1 < m ? cp[r][w + 1] : 0u; cb[r].z = w + 2 < m ? cp[r][w + 2] : 0u; cb[r].w = 0u; }      // past the row end: equal on both sides
+            }
+#pragma unroll
+            for (int q = 0; q < HTQ; q++) {
+                if ((uint32_t)q < nqr) {                           // (workgroup-uniform)
+                    const uint32_t *qp = Q + (uint64_t)qlist[it.x + q] * strideQ;
+                    uint4 qa;
+                    if (in) qa = *(const uint4 *)(qp + w);
+                    else { qa.x = w < m ? qp[w] : 0u; qa.y = w + 1 < m ? qp[w + 1] : 0u; qa.z = w + 2 < m ? qp[w + 2] : 0u; qa.w = 0u; }
+                    cmp_acc4<KIND>(cnt[0][q], cnt[1][q], cnt[2][q], cnt[3][q], qa.x, cb[0].x, cb[1].x, cb[2].x, cb[3].x);
+                    cmp_acc4<KIND>(cnt[0][q], cnt[1][q], cnt[2][q], cnt[3][q], qa.y, cb[0].y, cb[1].y, cb[2].y, cb[3].y);
+                    cmp_acc4<KIND>(cnt[0][q], cnt[1][q], cnt[2][q], cnt[3][q], qa.z, cb[0].z, cb[1].z, cb[2].z, cb[3].z);
+                    cmp_acc4<KIND>(cnt[0][q], cnt[1][q], cnt[2][q], cnt[3][q], qa.w, cb[0].w, cb[1].w, cb[2].w, cb[3].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < HTQ; q++) {
+            if ((uint32_t)q < nqr) {
+                const uint64_t orow = (uint64_t)qlist[it.x + q] * ld_out;
+#pragma unroll
+                for (int r = 0; r < HTR; r++) {
+                    uint32_t v = cnt[r][q];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+                    if (lane == 0 && r0 + r < ncr) out_cnt16[orow + clist[it.z + r0 + r]] = (uint16_t)v;
+                }
+            }
+        }
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k_hamming_pairs(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, const uint64_t *__restrict__ ia,
                                                         const uint64_t *__restrict__ ib, uint64_t npairs, uint32_t m, float *__restrict__ out)
@@ -241,13 +324,26 @@ __global__ __launch_bounds__(256) void k_blocks_set(const uint4 *__restrict__ it
     }
 }
 // the tiles of a work list (see k_hamming_qxc IDX): n_items x {qlist offset, rows (<= 128), clist offset, rows (<= 128)}, all in device memory
+// n_thin: the first n_thin items have at most HTQ (16) query rows - they go to k_hamming_thin where it applies (4-byte elements, 16-byte aligned rows)
 int hamming_blocks(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t strideQ_bytes, const void *C, uint64_t strideC_bytes, const void *items_dev,
-                   uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out)
+                   uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out, uint32_t n_thin)
 {
     if (n_items == 0) return GS_OK;
     GS_REQUIRE(kind == GS_KIND_F32 || kind == GS_KIND_U32 || kind == GS_KIND_U64, GS_ERR_UNSUPPORTED, "DistHamming kind %d not on the device path", kind);
+    GS_REQUIRE(n_thin <= n_items, GS_ERR_INVALID, "bad argument");
     const uint64_t sq = strideQ_bytes / 4, sc = strideC_bytes / 4;
     const bool vec4 = (strideQ_bytes % 16 == 0) && (strideC_bytes % 16 == 0) && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)C % 16 == 0);
+    if (n_thin && vec4 && kind != GS_KIND_U64 && !getenv("GS_BLOCKS_THIN_OFF")) {
+        ProfScope ps(c, FAM_HAMMING);
+        if (kind == GS_KIND_F32)
+            hipLaunchKernelGGL(k_hamming_thin<GS_KIND_F32>, dim3(n_thin * HTS), dim3(256), 0, c->stream, (const uint32_t *)Q, sq, (const uint32_t *)C, sc, m, out_cnt16, ld_out, (const uint4 *)items_dev, qlist_dev, clist_dev);
+        else
+            hipLaunchKernelGGL(k_hamming_thin<GS_KIND_U32>, dim3(n_thin * HTS), dim3(256), 0, c->stream, (const uint32_t *)Q, sq, (const uint32_t *)C, sc, m, out_cnt16, ld_out, (const uint4 *)items_dev, qlist_dev, clist_dev);
+        GS_HIP_CHECK(hipGetLastError());
+        items_dev = (const uint4 *)items_dev + n_thin;
+        n_items -= n_thin;
+        if (n_items == 0) return GS_OK;
+    }
     dim3 grid(n_items), block(256);
     // few tiles (thirty species in a batch = thirty tiles): the rows are split over blockIdx.z so that the whole chip works on them
     uint32_t ksplit_words = 0;

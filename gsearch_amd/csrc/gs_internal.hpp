@@ -156,7 +156,7 @@ int match_join_counts(gs_ctx *c, int kind, uint32_t m, const void *qrows, uint64
                       uint16_t *out16, uint64_t ld, DevBuf *scratch, int *declined = nullptr, unsigned long long *stats = nullptr, bool init = true, uint64_t col0 = 0,
                       const void *rows = nullptr, uint64_t rstride = 0);
 int hamming_blocks(gs_ctx *c, int kind, uint32_t m, const void *Q, uint64_t strideQ_bytes, const void *C, uint64_t strideC_bytes, const void *items_dev,
-                   uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out);
+                   uint32_t n_items, const uint32_t *qlist_dev, const uint32_t *clist_dev, uint16_t *out_cnt16, uint64_t ld_out, uint32_t n_thin = 0);
 int rows_to_cols(gs_ctx *c, int kind, uint32_t m, const void *rows, uint64_t stride, uint64_t nrows, void *cols, uint64_t colcap, uint64_t first);
 
 // gs_sketch.hip: the device sketch of a batch on context c's stream; sync_at_end = false leaves the results in flight (optdens / revoptdens only)

@@ -987,10 +987,18 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     }
     std::vector<uint4> tiles;
     tiles.reserve(ntiles);
-    for (uint32_t k = 1; k <= K; k++)
-        for (uint32_t a = cl_lo[k]; a < cl_lo[k + 1]; a += HTILE)
-            for (uint32_t b = ce_lo[k]; b < ce_lo[k + 1]; b += HTILE)
-                tiles.push_back(make_uint4(a, std::min<uint32_t>(HTILE, cl_lo[k + 1] - a), b, std::min<uint32_t>(HTILE, ce_lo[k + 1] - b)));
+    // the thin tiles first (at most 16 query rows - most clusters of a skewed database: hamming_blocks has a kernel of its own for them), then the others
+    uint32_t n_thin = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t k = 1; k <= K; k++)
+            for (uint32_t a = cl_lo[k]; a < cl_lo[k + 1]; a += HTILE) {
+                const uint32_t qr = std::min<uint32_t>(HTILE, cl_lo[k + 1] - a);
+                if ((qr <= 16) != (pass == 0)) continue;
+                for (uint32_t b = ce_lo[k]; b < ce_lo[k + 1]; b += HTILE) {
+                    tiles.push_back(make_uint4(a, qr, b, std::min<uint32_t>(HTILE, ce_lo[k + 1] - b)));
+                    n_thin += pass == 0;
+                }
+            }
     lap("host: lists");
     DevBuf &dqcl = scratch[6], &dnl = scratch[7], &dql = scratch[8], &del = scratch[9], &dtl = scratch[10], &dqs = scratch[11], &dcl = scratch[13];
     if ((rc = dqcl.ensure(2 * (size_t)nq)) || (rc = dnl.ensure(2 * (size_t)npad)) || (rc = dql.ensure(4 * (size_t)nhq)) || (rc = del.ensure(4 * (size_t)nhe)) ||
@@ -1013,7 +1021,7 @@ static int join_impl(gs_ctx *c, uint32_t m, const uint8_t *qrows, uint64_t qstri
     {
         ProfScope ps(c, FAM_HAMMING);
         lap("cluster-aware join");
-        if ((rc = hamming_blocks(c, KIND, m, qrows, qstride, rows, rstride, dtl.p, (uint32_t)tiles.size(), dql.as<uint32_t>(), del.as<uint32_t>(), out16, ld))) return rc;
+        if ((rc = hamming_blocks(c, KIND, m, qrows, qstride, rows, rstride, dtl.p, (uint32_t)tiles.size(), dql.as<uint32_t>(), del.as<uint32_t>(), out16, ld, n_thin))) return rc;
         lap("block compare");
     }
     return GS_OK;

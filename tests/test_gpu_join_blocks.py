@@ -77,6 +77,55 @@ def test_count_matrix_of_redundant_batches(gpu_ctx, monkeypatch, capfd, dtype, m
     hn.close()
 
 
+@pytest.mark.parametrize("dtype,m", [(np.float32, 800), (np.uint32, 1000), (np.float32, 802)])
+def test_count_matrix_on_a_skewed_database_of_small_clusters(gpu_ctx, monkeypatch, capfd, dtype, m):
+    """round 6, skewed databases: families of 40 .. 1500 genomes with 2 .. 16 isolates each in the batch (clusters by related PAIRS, gs_join.hip) - the regime in which most
+    nodes belong to a cluster and most blocks are a few query rows high. Exercises the in-place own-cluster test of k_match_join (>= 10 % of the nodes clustered), shared
+    table entries for every cluster (GS_JOIN_DEDUP_MINQ default 2), and k_hamming_thin (blocks of <= 16 query rows; m = 802: rows not 16-byte aligned, the tile kernel's
+    THIN path takes them). The count matrix must equal the oracle's for every pair, and stay the same with each of the three switched off."""
+    import gsearch_amd as G
+    rng = np.random.default_rng(m)
+    universe = 1500
+    def rnd(shape):
+        v = rng.integers(0, universe, shape)
+        return v.astype(np.float32) if np.dtype(dtype) == np.float32 else v.astype(dtype)
+    sizes = [1500, 1300, 1000, 800] + list(rng.integers(80, 260, 34))       # (the cluster path wants >= 8192 nodes and >= 256 queries)
+    isolates = [16, 9, 5, 3] + list(rng.integers(2, 9, 33)) + [40]        # the last family: a block 40 rows high (not thin)
+    roots = rnd((len(sizes), m))
+    db = np.repeat(roots, sizes, axis=0)
+    mk = rng.random(db.shape) > rng.uniform(0.3, 0.95, (len(db), 1))
+    db[mk] = rnd(db.shape)[mk]
+    q = np.repeat(roots, isolates, axis=0)
+    mk = rng.random(q.shape) > rng.uniform(0.3, 0.98, (len(q), 1))
+    q[mk] = rnd(q.shape)[mk]
+    q = np.concatenate([q, rnd((60, m)), db[[3, 3, 2000]]])              # unrelated rows, twins of a node
+    assert len(db) >= 8192 and len(q) >= 256
+    if np.dtype(dtype) == np.float32:
+        q[1, :30] = np.nan; q[2, 30:50] = -0.0; db[7, 30:50] = 0.0; db[8, :6] = np.nan
+    db = np.ascontiguousarray(db[rng.permutation(len(db))]); q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    n = len(db)
+    want = _oracle_counts(q, db, m)
+    hn = G.Hnsw.new(8, n, 16, 16, G.DistHamming(), dtype=dtype, seed=1)
+    hn.import_graph(db, _isolated_graph(n, 8))
+    monkeypatch.setenv("GS_JOIN_VERBOSE", "1")
+    monkeypatch.setenv("GS_JOIN_CLUSTER_MIN", "0")
+    capfd.readouterr()
+    got = hn.count_matrix(q)
+    err = capfd.readouterr().err
+    assert "clusters" in err and " 0 clusters" not in err, err
+    ncl = int(err.split(" clusters,")[0].split()[-1])
+    assert ncl >= 20, err                                                  # the small families became clusters (pair rule), not only the 40-isolate one
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, (len(bad), bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+    for env in ({"GS_JOIN_INPLACE": "0"}, {"GS_BLOCKS_THIN_OFF": "1"}, {"GS_JOIN_DEDUP_MINQ": "12"}, {"GS_JOIN_INPLACE": "1", "GS_JOIN_DEDUP_MINQ": "5"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert np.array_equal(hn.count_matrix(q), want), env
+        for k in env:
+            monkeypatch.delenv(k)
+    hn.close()
+
+
 def test_heavy_blocks_with_everything_related(gpu_ctx, monkeypatch, capfd):
     """degenerate batches: every query related to every node (one giant component), and a value band so narrow that chance matches alone
     make pairs heavy (random merges of unrelated components) - any labelling must give the oracle's counts"""
