@@ -181,7 +181,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
     // one 8-byte load per lane and group of four nodes), fetched again for every slot beside the column values - all eight labels resident would
     // cost four more registers than the 64 this kernel may use, and a look-up at hit time stalled the wavefront on every own-cluster hit (round 4:
     // 201 ms instead of 126 per request when a fifth of the nodes belong to clusters)
-    const uint2 *labT = CL ? (const uint2 *)nodelab + (uint64_t)bchunk * (JN / JU) * JT + threadIdx.x : nullptr;
+    const uint2 *labT = CL ? (const uint2 *)nodelab + (uint64_t)bchunk * (JN / JU) * JT : nullptr;      // (workgroup-uniform: + the lane at each use)
     uint32_t sticky[JN];
     uint32_t natom = 0;                                           // memory-side atomics this lane sends (work counter for the bench's roofline)
     uint32_t nexp = 0;                                            // CL: chance matches on shared entries this wavefront expanded
@@ -192,12 +192,14 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
     uint32_t vmask = 0;
 #pragma unroll
     for (int u = 0; u < JN; u++) vmask |= (uint32_t)(e0 + (uint64_t)u * JT < n) << u;
-    const uint64_t ebase = col0 + e0;
+    // (the matrix column of a node = a workgroup-uniform base + a 32-bit lane part, added where an atomic is sent: a per-lane 64-bit base lived through the whole slot loop)
+    const uint64_t ebase_u = col0 + (uint64_t)bchunk * (JT * JN);
+    const uint32_t tid = threadIdx.x;
     uint32_t labmask = 0;                                         // CL: which of the lane's nodes belong to a cluster at all (labels do not change from slot to slot)
     if (CL && DENSE) {
 #pragma unroll
         for (int it = 0; it < JN / JU; it++) {
-            const uint2 l4 = labT[it * JT];
+            const uint2 l4 = labT[it * JT + threadIdx.x];
             labmask |= ((uint32_t)((l4.x & 0xFFFFu) != 0u) | (uint32_t)((l4.x >> 16) != 0u) << 1 | (uint32_t)((l4.y & 0xFFFFu) != 0u) << 2 | (uint32_t)((l4.y >> 16) != 0u) << 3) << (it * JU);
         }
     }
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
         // (scalar bases + an offset the compiler cannot hoist: kept across the slot loop, the four per-lane offsets were spilled and every reload waited)
         constexpr int JQ = DENSE ? (int)((((1u << JP_MAX_LOG2) * 2) / 5 + JT - 1) / JT) : 1;
         T kq[JQ];
+        uint32_t tq[(JQ + 1) / 2] = {};
         if (DENSE) {
             typedef const T __attribute__((address_space(1))) *gptr;
             const uint64_t qb = (uint64_t)(qkey + (uint64_t)sr * nq);
@@ -221,14 +224,20 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
             asm volatile("" : "+v"(o));
 #pragma unroll
             for (int j = 0; j < JQ; j++) { const gptr qj = qk + j * JT; kq[j] = o + (uint32_t)j * JT < nq ? qj[o] : (T)0; }
+            // CL: the cluster ids of the lane's queries, requested with the keys (two per register). Read inside insert_key they were four global loads per slot, each
+            // waited for where it stood: ~15 VMEM wave-instructions per wavefront and slot more than the plain kernel (profiles/r06_join_cl_pmc_bench.txt)
+            if constexpr (CL) {
+#pragma unroll
+                for (int j = 0; j < JQ; j++) { const uint32_t i = o + (uint32_t)j * JT; tq[j >> 1] |= (i < nq ? (uint32_t)qcl[i] : 0u) << ((j & 1) * 16); }
+            }
         }
         join_lds_barrier();                                       // the previous round's probes are done
         if (E8) { for (uint32_t i = threadIdx.x; i < P; i += JT) ent[i] = 0ull; }
         else for (uint32_t i = threadIdx.x; i < P * SR; i += JT) tag[i] = 0;
         for (uint32_t i = threadIdx.x; i < BMW * SR; i += JT) bm[i] = 0;
         join_lds_barrier();
-        auto insert_key = [&](const uint32_t r, const uint32_t q, T k) {
-            const uint32_t tw = CL ? (q + 1) | ((uint32_t)qcl[q] << JTAG_CL_SHIFT) : q + 1;
+        auto insert_key = [&](const uint32_t r, const uint32_t q, T k, const uint32_t clq) {
+            const uint32_t tw = CL ? (q + 1) | (clq << JTAG_CL_SHIFT) : q + 1;
             if (never_equal<KIND, T>(k)) return;
             k = canon<KIND, T>(k);
             const uint32_t hq = join_hash(k);
@@ -257,15 +266,15 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
         };
         if (DENSE) {
 #pragma unroll
-            for (int j = 0; j < JQ; j++) { const uint32_t i = threadIdx.x + (uint32_t)j * JT; if (i < nq) insert_key(0u, i, kq[j]); }
+            for (int j = 0; j < JQ; j++) { const uint32_t i = threadIdx.x + (uint32_t)j * JT; if (i < nq) insert_key(0u, i, kq[j], (tq[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu); }
         } else {
-            for (uint32_t i = threadIdx.x; i < nq * nr; i += JT) { const uint32_t r = i / nq, q = i - r * nq; insert_key(r, q, qkey[(uint64_t)(sr + r) * nq + q]); }
+            for (uint32_t i = threadIdx.x; i < nq * nr; i += JT) { const uint32_t r = i / nq, q = i - r * nq; insert_key(r, q, qkey[(uint64_t)(sr + r) * nq + q], CL ? (uint32_t)qcl[q] : 0u); }
         }
         // CL: the cluster ids of the lane's eight nodes, fetched again for every slot (16 kB per workgroup: L2) so that they occupy registers only between the
         // inserts and the push - the request is in flight across the barrier (opaque offsets: hoisted out of the slot loop they would live, and spill, through it)
         uint2 lb0 = make_uint2(0u, 0u), lb1 = make_uint2(0u, 0u);
         if constexpr (CL && DENSE) {
-            if (wave_lab) { uint32_t o0 = 0, o1 = JT; asm volatile("" : "+v"(o0), "+v"(o1)); lb0 = labT[o0]; lb1 = labT[o1]; }
+            if (wave_lab) { uint32_t o0 = threadIdx.x, o1 = JT + threadIdx.x; asm volatile("" : "+v"(o0), "+v"(o1)); lb0 = labT[o0]; lb1 = labT[o1]; }
         }
         join_lds_barrier();
 #pragma unroll 1
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                             const uint32_t fl = same ? (full ? st : 0u) : (weak ? st : one);
                                             st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
                                             if (fl) {
-                                                if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom += GS_JOIN_COUNT_KIND == 0; }
+                                                if (flp) { join_flush(mm32, ld, flp, ebase_u + (tid - lane + eloc)); natom += GS_JOIN_COUNT_KIND == 0; }
                                                 flp = fl;
                                             }
                                         }
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                 pm &= pm - 1;
                                 nexp++;
                                 const uint32_t cl = __builtin_amdgcn_readlane(mitem, src), vsrc = __builtin_amdgcn_readlane(qe.x, src);
-                                const uint64_t e = ebase - lane + __builtin_amdgcn_readlane(eloc, src);
+                                const uint64_t e = ebase_u + (tid - lane + __builtin_amdgcn_readlane(eloc, src));
                                 const uint32_t lo = cl_lo[cl], hi = cl_lo[cl + 1];
                                 for (uint32_t pos = lo + lane; pos < hi; pos += 64) {
                                     const T k2 = qs[(uint64_t)s * nh + pos];
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                             if (!__any(have)) break;
                         }
                         if (lane < qn) {
-                            if (flp) { join_flush(mm32, ld, flp, ebase + eloc - lane); natom += GS_JOIN_COUNT_KIND == 0; }
+                            if (flp) { join_flush(mm32, ld, flp, ebase_u + (tid - lane + eloc)); natom += GS_JOIN_COUNT_KIND == 0; }
                             wq[lane].x = st;
                         }
                     } else if constexpr (D64) {
@@ -429,13 +438,13 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                     const uint32_t fl = same ? (full ? st : 0u) : (weak ? st : one);
                                     st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
                                     if (fl) {
-                                        if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                                        if (flp) { join_flush(mm32, ld, flp, ebase_u + (tid + eo)); natom++; }
                                         flp = fl;
                                     }
                                 }
                                 hh = (hh + 1) & mask;
                             }
-                            if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom++; }
+                            if (flp) { join_flush(mm32, ld, flp, ebase_u + (tid + eo)); natom++; }
                             wq[2 * lane + 1].x = st;
                         }
                     } else
@@ -460,14 +469,14 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                 if (GS_JOIN_COUNT_KIND == 6 && same) natom++;
                                 st = same ? (full ? one : st + 0x1000u) : (weak ? one : st);
                                 if (fl) {
-                                    if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom += GS_JOIN_COUNT_KIND == 0; }
+                                    if (flp) { join_flush(mm32, ld, flp, ebase_u + (tid + eo)); natom += GS_JOIN_COUNT_KIND == 0; }
                                     flp = fl;
                                 }
                                 if (!(t & JTAG_MORE)) break;                                // the last entry with this key
                             }
                             hh = (hh + 1) & mask;
                         }
-                        if (flp) { join_flush(mm32, ld, flp, ebase + eo); natom += GS_JOIN_COUNT_KIND == 0; }
+                        if (flp) { join_flush(mm32, ld, flp, ebase_u + (tid + eo)); natom += GS_JOIN_COUNT_KIND == 0; }
                         wq[lane].x = st;
                     }
                     join_wave_sync();
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
 #pragma unroll
             for (int it = 0; it < JN / JU; it++) {
                 uint2 lab4 = make_uint2(0u, 0u);
-                if (CL) { uint32_t o = it * JT; asm volatile("" : "+v"(o)); lab4 = labT[o]; }      // (opaque offset: reloaded per slot, not kept live)
+                if (CL) { uint32_t o = it * JT + threadIdx.x; asm volatile("" : "+v"(o)); lab4 = labT[o]; }      // (opaque offset: reloaded per slot, not kept live)
                 // (the four bitmap words are read unconditionally and together: behind `&&` each read sat in its own branch with its own wait)
                 T v[JU]; uint32_t hs[JU]; uint32_t pend = 0; uint32_t bw[JU];
 #pragma unroll
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
         }
     }
 #pragma unroll
-    for (int i = 0; i < JN; i++) if (sticky[i]) { join_flush(mm32, ld, sticky[i], col0 + e0 + (uint64_t)i * JT); natom += GS_JOIN_COUNT_KIND == 0 || (GS_JOIN_COUNT_KIND == 3 && sticky[i] >= 0x2000u) || (GS_JOIN_COUNT_KIND == 4 && sticky[i] < 0x2000u); }
+    for (int i = 0; i < JN; i++) if (sticky[i]) { join_flush(mm32, ld, sticky[i], ebase_u + (tid + (uint32_t)i * JT)); natom += GS_JOIN_COUNT_KIND == 0 || (GS_JOIN_COUNT_KIND == 3 && sticky[i] >= 0x2000u) || (GS_JOIN_COUNT_KIND == 4 && sticky[i] < 0x2000u); }
     if (stats) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) natom += __shfl_down(natom, o);
