@@ -166,3 +166,13 @@ def test_search_of_redundant_batch_matches_oracle(gpu_ctx, monkeypatch, cluster)
     got, want = hn.search_arrays(base, 10, 80), oix.parallel_search(base, 10, 80, nthreads=os.cpu_count())
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+def test_count_matrix_differential_run_over_random_redundant_and_skewed_shapes():
+    """tools/join_fuzz.py (round 6): the count matrix of a request batch against the oracle over random element types, sketch sizes (aligned rows or not), family-size laws,
+    isolates per family, value universes and join knobs (in-place own-cluster test on / off, shared-entry threshold, thin blocks off, pair bar, cluster rule). 14 cases, bounded."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "join_fuzz.py"), "14", "7"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "14 cases, 0 mismatches" in out.stdout, out.stdout[-1500:]
