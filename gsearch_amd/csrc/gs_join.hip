@@ -375,11 +375,7 @@ __global__ __launch_bounds__(JT, (sizeof(T) == 8 && SR == 1) ? 4 : 8) void k_mat
                                             uint32_t nl = 0;
                                             if ((qe.y >> 29) & 1u) {
                                                 const uint32_t uo = (qe.y >> 6) & 7u, to = threadIdx.x - lane + (qe.y & 63u);
-#ifdef GS_JOIN_FAKE_LABEL                                              /* timing experiment only (wrong counts): what the look-up at hit time costs */
-                                                nl = cl + (uo & 0u) + (to & 0u);
-#else
                                                 nl = nodelab[(((uint64_t)bchunk * (JN / JU) + (uo >> 2)) * JT + to) * JU + (uo & 3u)];
-#endif
                                             }
                                             if (nl == cl) { count_it = false; natom += GS_JOIN_COUNT_KIND == 9; }      // own cluster: the block compare writes this pair's counter
                                             else if (t & JTAG_MULTI) { mitem = cl; count_it = false; }
