@@ -1121,7 +1121,8 @@ def redundant_leg(args, ctx, hn, lib, chk, torch, sketch_dev, d_rs, d_rl, d_goff
             ctx.profile(False)
             st = hn.search_stats(reset=True)
             if i:
-                steps.append({"ms": dt * 1e3, "sketch_ms": sk[0], "producer_ms": prod[0], "producer_launches": prod[1], "traversal_ms": srch[0], "join_atomics": st.get("join_atomics", 0)})
+                steps.append({"ms": dt * 1e3, "sketch_ms": sk[0], "producer_ms": prod[0], "producer_launches": prod[1], "traversal_ms": srch[0], "join_atomics": st.get("join_atomics", 0),
+                              "join_shared_entry_expansions": st.get("join_shared_expansions", 0)})
         best = min(steps, key=lambda x: x["ms"])
         ns = 32
         qsig = ctx.download(d_sig, (qps, m), np.float32)[:ns]
@@ -1190,7 +1191,8 @@ def skewed_leg(args, ctx, lib, chk, d_rs, d_rl, d_goff, gbytes, headline_ms):
                 st = hs.search_stats(reset=True)
                 if i:
                     steps.append({"ms": dt * 1e3, "sketch_ms": sk[0], "producer_ms": prod[0], "producer_launches": prod[1], "traversal_ms": srch[0],
-                                  "join_atomics": int(st.get("join_atomics", 0)), "pops_per_query": st.get("pops", 0) / qps})
+                                  "join_atomics": int(st.get("join_atomics", 0)), "join_shared_entry_expansions": int(st.get("join_shared_expansions", 0)),
+                                  "pops_per_query": st.get("pops", 0) / qps})
             if prev is None:
                 os.environ.pop("GS_DIST_MODE", None)
             else:
